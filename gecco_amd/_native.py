@@ -1,0 +1,321 @@
+"""ctypes binding of the C ABI in ``include/gecco_crf.h`` (``gecco_amd/lib/libgecco_crf.so``).
+
+This is the stub a GECCO maintainer would add on the reference side: it
+replaces the per-window python-crfsuite crossing at ``gecco/crf/__init__.py:253`` with one
+call per batch of contigs.  There is no CPU fallback: if the library cannot be loaded the
+import error propagates, and compute calls on a box without a HIP device raise.
+"""
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgecco_crf.so")
+
+OK, EINVAL, EFORMAT, ENOMEM, EHIP, ENODEV, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+
+_c_i32p = ctypes.POINTER(ctypes.c_int32)
+_c_f64p = ctypes.POINTER(ctypes.c_double)
+_c_u8p = ctypes.POINTER(ctypes.c_uint8)
+_c_i8p = ctypes.POINTER(ctypes.c_int8)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol include/gecco_crf.h declares
+SIGNATURES = {
+    "gecco_crf_last_error": (ctypes.c_char_p, []),
+    "gecco_crf_version": (ctypes.c_int, []),
+    "gecco_crf_model_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "gecco_crf_model_from_tables": (ctypes.c_int, [_c_f64p, _c_f64p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_vp)]),
+    "gecco_crf_model_free": (None, [_vp]),
+    "gecco_crf_model_num_labels": (ctypes.c_int32, [_vp]),
+    "gecco_crf_model_num_attrs": (ctypes.c_int32, [_vp]),
+    "gecco_crf_model_num_features": (ctypes.c_int32, [_vp]),
+    "gecco_crf_model_label_name": (ctypes.c_char_p, [_vp, ctypes.c_int32]),
+    "gecco_crf_model_attr_name": (ctypes.c_char_p, [_vp, ctypes.c_int32]),
+    "gecco_crf_model_label_id": (ctypes.c_int32, [_vp, ctypes.c_char_p]),
+    "gecco_crf_model_attr_id": (ctypes.c_int32, [_vp, ctypes.c_char_p]),
+    "gecco_crf_model_map_attrs": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int32, _c_i32p]),
+    "gecco_crf_model_state_weights": (ctypes.c_int, [_vp, _c_f64p, _c_u8p]),
+    "gecco_crf_model_trans_weights": (ctypes.c_int, [_vp, _c_f64p, _c_u8p]),
+    "gecco_crf_device_count": (ctypes.c_int, [_c_i32p]),
+    "gecco_crf_windowed_marginals": (
+        ctypes.c_int,
+        [_vp, ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+         ctypes.c_int32, _c_f64p],
+    ),
+    "gecco_crf_marginals_full": (ctypes.c_int, [_vp, ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, _c_f64p, _c_f64p]),
+    "gecco_crf_viterbi": (ctypes.c_int, [_vp, ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, _c_i8p, _c_f64p]),
+    "gecco_crf_segment": (
+        ctypes.c_int,
+        [ctypes.c_int32, _c_f64p, _c_u8p, _c_i32p, ctypes.c_int32, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
+         ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p],
+    ),
+    "gecco_crf_plan_create": (
+        ctypes.c_int, [_vp, ctypes.c_int32, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_vp)]
+    ),
+    "gecco_crf_plan_free": (None, [_vp]),
+    "gecco_crf_plan_num_genes": (ctypes.c_int32, [_vp]),
+    "gecco_crf_plan_num_windows": (ctypes.c_int64, [_vp]),
+    "gecco_crf_plan_num_tiles": (ctypes.c_int32, [_vp]),
+    "gecco_crf_plan_kernel_name": (ctypes.c_char_p, [_vp]),
+    "gecco_crf_plan_run_windowed": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp]),
+    "gecco_crf_plan_run_marginals_full": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "gecco_crf_plan_run_viterbi": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "gecco_crf_plan_time_windowed": (
+        ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]
+    ),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen the native library and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} not found: build it with `python -m gecco_amd.build` (hipcc, gfx950). "
+            "gecco_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{msg} (gecco_crf status {code})")
+        self.code = code
+
+
+def _check(rc: int) -> None:
+    if rc == OK:
+        return
+    msg = load_library().gecco_crf_last_error().decode("utf-8", "replace")
+    if rc == EINVAL:
+        raise ValueError(msg)
+    if rc == EFORMAT:
+        raise ValueError(msg)
+    if rc == ENOMEM:
+        raise MemoryError(msg)
+    raise NativeError(rc, msg)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+def device_count() -> int:
+    n = ctypes.c_int32(0)
+    _check(load_library().gecco_crf_device_count(ctypes.byref(n)))
+    return n.value
+
+
+class Model:
+    """Handle on a parsed CRF model (immutable, thread-safe)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._lib = load_library()
+
+    @classmethod
+    def from_lcrf(cls, blob: bytes) -> "Model":
+        lib = load_library()
+        h = _vp()
+        _check(lib.gecco_crf_model_load(blob, len(blob), ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_tables(cls, state: np.ndarray, trans: np.ndarray) -> "Model":
+        lib = load_library()
+        state = np.ascontiguousarray(state, dtype=np.float64)
+        trans = np.ascontiguousarray(trans, dtype=np.float64)
+        A, L = state.shape
+        assert trans.shape == (L, L)
+        h = _vp()
+        _check(lib.gecco_crf_model_from_tables(_ptr(state, _c_f64p), _ptr(trans, _c_f64p), A, L, ctypes.byref(h)))
+        return cls(h)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.gecco_crf_model_free(h)
+
+    @property
+    def num_labels(self) -> int:
+        return self._lib.gecco_crf_model_num_labels(self._h)
+
+    @property
+    def num_attrs(self) -> int:
+        return self._lib.gecco_crf_model_num_attrs(self._h)
+
+    @property
+    def num_features(self) -> int:
+        return self._lib.gecco_crf_model_num_features(self._h)
+
+    def labels(self):
+        return [self._lib.gecco_crf_model_label_name(self._h, i).decode() for i in range(self.num_labels)]
+
+    def attrs(self):
+        return [self._lib.gecco_crf_model_attr_name(self._h, i).decode() for i in range(self.num_attrs)]
+
+    def label_id(self, name: str) -> int:
+        return self._lib.gecco_crf_model_label_id(self._h, name.encode())
+
+    def attr_id(self, name: str) -> int:
+        return self._lib.gecco_crf_model_attr_id(self._h, name.encode())
+
+    def map_attrs(self, names: Sequence[str]) -> np.ndarray:
+        n = len(names)
+        arr = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+        ids = np.empty(max(n, 1), dtype=np.int32)
+        _check(self._lib.gecco_crf_model_map_attrs(self._h, arr, n, _ptr(ids, _c_i32p)))
+        return ids[:n]
+
+    def state_weights(self):
+        A, L = self.num_attrs, self.num_labels
+        w = np.zeros((A, L), dtype=np.float64)
+        present = np.zeros((A, L), dtype=np.uint8)
+        _check(self._lib.gecco_crf_model_state_weights(self._h, _ptr(w, _c_f64p), _ptr(present, _c_u8p)))
+        return w, present.astype(bool)
+
+    def trans_weights(self):
+        L = self.num_labels
+        w = np.zeros((L, L), dtype=np.float64)
+        present = np.zeros((L, L), dtype=np.uint8)
+        _check(self._lib.gecco_crf_model_trans_weights(self._h, _ptr(w, _c_f64p), _ptr(present, _c_u8p)))
+        return w, present.astype(bool)
+
+    # ---- one-shot compute (host buffers) ----
+    def windowed_marginals(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True, device=0):
+        contig_ptr, gene_ptr, attr_id = _i32(contig_ptr), _i32(gene_ptr), _i32(attr_id)
+        n = int(contig_ptr[-1]) if len(contig_ptr) else 0
+        out = np.zeros(max(n, 1), dtype=np.float64)
+        if attr_id.size == 0:
+            attr_id = np.zeros(1, dtype=np.int32)
+        _check(
+            self._lib.gecco_crf_windowed_marginals(
+                self._h, device, _ptr(contig_ptr, _c_i32p), max(len(contig_ptr) - 1, 0), _ptr(gene_ptr, _c_i32p),
+                _ptr(attr_id, _c_i32p), int(window), int(step), int(label), int(bool(pad)), _ptr(out, _c_f64p),
+            )
+        )
+        return out[:n]
+
+    def marginals_full(self, contig_ptr, gene_ptr, attr_id, device=0):
+        contig_ptr, gene_ptr, attr_id = _i32(contig_ptr), _i32(gene_ptr), _i32(attr_id)
+        n, nc, L = int(contig_ptr[-1]), len(contig_ptr) - 1, self.num_labels
+        marg = np.zeros((max(n, 1), L), dtype=np.float64)
+        ln = np.zeros(max(nc, 1), dtype=np.float64)
+        if attr_id.size == 0:
+            attr_id = np.zeros(1, dtype=np.int32)
+        _check(
+            self._lib.gecco_crf_marginals_full(
+                self._h, device, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p), _ptr(attr_id, _c_i32p),
+                _ptr(marg, _c_f64p), _ptr(ln, _c_f64p),
+            )
+        )
+        return marg[:n], ln[:nc]
+
+    def viterbi(self, contig_ptr, gene_ptr, attr_id, device=0):
+        contig_ptr, gene_ptr, attr_id = _i32(contig_ptr), _i32(gene_ptr), _i32(attr_id)
+        n, nc = int(contig_ptr[-1]), len(contig_ptr) - 1
+        y = np.zeros(max(n, 1), dtype=np.int8)
+        sc = np.zeros(max(nc, 1), dtype=np.float64)
+        if attr_id.size == 0:
+            attr_id = np.zeros(1, dtype=np.int32)
+        _check(
+            self._lib.gecco_crf_viterbi(
+                self._h, device, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p), _ptr(attr_id, _c_i32p),
+                _ptr(y, _c_i8p), _ptr(sc, _c_f64p),
+            )
+        )
+        return y[:n], sc[:nc]
+
+
+def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, trim=True, device=0) -> np.ndarray:
+    lib = load_library()
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    annotated = np.ascontiguousarray(annotated, dtype=np.uint8)
+    contig_ptr = _i32(contig_ptr)
+    cap = max(1, len(p))
+    seg = np.zeros((cap, 4), dtype=np.int32)
+    n_seg = ctypes.c_int32(0)
+    _check(
+        lib.gecco_crf_segment(
+            device, _ptr(p, _c_f64p), _ptr(annotated, _c_u8p), _ptr(contig_ptr, _c_i32p), len(contig_ptr) - 1,
+            float(threshold), int(n_cds), int(edge_distance), int(bool(trim)), _ptr(seg, _c_i32p), cap, ctypes.byref(n_seg),
+        )
+    )
+    return seg[: n_seg.value].copy()
+
+
+class Plan:
+    """Resident batch: contig layout + model tables on one device; bulk arrays stay in
+    caller-owned device memory (e.g. torch tensors) and launches go to the caller's stream."""
+
+    def __init__(self, model: Model, contig_ptr, window, step=1, pad=True, device=0):
+        self._lib = load_library()
+        self.model = model
+        contig_ptr = _i32(contig_ptr)
+        h = _vp()
+        _check(
+            self._lib.gecco_crf_plan_create(
+                model._h, int(device), _ptr(contig_ptr, _c_i32p), max(len(contig_ptr) - 1, 0), int(window), int(step),
+                int(bool(pad)), ctypes.byref(h),
+            )
+        )
+        self._h = h
+        self.device = device
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.gecco_crf_plan_free(h)
+
+    @property
+    def num_genes(self) -> int:
+        return self._lib.gecco_crf_plan_num_genes(self._h)
+
+    @property
+    def num_windows(self) -> int:
+        return self._lib.gecco_crf_plan_num_windows(self._h)
+
+    @property
+    def num_tiles(self) -> int:
+        return self._lib.gecco_crf_plan_num_tiles(self._h)
+
+    @property
+    def kernel_name(self) -> str:
+        return self._lib.gecco_crf_plan_kernel_name(self._h).decode()
+
+    def run_windowed(self, d_gene_ptr: int, d_attr_id: int, d_p_out: int, label=1, stream: int = 0):
+        _check(self._lib.gecco_crf_plan_run_windowed(self._h, d_gene_ptr, d_attr_id, int(label), d_p_out, stream or None))
+
+    def run_marginals_full(self, d_gene_ptr: int, d_attr_id: int, d_marg: int, d_lognorm: int = 0, stream: int = 0):
+        _check(self._lib.gecco_crf_plan_run_marginals_full(self._h, d_gene_ptr, d_attr_id, d_marg, d_lognorm or None, stream or None))
+
+    def run_viterbi(self, d_gene_ptr: int, d_attr_id: int, d_y: int, d_score: int = 0, stream: int = 0):
+        _check(self._lib.gecco_crf_plan_run_viterbi(self._h, d_gene_ptr, d_attr_id, d_y, d_score or None, stream or None))
+
+    def time_windowed(self, d_gene_ptr: int, d_attr_id: int, d_p_out: int, label=1, stream: int = 0, warmup=2, iters=10) -> float:
+        ms = ctypes.c_float(0)
+        _check(
+            self._lib.gecco_crf_plan_time_windowed(
+                self._h, d_gene_ptr, d_attr_id, int(label), d_p_out, stream or None, int(warmup), int(iters), ctypes.byref(ms)
+            )
+        )
+        return ms.value

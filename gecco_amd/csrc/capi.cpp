@@ -1,0 +1,278 @@
+// extern "C" surface declared in include/gecco_crf.h.
+#include <cstring>
+#include <new>
+
+#include "../../include/gecco_crf.h"
+#include "crf_model.hpp"
+#include "crf_plan.hpp"
+
+using namespace gecco;
+
+struct gecco_crf_model {
+    Model m;
+};
+struct gecco_crf_plan {
+    Plan p;
+};
+
+#define GECCO_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+struct DeviceGuard {  // restores the caller's current device
+    int prev = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t n, const char *what) {
+        return check_hip(hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T)), what);
+    }
+};
+
+int check_device(int32_t device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (this library has no CPU fallback)");
+        return GECCO_CRF_ENODEV;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device index out of range");
+        return GECCO_CRF_ENODEV;
+    }
+    return GECCO_CRF_OK;
+}
+}  // namespace
+
+GECCO_API const char *gecco_crf_last_error(void) { return last_error(); }
+GECCO_API int gecco_crf_version(void) { return 100; }
+
+GECCO_API int gecco_crf_model_load(const uint8_t *lcrf, size_t n_bytes, gecco_crf_model **out) {
+    if (!out) return GECCO_CRF_EINVAL;
+    *out = nullptr;
+    auto *h = new (std::nothrow) gecco_crf_model();
+    if (!h) return GECCO_CRF_ENOMEM;
+    int rc = parse_lcrf(lcrf, n_bytes, h->m);
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return GECCO_CRF_OK;
+}
+
+GECCO_API int gecco_crf_model_from_tables(const double *state, const double *trans, int32_t num_attrs,
+                                          int32_t num_labels, gecco_crf_model **out) {
+    if (!out) return GECCO_CRF_EINVAL;
+    *out = nullptr;
+    auto *h = new (std::nothrow) gecco_crf_model();
+    if (!h) return GECCO_CRF_ENOMEM;
+    int rc = model_from_tables(state, trans, num_attrs, num_labels, h->m);
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return GECCO_CRF_OK;
+}
+
+GECCO_API void gecco_crf_model_free(gecco_crf_model *m) { delete m; }
+GECCO_API int32_t gecco_crf_model_num_labels(const gecco_crf_model *m) { return m ? m->m.L : 0; }
+GECCO_API int32_t gecco_crf_model_num_attrs(const gecco_crf_model *m) { return m ? m->m.A : 0; }
+GECCO_API int32_t gecco_crf_model_num_features(const gecco_crf_model *m) { return m ? m->m.n_features : 0; }
+GECCO_API const char *gecco_crf_model_label_name(const gecco_crf_model *m, int32_t id) {
+    return (m && id >= 0 && id < m->m.L) ? m->m.labels[id].c_str() : nullptr;
+}
+GECCO_API const char *gecco_crf_model_attr_name(const gecco_crf_model *m, int32_t id) {
+    return (m && id >= 0 && id < m->m.A) ? m->m.attrs[id].c_str() : nullptr;
+}
+GECCO_API int32_t gecco_crf_model_label_id(const gecco_crf_model *m, const char *name) {
+    if (!m || !name) return -1;
+    auto it = m->m.label_index.find(name);
+    return it == m->m.label_index.end() ? -1 : it->second;
+}
+GECCO_API int32_t gecco_crf_model_attr_id(const gecco_crf_model *m, const char *name) {
+    if (!m || !name) return -1;
+    auto it = m->m.attr_index.find(name);
+    return it == m->m.attr_index.end() ? -1 : it->second;
+}
+GECCO_API int gecco_crf_model_map_attrs(const gecco_crf_model *m, const char *const *names, int32_t n, int32_t *ids) {
+    if (!m || (n > 0 && (!names || !ids))) return GECCO_CRF_EINVAL;
+    std::string key;
+    for (int32_t i = 0; i < n; ++i) {
+        if (!names[i]) {
+            ids[i] = -1;
+            continue;
+        }
+        key.assign(names[i]);
+        auto it = m->m.attr_index.find(key);
+        ids[i] = it == m->m.attr_index.end() ? -1 : it->second;
+    }
+    return GECCO_CRF_OK;
+}
+GECCO_API int gecco_crf_model_state_weights(const gecco_crf_model *m, double *w, uint8_t *present) {
+    if (!m) return GECCO_CRF_EINVAL;
+    if (w) std::memcpy(w, m->m.state.data(), m->m.state.size() * sizeof(double));
+    if (present) std::memcpy(present, m->m.state_mask.data(), m->m.state_mask.size());
+    return GECCO_CRF_OK;
+}
+GECCO_API int gecco_crf_model_trans_weights(const gecco_crf_model *m, double *w, uint8_t *present) {
+    if (!m) return GECCO_CRF_EINVAL;
+    if (w) std::memcpy(w, m->m.trans.data(), m->m.trans.size() * sizeof(double));
+    if (present) std::memcpy(present, m->m.trans_mask.data(), m->m.trans_mask.size());
+    return GECCO_CRF_OK;
+}
+
+GECCO_API int gecco_crf_device_count(int32_t *n) {
+    if (!n) return GECCO_CRF_EINVAL;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *n = (e == hipSuccess) ? c : 0;
+    return GECCO_CRF_OK;
+}
+
+// ---- plans -----------------------------------------------------------------------------
+GECCO_API int gecco_crf_plan_create(const gecco_crf_model *m, int32_t device, const int32_t *contig_ptr,
+                                    int32_t n_contigs, int32_t window, int32_t step, int32_t pad,
+                                    gecco_crf_plan **out) {
+    if (!m || !out) return GECCO_CRF_EINVAL;
+    *out = nullptr;
+    if (device >= 0) {
+        int rc = check_device(device);
+        if (rc) return rc;
+    }
+    DeviceGuard guard;
+    auto *h = new (std::nothrow) gecco_crf_plan();
+    if (!h) return GECCO_CRF_ENOMEM;
+    int rc = plan_build(m->m, device, contig_ptr, n_contigs, window, step, pad, h->p);
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return GECCO_CRF_OK;
+}
+GECCO_API void gecco_crf_plan_free(gecco_crf_plan *p) {
+    DeviceGuard guard;
+    delete p;
+}
+GECCO_API int32_t gecco_crf_plan_num_genes(const gecco_crf_plan *p) { return p ? p->p.n_genes : 0; }
+GECCO_API int64_t gecco_crf_plan_num_windows(const gecco_crf_plan *p) { return p ? p->p.n_windows : 0; }
+GECCO_API int32_t gecco_crf_plan_num_tiles(const gecco_crf_plan *p) { return p ? p->p.ntiles : 0; }
+GECCO_API const char *gecco_crf_plan_kernel_name(const gecco_crf_plan *p) { return p ? p->p.kernel_name.c_str() : ""; }
+
+GECCO_API int gecco_crf_plan_run_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                          int32_t label, double *d_p_out, void *stream) {
+    if (!p) return GECCO_CRF_EINVAL;
+    DeviceGuard guard;
+    return plan_run_windowed(p->p, d_gene_ptr, d_attr_id, label, d_p_out, static_cast<hipStream_t>(stream));
+}
+
+GECCO_API int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                           int32_t label, double *d_p_out, void *stream, int32_t warmup,
+                                           int32_t iters, float *ms_per_launch) {
+    if (!p || !ms_per_launch || iters <= 0) return GECCO_CRF_EINVAL;
+    DeviceGuard guard;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    for (int i = 0; i < warmup; ++i)
+        if ((rc = plan_run_windowed(p->p, d_gene_ptr, d_attr_id, label, d_p_out, s))) return rc;
+    hipEvent_t e0, e1;
+    if ((rc = check_hip(hipEventCreate(&e0), "hipEventCreate"))) return rc;
+    if ((rc = check_hip(hipEventCreate(&e1), "hipEventCreate"))) return rc;
+    rc = check_hip(hipEventRecord(e0, s), "hipEventRecord");
+    for (int i = 0; i < iters && !rc; ++i) rc = plan_run_windowed(p->p, d_gene_ptr, d_attr_id, label, d_p_out, s);
+    if (!rc) rc = check_hip(hipEventRecord(e1, s), "hipEventRecord");
+    if (!rc) rc = check_hip(hipEventSynchronize(e1), "hipEventSynchronize");
+    float ms = 0.f;
+    if (!rc) rc = check_hip(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / float(iters);
+    return rc;
+}
+
+GECCO_API int gecco_crf_plan_run_marginals_full(gecco_crf_plan *, const int32_t *, const int32_t *, double *, double *,
+                                                void *) {
+    set_error("full-sequence marginals: not built yet");
+    return GECCO_CRF_EUNSUPPORTED;
+}
+GECCO_API int gecco_crf_plan_run_viterbi(gecco_crf_plan *, const int32_t *, const int32_t *, int8_t *, double *,
+                                         void *) {
+    set_error("viterbi: not built yet");
+    return GECCO_CRF_EUNSUPPORTED;
+}
+
+// ---- one-shot host entry points ------------------------------------------------------------
+GECCO_API int gecco_crf_windowed_marginals(const gecco_crf_model *m, int32_t device, const int32_t *contig_ptr,
+                                           int32_t n_contigs, const int32_t *gene_ptr, const int32_t *attr_id,
+                                           int32_t window, int32_t step, int32_t label, int32_t pad, double *p_out) {
+    if (!m) return GECCO_CRF_EINVAL;
+    // argument errors first, so that they surface even on a box without a GPU
+    if (window <= 0) {
+        set_error("Window size must be strictly positive");
+        return GECCO_CRF_EINVAL;
+    }
+    if (step <= 0 || step > window) {
+        set_error("Window step must be strictly positive and under `window_size`");
+        return GECCO_CRF_EINVAL;
+    }
+    if (label < 0 || label >= m->m.L) {
+        set_error("label out of range");
+        return GECCO_CRF_EINVAL;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    DeviceGuard guard;
+    gecco_crf_plan h;
+    if ((rc = plan_build(m->m, device, contig_ptr, n_contigs, window, step, pad, h.p))) return rc;
+    const int32_t n = h.p.n_genes;
+    if (n == 0) return GECCO_CRF_OK;
+    if (!gene_ptr || !p_out) {
+        set_error("null buffer");
+        return GECCO_CRF_EINVAL;
+    }
+    const size_t nnz = size_t(gene_ptr[n]);
+    for (size_t k = 0; k < nnz; ++k)
+        if (attr_id[k] < 0 || attr_id[k] >= m->m.A) {
+            set_error("attr_id out of range (unknown attributes must be dropped by the packer)");
+            return GECCO_CRF_EINVAL;
+        }
+    DevBuf<int32_t> d_gp, d_at;
+    DevBuf<double> d_p;
+    if ((rc = d_gp.alloc(size_t(n) + 1, "hipMalloc gene_ptr"))) return rc;
+    if ((rc = d_at.alloc(nnz, "hipMalloc attr_id"))) return rc;
+    if ((rc = d_p.alloc(size_t(n), "hipMalloc p_out"))) return rc;
+    if ((rc = check_hip(hipMemcpy(d_gp.p, gene_ptr, (size_t(n) + 1) * 4, hipMemcpyHostToDevice), "H2D gene_ptr"))) return rc;
+    if (nnz && (rc = check_hip(hipMemcpy(d_at.p, attr_id, nnz * 4, hipMemcpyHostToDevice), "H2D attr_id"))) return rc;
+    if ((rc = check_hip(hipMemset(d_p.p, 0, size_t(n) * 8), "memset"))) return rc;
+    if ((rc = plan_run_windowed(h.p, d_gp.p, d_at.p, label, d_p.p, nullptr))) return rc;
+    if ((rc = check_hip(hipMemcpy(p_out, d_p.p, size_t(n) * 8, hipMemcpyDeviceToHost), "D2H p_out"))) return rc;
+    return GECCO_CRF_OK;
+}
+
+GECCO_API int gecco_crf_marginals_full(const gecco_crf_model *, int32_t, const int32_t *, int32_t, const int32_t *,
+                                       const int32_t *, double *, double *) {
+    set_error("full-sequence marginals: not built yet");
+    return GECCO_CRF_EUNSUPPORTED;
+}
+GECCO_API int gecco_crf_viterbi(const gecco_crf_model *, int32_t, const int32_t *, int32_t, const int32_t *,
+                                const int32_t *, int8_t *, double *) {
+    set_error("viterbi: not built yet");
+    return GECCO_CRF_EUNSUPPORTED;
+}
+GECCO_API int gecco_crf_segment(int32_t, const double *, const uint8_t *, const int32_t *, int32_t, double, int32_t,
+                                int32_t, int32_t, int32_t *, int32_t, int32_t *) {
+    set_error("segment: not built yet");
+    return GECCO_CRF_EUNSUPPORTED;
+}

@@ -1,0 +1,39 @@
+// Device-side interface between the plan/C-ABI layer and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace gecco {
+
+// Arguments of the windowed-marginals kernels (row W of SURVEY.md §8a).
+// "slot space" = genes of all scored contigs laid end to end, each contig padded to at
+// least `W` slots (gecco/crf/__init__.py:216-227); windows start at slots.
+struct WinArgs {
+    const int32_t *gene_ptr;   // [n_genes+1]  CSR attribute offsets            (HBM, streamed)
+    const int32_t *attr_id;    // [nnz]        attribute ids                    (HBM, streamed)
+    const double2 *wtab2;      // [A]          (w[a][other], w[a][label]) L == 2 (L2-resident)
+    const double *wtab;        // [A*L]        dense state weights, any L        (L2-resident)
+    const int32_t *c_slot;     // [K+1]        first slot of every scored contig
+    const int32_t *c_gene;     // [K]          first gene of every scored contig
+    const int32_t *c_n;        // [K]          number of genes of every scored contig
+    const int2 *tile_c;        // [ntiles]     (first, last) scored contig a tile overlaps
+    double *p_out;             // [n_genes]
+    int32_t K, S, ntiles, W, step, L, label;
+    uint32_t rescale_mask;     // bit k: renormalise the DP vectors after step k
+    double m00, m01, m10, m11; // exp(trans - max(trans)), rows/cols ordered (other, label)
+    const double *exp_trans;   // [L*L] exp(trans) for the generic kernel
+    double *scratch;           // generic kernel workspace
+};
+
+// Geometry of the fast L==2 kernel.
+constexpr int kWinThreads = 256;  // lanes (= window starts) per workgroup
+constexpr int kWinMaxW = 32;      // largest window the register-resident kernel handles
+
+const char *windowed_kernel_name(int W, int L);
+// tile_out = output slots per workgroup for the kernel that (W, L) dispatches to.
+int windowed_tile_out(int W, int L);
+hipError_t launch_windowed(const WinArgs &a, hipStream_t stream);
+hipError_t launch_fill_nan(double *p, const int2 *ranges, int n_ranges, hipStream_t stream);
+
+}  // namespace gecco

@@ -1,0 +1,253 @@
+#include "crf_plan.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "../../include/gecco_crf.h"
+
+namespace gecco {
+
+int check_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return GECCO_CRF_OK;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return GECCO_CRF_ENODEV;
+    if (e == hipErrorOutOfMemory) return GECCO_CRF_ENOMEM;
+    return GECCO_CRF_EHIP;
+}
+
+namespace {
+template <class T>
+int upload(T **dst, const T *src, size_t n, const char *what) {
+    *dst = nullptr;
+    if (n == 0) n = 1;  // keep pointers valid
+    int rc = check_hip(hipMalloc(reinterpret_cast<void **>(dst), n * sizeof(T)), what);
+    if (rc) return rc;
+    if (src) rc = check_hip(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice), what);
+    return rc;
+}
+}  // namespace
+
+Model::~Model() {
+    for (DeviceTables *t : dev_tables) {
+        if (!t) continue;
+        int prev = 0;
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(t->device) == hipSuccess) {
+            (void)hipFree(t->wtab);
+            (void)hipFree(t->wtab2[0]);
+            (void)hipFree(t->wtab2[1]);
+            (void)hipFree(t->exp_trans);
+            (void)hipSetDevice(prev);
+        }
+        delete t;
+    }
+}
+
+int get_device_tables(const Model &m, int device, const DeviceTables **out) {
+    std::lock_guard<std::mutex> lock(m.dev_mutex);
+    for (DeviceTables *t : m.dev_tables)
+        if (t && t->device == device) {
+            *out = t;
+            return GECCO_CRF_OK;
+        }
+    int rc = check_hip(hipSetDevice(device), "hipSetDevice");
+    if (rc) return rc;
+    auto *t = new DeviceTables();
+    t->device = device;
+    const size_t A = size_t(m.A), L = size_t(m.L);
+    if ((rc = upload(&t->wtab, m.state.data(), A * L, "upload state weights"))) return rc;
+    std::vector<double> et(L * L);
+    for (size_t i = 0; i < L * L; ++i) et[i] = std::exp(m.trans[i]);
+    if ((rc = upload(&t->exp_trans, et.data(), L * L, "upload transitions"))) return rc;
+    if (m.L == 2) {
+        std::vector<double2> w2(A ? A : 1);
+        for (int label = 0; label < 2; ++label) {
+            for (size_t a = 0; a < A; ++a) w2[a] = make_double2(m.state[a * 2 + (1 - label)], m.state[a * 2 + label]);
+            if ((rc = upload(&t->wtab2[label], w2.data(), A, "upload state weight pairs"))) return rc;
+        }
+    }
+    m.dev_tables.push_back(t);
+    *out = t;
+    return GECCO_CRF_OK;
+}
+
+Plan::~Plan() {
+    if (device >= 0) {
+        int prev = 0;
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess) {
+            (void)hipFree(d_c_slot);
+            (void)hipFree(d_c_gene);
+            (void)hipFree(d_c_n);
+            (void)hipFree(d_contig_ptr);
+            (void)hipFree(d_tile_c);
+            (void)hipFree(d_skipped);
+            (void)hipSetDevice(prev);
+        }
+    }
+}
+
+// Steps after which the un-normalised DP vectors are rescaled by a power of two.
+// With emissions and transitions max-normalised to (0,1] the larger component of alpha
+// shrinks by at most mu = min(exp(trans))/max(exp(trans)) per step and that of beta by at
+// most mu^2 (crf_kernels.hip header), so candidates x,y stay comparable by
+// cross-multiplication in fp64 as long as (3*P+1)*log2(1/mu) <= 498 for a rescale
+// period P.  GECCO's embedded model: log2(1/mu) = 7.6 -> P = 21 >= W-1, mask = 0.
+static bool rescale_mask_for(const Model &m, int W, uint32_t *mask) {
+    double lo = m.trans[0], hi = m.trans[0];
+    for (double t : m.trans) {
+        lo = std::min(lo, t);
+        hi = std::max(hi, t);
+    }
+    const double bits = (hi - lo) / std::log(2.0);
+    *mask = 0;
+    if (!(bits >= 0.0) || !std::isfinite(bits)) return false;
+    if (bits == 0.0) return true;
+    const double pf = std::floor((498.0 / bits - 1.0) / 3.0);
+    if (pf < 1.0) return false;
+    if (pf >= double(W)) return true;
+    const int P = int(pf);
+    for (int k = P; k < W && k < 32; k += P) *mask |= (1u << k);
+    return true;
+}
+
+int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_contigs, int32_t W, int32_t step,
+               int32_t pad, Plan &p) {
+    // same checks, same order as gecco/_meta.py:127-130
+    if (W <= 0) {
+        set_error("Window size must be strictly positive");
+        return GECCO_CRF_EINVAL;
+    }
+    if (step <= 0 || step > W) {
+        set_error("Window step must be strictly positive and under `window_size`");
+        return GECCO_CRF_EINVAL;
+    }
+    if (n_contigs < 0 || (n_contigs > 0 && !contig_ptr)) {
+        set_error("bad contig_ptr");
+        return GECCO_CRF_EINVAL;
+    }
+    p.model = &m;
+    p.device = device;
+    p.W = W;
+    p.step = step;
+    p.pad = pad ? 1 : 0;
+    p.n_contigs = n_contigs;
+    p.n_genes = n_contigs ? contig_ptr[n_contigs] : 0;
+    p.contig_ptr.assign(contig_ptr, contig_ptr + (n_contigs ? n_contigs + 1 : 0));
+    if (n_contigs && contig_ptr[0] != 0) {
+        set_error("contig_ptr[0] must be 0");
+        return GECCO_CRF_EINVAL;
+    }
+    int64_t S = 0;
+    p.n_windows = 0;
+    for (int32_t c = 0; c < n_contigs; ++c) {
+        const int32_t g0 = contig_ptr[c], n = contig_ptr[c + 1] - g0;
+        if (n < 0) {
+            set_error("contig_ptr must be non-decreasing");
+            return GECCO_CRF_EINVAL;
+        }
+        if (n == 0) continue;  // cannot occur in the reference (groupby never yields empty groups)
+        int32_t np = n;
+        if (n < W) {
+            if (!p.pad) {  // crf/__init__.py:228-234: contig skipped, genes keep "no prediction"
+                p.skipped.push_back(make_int2(g0, g0 + n));
+                continue;
+            }
+            np = W;  // :226-227
+        }
+        p.c_slot.push_back(int32_t(S));
+        p.c_gene.push_back(g0);
+        p.c_n.push_back(n);
+        S += np;
+        p.n_windows += np - W + 1;  // :239 (ignores step, like the reference)
+        if (S > INT32_MAX - 4096) {
+            set_error("batch too large: more than 2^31 padded gene slots");
+            return GECCO_CRF_EUNSUPPORTED;
+        }
+    }
+    p.K = int32_t(p.c_gene.size());
+    p.S = int32_t(S);
+    p.c_slot.push_back(p.S);
+
+    p.fast_ok = (m.L == 2 && W <= kWinMaxW && rescale_mask_for(m, W, &p.rescale_mask));
+    if (!p.fast_ok) {
+        set_error("no kernel for this model/window shape yet (need 2 labels, window <= 32)");
+        return GECCO_CRF_EUNSUPPORTED;
+    }
+    p.kernel_name = windowed_kernel_name(W, m.L);
+    p.tile_out = windowed_tile_out(W, m.L);
+    p.ntiles = p.S > 0 ? (p.S + p.tile_out - 1) / p.tile_out : 0;
+    p.tile_c.resize(p.ntiles);
+    for (int32_t b = 0; b < p.ntiles; ++b) {
+        const int64_t q_lo = std::max<int64_t>(int64_t(b) * p.tile_out - (W - 1), 0);
+        const int64_t q_hi = std::min<int64_t>(int64_t(b) * p.tile_out - (W - 1) + kWinThreads + W - 2, p.S - 1);
+        const auto first = std::upper_bound(p.c_slot.begin(), p.c_slot.begin() + p.K, int32_t(q_lo)) - p.c_slot.begin() - 1;
+        const auto last = std::upper_bound(p.c_slot.begin(), p.c_slot.begin() + p.K, int32_t(q_hi)) - p.c_slot.begin() - 1;
+        p.tile_c[b] = make_int2(int(first), int(last));
+    }
+    if (device < 0) return GECCO_CRF_OK;
+
+    int rc = check_hip(hipSetDevice(device), "hipSetDevice");
+    if (rc) return rc;
+    if ((rc = get_device_tables(m, device, &p.tables))) return rc;
+    if ((rc = upload(&p.d_c_slot, p.c_slot.data(), p.c_slot.size(), "upload plan"))) return rc;
+    if ((rc = upload(&p.d_c_gene, p.c_gene.data(), p.c_gene.size(), "upload plan"))) return rc;
+    if ((rc = upload(&p.d_c_n, p.c_n.data(), p.c_n.size(), "upload plan"))) return rc;
+    if ((rc = upload(&p.d_tile_c, p.tile_c.data(), p.tile_c.size(), "upload plan"))) return rc;
+    if ((rc = upload(&p.d_skipped, p.skipped.data(), p.skipped.size(), "upload plan"))) return rc;
+    if ((rc = upload(&p.d_contig_ptr, p.contig_ptr.data(), p.contig_ptr.size(), "upload plan"))) return rc;
+    return GECCO_CRF_OK;
+}
+
+int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                      hipStream_t stream) {
+    if (p.device < 0) {
+        set_error("host-only plan: no HIP device bound (there is no CPU fallback)");
+        return GECCO_CRF_ENODEV;
+    }
+    if (label < 0 || label >= p.model->L) {
+        set_error("label out of range");
+        return GECCO_CRF_EINVAL;
+    }
+    if (p.n_genes == 0) return GECCO_CRF_OK;
+    if (!d_gene_ptr || !d_p_out) {
+        set_error("null device buffer");
+        return GECCO_CRF_EINVAL;
+    }
+    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
+    if (rc) return rc;
+    const Model &m = *p.model;
+    WinArgs a{};
+    a.gene_ptr = d_gene_ptr;
+    a.attr_id = d_attr_id;
+    a.wtab = p.tables->wtab;
+    a.wtab2 = p.tables->wtab2[label];
+    a.exp_trans = p.tables->exp_trans;
+    a.c_slot = p.d_c_slot;
+    a.c_gene = p.d_c_gene;
+    a.c_n = p.d_c_n;
+    a.tile_c = p.d_tile_c;
+    a.p_out = d_p_out;
+    a.K = p.K;
+    a.S = p.S;
+    a.ntiles = p.ntiles;
+    a.W = p.W;
+    a.step = p.step;
+    a.L = m.L;
+    a.label = label;
+    a.rescale_mask = p.rescale_mask;
+    {
+        const int o = 1 - label;
+        const double mx = *std::max_element(m.trans.begin(), m.trans.end());
+        auto M = [&](int i, int j) { return std::exp(m.trans[size_t(i) * 2 + j] - mx); };
+        a.m00 = M(o, o);
+        a.m01 = M(o, label);
+        a.m10 = M(label, o);
+        a.m11 = M(label, label);
+    }
+    if (!p.skipped.empty())
+        if ((rc = check_hip(launch_fill_nan(d_p_out, p.d_skipped, int(p.skipped.size()), stream), "fill_nan launch")))
+            return rc;
+    return check_hip(launch_windowed(a, stream), "windowed launch");
+}
+
+}  // namespace gecco

@@ -1,0 +1,54 @@
+// Batch plan: host-side layout of one batch of contigs in "slot space" + the device copies
+// the kernels need.  Mirrors the bookkeeping half of gecco/crf/__init__.py:209-240
+// (which contigs are scored, how they are padded, how many windows there are).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "crf_device.hpp"
+#include "crf_model.hpp"
+
+namespace gecco {
+
+// Per-device copies of a model's tables (owned by the Model, created on first use).
+struct DeviceTables {
+    int device = -1;
+    double *wtab = nullptr;       // [A*L]
+    double2 *wtab2[2] = {nullptr, nullptr};  // L == 2: [A] (other, label) for label = 0 / 1
+    double *exp_trans = nullptr;  // [L*L]
+};
+
+struct Plan {
+    const Model *model = nullptr;
+    int device = -1;  // -1: host-only plan (layout queries work, launches return ENODEV)
+    int32_t W = 0, step = 1, pad = 1;
+    int32_t n_contigs = 0, n_genes = 0;
+    int64_t n_windows = 0;
+    // slot-space layout (host)
+    int32_t K = 0, S = 0, ntiles = 0, tile_out = 0;
+    std::vector<int32_t> c_slot, c_gene, c_n;
+    std::vector<int2> tile_c;
+    std::vector<int2> skipped;  // gene ranges of contigs skipped by pad == 0
+    std::vector<int32_t> contig_ptr;
+    uint32_t rescale_mask = 0;
+    bool fast_ok = false;
+    std::string kernel_name;
+    // device copies
+    int32_t *d_c_slot = nullptr, *d_c_gene = nullptr, *d_c_n = nullptr, *d_contig_ptr = nullptr;
+    int2 *d_tile_c = nullptr, *d_skipped = nullptr;
+    const DeviceTables *tables = nullptr;
+    ~Plan();
+};
+
+int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_contigs, int32_t W, int32_t step,
+               int32_t pad, Plan &p);
+int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                      hipStream_t stream);
+// returns GECCO_CRF_* ; on HIP failure sets the error text
+int check_hip(hipError_t e, const char *what);
+int get_device_tables(const Model &m, int device, const DeviceTables **out);
+
+}  // namespace gecco

@@ -1,0 +1,138 @@
+/*
+ * gecco_crf.h -- C ABI of the MI355X-native linear-chain CRF inference engine for GECCO's
+ * `gecco.crf` hot path.
+ *
+ * This is the drop-in boundary: the native interface GECCO reaches today for this path is
+ * python-crfsuite's `Tagger` ([EXT] CRFsuite 0.12 `crfsuite_tagger_t`: open / labels / set /
+ * marginal_point / viterbi), crossed once per sliding window at
+ *     /root/reference/gecco/crf/__init__.py:253   self.model.predict_marginals_single(feats[win])
+ * inside the per-contig window loop at :244-258.  The entry points below replace that
+ * per-window boundary with one call per *batch of contigs*; the reference-side binding a
+ * maintainer would add (a ctypes stub inside a `ClusterCRF` subclass handed to
+ * `gecco.cli.main(crf_type=...)`, gecco/cli/commands/__init__.py:127-137) is shown in
+ * INTEGRATION.md and implemented in gecco_amd/crf.py.
+ *
+ * Conventions: plain pointers and sizes; every function returns an int status (0 = OK,
+ * <0 = error, text via gecco_crf_last_error()); caller owns all buffers; handles are
+ * immutable after creation and may be shared between threads.  Batches are CSR:
+ *   contig_ptr[n_contigs+1]  gene offsets of each contig          (host memory, always)
+ *   gene_ptr  [n_genes+1]    attribute offsets of each gene
+ *   attr_id   [nnz]          attribute ids (unknown names already dropped, as CRFsuite does)
+ * Genes are in the reference's order: sorted by (contig id, start) -- crf/__init__.py:199.
+ * There is NO CPU fallback in this library: without a HIP device the compute entry points
+ * return GECCO_CRF_ENODEV.
+ */
+#ifndef GECCO_CRF_H
+#define GECCO_CRF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GECCO_CRF_OK 0
+#define GECCO_CRF_EINVAL (-1)       /* bad argument; window errors mirror _meta.py:127-130 */
+#define GECCO_CRF_EFORMAT (-2)      /* malformed CRFsuite model blob */
+#define GECCO_CRF_ENOMEM (-3)
+#define GECCO_CRF_EHIP (-4)         /* HIP runtime error */
+#define GECCO_CRF_ENODEV (-5)       /* no usable HIP device */
+#define GECCO_CRF_EUNSUPPORTED (-6) /* model/window shape outside every kernel's range */
+
+typedef struct gecco_crf_model gecco_crf_model;
+typedef struct gecco_crf_plan gecco_crf_plan;
+
+/* Thread-local description of the last error returned on this thread. */
+const char *gecco_crf_last_error(void);
+/* ABI version: major*10000 + minor*100 + patch. */
+int gecco_crf_version(void);
+
+/* ---- model (replaces [EXT] pycrfsuite.Tagger.open / labels() / info(); the blob is the
+ * `__FILE_RESOURCE_DATA__` bytes held by the pickle that ClusterCRF.trained() loads,
+ * gecco/crf/__init__.py:61-99) ------------------------------------------------------- */
+int gecco_crf_model_load(const uint8_t *lcrf, size_t n_bytes, gecco_crf_model **out);
+/* Model from dense tables (row-major state[A][L], trans[L][L]); names are "0".."L-1" and
+ * "a<id>".  Used for synthetic benchmark models. */
+int gecco_crf_model_from_tables(const double *state, const double *trans, int32_t num_attrs,
+                                int32_t num_labels, gecco_crf_model **out);
+void gecco_crf_model_free(gecco_crf_model *m);
+int32_t gecco_crf_model_num_labels(const gecco_crf_model *m);
+int32_t gecco_crf_model_num_attrs(const gecco_crf_model *m);
+int32_t gecco_crf_model_num_features(const gecco_crf_model *m); /* state + transition */
+const char *gecco_crf_model_label_name(const gecco_crf_model *m, int32_t id); /* NULL if out of range */
+const char *gecco_crf_model_attr_name(const gecco_crf_model *m, int32_t id);
+int32_t gecco_crf_model_label_id(const gecco_crf_model *m, const char *name); /* -1 if unknown */
+int32_t gecco_crf_model_attr_id(const gecco_crf_model *m, const char *name);  /* -1 if unknown */
+/* Bulk name->id (ids[i] = -1 for names the model does not know). */
+int gecco_crf_model_map_attrs(const gecco_crf_model *m, const char *const *names, int32_t n, int32_t *ids);
+/* Dense weights; `present` (may be NULL) flags which entries are actual model features
+ * ([EXT] CRF.state_features_ / transition_features_ list only those). */
+int gecco_crf_model_state_weights(const gecco_crf_model *m, double *w /* A*L */, uint8_t *present /* A*L */);
+int gecco_crf_model_trans_weights(const gecco_crf_model *m, double *w /* L*L */, uint8_t *present /* L*L */);
+
+/* ---- devices ---------------------------------------------------------------------- */
+int gecco_crf_device_count(int32_t *n);
+
+/* ---- one-shot, host buffers in / host buffers out, synchronous ----------------------
+ * Row W (+D,S,A/B,P): p_out[g] = max over sliding windows covering gene g of
+ * P(y_g = label) from an independent forward-backward on each window of `window` genes
+ * (gecco/crf/__init__.py:209-258).  Contigs shorter than the window are centre-padded
+ * with empty genes when pad != 0, else skipped and their genes get NaN ("no prediction",
+ * :228-234,246-248).  Genes covered by no window (step > 1) get 0.0 (:251). */
+int gecco_crf_windowed_marginals(const gecco_crf_model *m, int32_t device,
+                                 const int32_t *contig_ptr, int32_t n_contigs,
+                                 const int32_t *gene_ptr, const int32_t *attr_id,
+                                 int32_t window, int32_t step, int32_t label, int32_t pad,
+                                 double *p_out /* n_genes */);
+/* Row F (extension; [EXT] CRF.predict_marginals_single on a whole contig): marginals of
+ * every label, marg[n_genes][L]; lognorm[n_contigs] may be NULL. */
+int gecco_crf_marginals_full(const gecco_crf_model *m, int32_t device,
+                             const int32_t *contig_ptr, int32_t n_contigs,
+                             const int32_t *gene_ptr, const int32_t *attr_id,
+                             double *marg, double *lognorm);
+/* Row V (extension; [EXT] CRF.predict_single / crf1dc_viterbi): best label path per
+ * contig, first-argmax tie-breaking; score[n_contigs] may be NULL. */
+int gecco_crf_viterbi(const gecco_crf_model *m, int32_t device,
+                      const int32_t *contig_ptr, int32_t n_contigs,
+                      const int32_t *gene_ptr, const int32_t *attr_id,
+                      int8_t *y_out /* n_genes */, double *score);
+/* Row R (gecco/refine.py:51-64,118-200, criterion "gecco"): threshold run-length
+ * segmentation with the stateful grouper, optional trimming of un-annotated edge genes and
+ * validation.  seg_out rows = (contig, cluster_number, first_gene, last_gene_exclusive);
+ * *n_seg receives the number of rows; GECCO_CRF_EINVAL if max_seg is too small. */
+int gecco_crf_segment(int32_t device, const double *p, const uint8_t *annotated,
+                      const int32_t *contig_ptr, int32_t n_contigs,
+                      double threshold, int32_t n_cds, int32_t edge_distance, int32_t trim,
+                      int32_t *seg_out, int32_t max_seg, int32_t *n_seg);
+
+/* ---- resident / asynchronous API ----------------------------------------------------
+ * A plan owns the device copies of the model tables and of the contig layout of one
+ * batch; bulk arrays stay in caller-owned DEVICE memory and launches go to the caller's
+ * stream (`stream` is a hipStream_t passed as void*; NULL = the default stream).  This is
+ * what bench.py and multi-GPU drivers use: one plan per rank/shard, no collectives. */
+int gecco_crf_plan_create(const gecco_crf_model *m, int32_t device,
+                          const int32_t *contig_ptr /* host */, int32_t n_contigs,
+                          int32_t window, int32_t step, int32_t pad, gecco_crf_plan **out);
+void gecco_crf_plan_free(gecco_crf_plan *p);
+int32_t gecco_crf_plan_num_genes(const gecco_crf_plan *p);
+int64_t gecco_crf_plan_num_windows(const gecco_crf_plan *p); /* = the reference's progress `total` */
+int32_t gecco_crf_plan_num_tiles(const gecco_crf_plan *p);   /* workgroups of the windowed kernel */
+/* Name of the kernel variant the plan dispatches to (for profiles / bench). */
+const char *gecco_crf_plan_kernel_name(const gecco_crf_plan *p);
+int gecco_crf_plan_run_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                int32_t label, double *d_p_out, void *stream);
+int gecco_crf_plan_run_marginals_full(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                      double *d_marg, double *d_lognorm, void *stream);
+int gecco_crf_plan_run_viterbi(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                               int8_t *d_y, double *d_score, void *stream);
+/* Average milliseconds per launch of `iters` back-to-back windowed launches, measured with
+ * HIP events on `stream` (after `warmup` untimed launches). */
+int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                 int32_t label, double *d_p_out, void *stream,
+                                 int32_t warmup, int32_t iters, float *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GECCO_CRF_H */

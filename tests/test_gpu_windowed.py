@@ -1,0 +1,130 @@
+"""GPU parity: HIP windowed-marginals path (through the C ABI) vs the CPU oracle and the
+reference's golden table.  Tolerance: |dp| <= 1e-12 (north star asks 1e-6; fp64 throughout,
+differences come from exp()/rounding order only)."""
+import numpy as np
+import pytest
+
+from tests.helpers import golden_csr, synth_contigs, synth_model
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from gecco_amd import _native
+
+    assert _native.device_count() >= 1, "no HIP device: the GPU suite must run on an MI355X"
+    return _native
+
+
+@pytest.fixture(scope="module")
+def real_model(nat, oracle_model):
+    from oracle import lcrf
+    import os
+    from tests.helpers import GOLDEN
+
+    st = lcrf.load_pickle(os.path.join(GOLDEN, "model.pkl"))
+    return nat.Model.from_lcrf(st["blob"])
+
+
+def _cmp(got, exp):
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    err = np.abs(np.nan_to_num(got) - np.nan_to_num(exp)).max() if len(exp) else 0.0
+    assert err <= TOL, err
+    return err
+
+
+def test_golden_fixture(real_model, oracle_model):
+    ids, cptr, gptr, attr, expected, ann = golden_csr(oracle_model["attr_index"])
+    p = real_model.windowed_marginals(cptr, gptr, attr, 20, 1, 1, True)
+    assert np.abs(p - expected).max() <= 1e-14
+
+
+@pytest.mark.parametrize("W,step,pad,label", [
+    (20, 1, True, 1), (20, 1, False, 1), (20, 1, True, 0), (20, 3, True, 1), (20, 20, True, 1),
+    (5, 1, True, 1), (5, 2, False, 1), (1, 1, True, 1), (2, 1, True, 1), (19, 1, True, 1),
+    (21, 1, True, 1), (32, 1, True, 1), (32, 5, True, 0), (7, 7, True, 1),
+])
+def test_random_contigs_real_model(real_model, oracle_model, W, step, pad, label):
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(1000 * W + 10 * step + label)
+    lengths = [1, 2, 3, W - 1 if W > 1 else 1, W, W + 1, 2 * W, 19, 20, 21, 39, 40, 41, 236, 237, 238, 255, 256, 257,
+               274, 275, 276, 474, 475, 513, 1000] + list(rng.integers(1, 400, size=60))
+    rng.shuffle(lengths)
+    cptr, gptr, attr = synth_contigs(rng, lengths, oracle_model["state"].shape[0])
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, W, step, label, pad)
+    got = real_model.windowed_marginals(cptr, gptr, attr, W, step, label, pad)
+    _cmp(got, exp)
+
+
+def test_c2_synthetic_model(nat):
+    """configs[1]: 1k contigs x ~200 genes, A = 35k synthetic attributes."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(0x6ECC0)
+    A = 35000
+    w, trans = synth_model(A, rng)
+    lengths = np.clip(np.round(rng.lognormal(np.log(200), 0.5, size=1000)), 5, 2000).astype(int)
+    cptr, gptr, attr = synth_contigs(rng, lengths, A)
+    model = nat.Model.from_tables(w, trans)
+    got = model.windowed_marginals(cptr, gptr, attr, 20)
+    exp = orc.windowed_marginals(w, trans, cptr, gptr, attr, 20)
+    _cmp(got, exp)
+    # cluster calls identical
+    assert np.array_equal(got > 0.8, exp > 0.8)
+
+
+def test_long_contig(real_model, oracle_model):
+    """configs[4] shape at reduced size: one long contig spans many tiles."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(5)
+    cptr, gptr, attr = synth_contigs(rng, [20000, 7], oracle_model["state"].shape[0])
+    got = real_model.windowed_marginals(cptr, gptr, attr, 20)
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20)
+    _cmp(got, exp)
+
+
+def test_empty_and_degenerate(real_model):
+    assert len(real_model.windowed_marginals([0], [0], [], 20)) == 0
+    # genes without any domain: p is the prior path through empty items, identical for all genes
+    p = real_model.windowed_marginals([0, 30], np.zeros(31, dtype=np.int32), [], 20)
+    assert p.shape == (30,) and np.all(p > 0) and np.all(p < 1)
+    # all contigs skipped (pad=False)
+    p = real_model.windowed_marginals([0, 3, 5], [0, 1, 2, 3, 4, 5], [1, 2, 3, 4, 5], 20, pad=False)
+    assert np.isnan(p).all()
+
+
+def test_strong_transitions_need_rescale(nat):
+    """Transition spread large enough that the kernel must renormalise mid-window."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(77)
+    A = 300
+    w, _ = synth_model(A, rng)
+    trans = np.array([[20.0, -25.0], [-22.0, 18.0]])
+    cptr, gptr, attr = synth_contigs(rng, [300, 45, 20, 8], A)
+    model = nat.Model.from_tables(w, trans)
+    for W in (20, 32, 9):
+        got = model.windowed_marginals(cptr, gptr, attr, W)
+        exp = orc.windowed_marginals(w, trans, cptr, gptr, attr, W)
+        _cmp(got, exp)
+
+
+def test_extreme_state_scores(nat):
+    """Saturated emissions (|s1-s0| in the hundreds) must not overflow / NaN."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(78)
+    A = 50
+    w = rng.normal(0, 150.0, size=(A, 2))
+    trans = np.array([[2.67, -2.6], [-2.6, 2.57]])
+    cptr, gptr, attr = synth_contigs(rng, [200, 30], A)
+    model = nat.Model.from_tables(w, trans)
+    got = model.windowed_marginals(cptr, gptr, attr, 20)
+    exp = orc.windowed_marginals(w, trans, cptr, gptr, attr, 20)
+    assert np.isfinite(got).all()
+    _cmp(got, exp)
