@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the GECCO CRF hot path on MI355X (contract: see the task statement).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one resident batch: the windowed forward-backward
+marginals of every gene (the reference's `ClusterCRF.predict_probabilities` arithmetic,
+gecco/crf/__init__.py:244-258) followed by whole-contig Viterbi decoding when that kernel
+is available.  Workload at N=1 = BASELINE.json configs[2] ("C3": 10k-contig synthetic
+metagenome, ~2M genes, 35k-attribute synthetic model, W=20); with N>1 every rank owns its
+own C3-sized shard of contigs (weak scaling, no collective on the data path).
+Inputs are resident in HBM before the timed region.  One JSON line on stdout (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from gecco_amd import _native as nat
+    from gecco_amd import synth
+
+    # ---- workload: every rank generates its own shard (same model, different contigs)
+    wl = synth.workload(args.workload, seed=synth.SEED)
+    if rank > 0:
+        rng = np.random.default_rng(synth.SEED + rank)
+        lengths = np.diff(wl["contig_ptr"]).astype(np.int64)
+        rng.shuffle(lengths)
+        hot = np.argsort(wl["w"][:, 1] - wl["w"][:, 0])[-200:]
+        cptr, gptr, attr = synth.synth_contigs(rng, lengths, wl["A"], planted=0.01, hot_attrs=hot)
+        wl.update(contig_ptr=cptr, gene_ptr=gptr, attr_id=attr)
+    n_genes = int(wl["contig_ptr"][-1])
+    nnz = int(wl["gene_ptr"][-1])
+    W, STEP, LABEL = 20, 1, 1
+
+    model = nat.Model.from_tables(wl["w"], wl["trans"])
+    plan = nat.Plan(model, wl["contig_ptr"], W, STEP, True, device=local_rank)
+    d_gp = torch.from_numpy(wl["gene_ptr"]).to(dev)
+    d_at = torch.from_numpy(wl["attr_id"]).to(dev)
+    d_p = torch.zeros(n_genes, dtype=torch.float64, device=dev)
+    d_y = torch.zeros(n_genes, dtype=torch.int8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    have_viterbi = True
+    try:
+        plan.run_viterbi(d_gp.data_ptr(), d_at.data_ptr(), d_y.data_ptr(), 0, stream)
+    except nat.NativeError as e:
+        if e.code != nat.EUNSUPPORTED:
+            raise
+        have_viterbi = False
+
+    def step():
+        plan.run_windowed(d_gp.data_ptr(), d_at.data_ptr(), d_p.data_ptr(), LABEL, stream)
+        if have_viterbi:
+            plan.run_viterbi(d_gp.data_ptr(), d_at.data_ptr(), d_y.data_ptr(), 0, stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    total_genes = n_genes
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        g = torch.tensor([n_genes], dtype=torch.int64, device=dev)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        total_genes = int(g.item())
+
+    # ---- dominant kernel: average launch duration by HIP events on the launch stream
+    kern_ms = plan.time_windowed(d_gp.data_ptr(), d_at.data_ptr(), d_p.data_ptr(), LABEL, stream, warmup=3,
+                                 iters=args.kernel_iters)
+    # algorithmic bytes of one launch: CSR row pointers + attribute ids in,
+    # one fp64 probability per gene out, + the contig table; weight table excluded.
+    alg_bytes = 4 * (n_genes + 1) + 4 * nnz + 8 * n_genes + 4 * len(wl["contig_ptr"])
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get(args.workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "genes/sec CRF decode (windowed fwd-bwd marginals" + (" + Viterbi)" if have_viterbi else ")"),
+        "value": total_genes * args.steps / elapsed,
+        "unit": "genes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {len(wl['contig_ptr']) - 1} contigs, {n_genes} genes, {nnz} domain hits per GPU; "
+                        f"A=35000 synthetic 2-label model, window 20 step 1, pad",
+            "genes_per_gpu": n_genes,
+            "viterbi_in_step": have_viterbi,
+            "sharding": "independent contig shards per rank, no collective",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": plan.kernel_name,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms": kern_ms,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle (C restatement of the CRFsuite tagger driven window by
+        # window like the reference), 1 thread, on a bounded sample of the same workload.
+        from oracle import crf_oracle as orc
+
+        nc = min(len(wl["contig_ptr"]) - 1, 10000)
+        cp = wl["contig_ptr"][: nc + 1]
+        ng = int(cp[-1])
+        t0 = time.perf_counter()
+        p_ref = orc.windowed_marginals(wl["w"], wl["trans"], cp, wl["gene_ptr"][: ng + 1], wl["attr_id"], W, STEP, LABEL, True)
+        dt = time.perf_counter() - t0
+        got = d_p[:ng].cpu().numpy()
+        out["cpu_baseline"] = {
+            "value": ng / dt,
+            "unit": "genes/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"first {nc} contigs ({ng} genes) of the same workload, windowed marginals only, {dt:.1f} s",
+        }
+        out["parity"] = {
+            "max_abs_dp_vs_oracle": float(np.abs(got - p_ref).max()),
+            "cluster_call_mismatches": int(((got > 0.8) != (p_ref > 0.8)).sum()),
+            "genes_checked": ng,
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
