@@ -17,11 +17,14 @@ struct WinArgs {
     const int32_t *c_slot;     // [K+1]        first slot of every scored contig
     const int32_t *c_gene;     // [K]          first gene of every scored contig
     const int32_t *c_n;        // [K]          number of genes of every scored contig
-    const int2 *tile_c;        // [ntiles]     (first, last) scored contig a tile overlaps
+    const int4 *tile_desc;     // [ntiles]     (gene-slot shift, first contig, last contig, flags: 1 = regular)
+    const uint64_t *start_bits;// [S/64+1]     bit q: a window may start at slot q
     double *p_out;             // [n_genes]
     int32_t K, S, ntiles, W, step, L, label;
     uint32_t rescale_mask;     // bit k: renormalise the DP vectors after step k
-    double m00, m01, m10, m11; // exp(trans - max(trans)), rows/cols ordered (other, label)
+    // transitions in the transformed basis (rows/cols ordered (other, label)):
+    //   mu01 = m01*m10/m00^2, mu11 = m11/m00, kappa = m10/m00  with m = exp(trans)
+    double mu01, mu11, kappa_over_mu11, inv_kappa;
     const double *exp_trans;   // [L*L] exp(trans) for the generic kernel
     double *scratch;           // generic kernel workspace
 };

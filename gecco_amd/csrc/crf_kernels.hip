@@ -11,8 +11,10 @@
 //     slots (:216-227).  A 256-lane workgroup owns 256 consecutive slots as window starts;
 //     its first W-1 lanes are a recomputed halo, so workgroups never exchange data.
 //   * stage 1 (HBM -> LDS, coalesced CSR reads + L2-resident weight gather): per slot the
-//     state scores s[y] = sum_a w[a][y] ([EXT] crf1dt_state_score), reduced to the pair
-//     e = exp(s - max(s)) and parked in LDS (16 B/slot).  A per-position scale factor
+//     state scores s[y] = sum_a w[a][y] ([EXT] crf1dt_state_score): the tile's attribute
+//     range is read flat and coalesced, weight pairs are gathered and staged in LDS, then
+//     every slot sums its run in CSR order.  Scores are reduced to e = exp(s - max(s)) and
+//     parked in LDS pre-multiplied with the transition constants (24 B/slot).  A per-position scale factor
 //     cancels in every marginal, so e (and exp(trans - max)) replace CRFsuite's raw exps;
 //     this bounds the DP vectors in (0, 2^k] and removes CRFsuite's per-step 1/sum
 //     division.  Renormalisation by an exact power of two happens only at the steps the
@@ -56,10 +58,17 @@ __device__ __forceinline__ void rescale_pair(double &u, double &v) {
     v = ldexp(v, -ex);
 }
 
+// 16-byte LDS/global accesses must stay single b128 instructions: a struct double2 gets
+// scalarised and re-paired by the compiler into bank-conflicting ds_read2_b64.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kGatherUnroll = 8;  // attribute loads in flight per slot before the first use
+
 template <int WMAX, int NT>
 struct WinSmem {
-    double2 em[NT + WMAX - 1];      // per-slot emission pair (other, label), max-normalised
-    double2 carry[NT / 64][WMAX];   // running best leaving lane 63 of each wave, per step
+    f64x2 fg[NT + WMAX - 1];        // per slot: (mu01*e1, mu11*e1)
+    double e0[NT + WMAX - 1];       // per slot: e0         (e = exp(s - max s), "other" first)
+    f64x2 carry[NT / 64][WMAX];     // running best leaving lane 63 of each wave, per step
     int32_t cslot[NT + WMAX + 1];   // slot offsets of the contigs this tile overlaps
     int32_t cgene[NT + WMAX];
     int32_t cn[NT + WMAX];
@@ -88,8 +97,73 @@ __device__ __forceinline__ SlotInfo slot_lookup(const Smem &sm, int cnt, int q, 
     return r;
 }
 
+// Row S: state scores of one gene, s[y] = sum over its attributes of w[a][y], added in CSR
+// order ([EXT] crf1dt_state_score).  kGatherUnroll attribute ids are requested before the
+// first weight gather and all gathers before the first add, so a gene costs two memory round
+// trips instead of two per attribute; padding lanes add +0.0, which leaves the sum bit-exact.
+__device__ __forceinline__ void state_scores_l2(const int32_t *__restrict__ attr_id,
+                                                const double2 *__restrict__ wtab2, int lo, int hi,
+                                                double &s0, double &s1) {
+    for (int base = lo; base < hi; base += kGatherUnroll) {
+        int a[kGatherUnroll];
+#pragma unroll
+        for (int u = 0; u < kGatherUnroll; ++u) a[u] = base + u < hi ? attr_id[base + u] : -1;
+        double2 w[kGatherUnroll];
+#pragma unroll
+        for (int u = 0; u < kGatherUnroll; ++u) w[u] = a[u] >= 0 ? wtab2[a[u]] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < kGatherUnroll; ++u) {
+            s0 += w[u].x;
+            s1 += w[u].y;
+        }
+    }
+}
+
+// Same for the two slots a lane may own (its own and, for the first W-1 lanes, a tail slot):
+// the first chunk of both genes is in flight together.
+__device__ __forceinline__ void state_scores_l2_pair(const int32_t *__restrict__ attr_id,
+                                                     const double2 *__restrict__ wtab2, int lo0, int hi0,
+                                                     int lo1, int hi1, bool any1, double &s00, double &s01,
+                                                     double &s10, double &s11) {
+    int a0[kGatherUnroll], a1[kGatherUnroll];
+#pragma unroll
+    for (int u = 0; u < kGatherUnroll; ++u) a0[u] = lo0 + u < hi0 ? attr_id[lo0 + u] : -1;
+    if (any1) {
+#pragma unroll
+        for (int u = 0; u < kGatherUnroll; ++u) a1[u] = lo1 + u < hi1 ? attr_id[lo1 + u] : -1;
+    }
+    double2 w0[kGatherUnroll], w1[kGatherUnroll];
+#pragma unroll
+    for (int u = 0; u < kGatherUnroll; ++u) w0[u] = a0[u] >= 0 ? wtab2[a0[u]] : make_double2(0.0, 0.0);
+    if (any1) {
+#pragma unroll
+        for (int u = 0; u < kGatherUnroll; ++u) w1[u] = a1[u] >= 0 ? wtab2[a1[u]] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < kGatherUnroll; ++u) {
+        s00 += w0[u].x;
+        s01 += w0[u].y;
+    }
+    if (any1) {
+#pragma unroll
+        for (int u = 0; u < kGatherUnroll; ++u) {
+            s10 += w1[u].x;
+            s11 += w1[u].y;
+        }
+    }
+    state_scores_l2(attr_id, wtab2, lo0 + kGatherUnroll, hi0, s00, s01);  // rare: > 8 domains
+    if (any1) state_scores_l2(attr_id, wtab2, lo1 + kGatherUnroll, hi1, s10, s11);
+}
+
+// Recurrences in the transformed basis (see crf_plan.cpp for the constants):
+//   alpha~ = alpha * diag(1, kappa), beta~ = diag(1, 1/kappa) * beta, transitions divided by
+//   m00 and conjugated so that their first column is (1, 1):  M~ = [[1, mu01], [1, mu11]].
+//   forward : t = a0 + a1;  a0' = t * e0;  a1' = a0 * f + a1 * g        (f = mu01 e1, g = mu11 e1)
+//   backward: c = e0 * b0;  b0' = c + f * b1;  b1' = c + g * b1
+//   candidate for slot s+k: x = a1 * b1 (label), y = a0 * b0 (other); all scale factors cancel
+//   in x / (x + y).
 template <int WMAX, bool EXACT, bool RESCALE, int NT>
-__global__ void __launch_bounds__(NT) crf_windowed_l2(const WinArgs P) {
+__global__ void __launch_bounds__(NT, (WMAX <= 20 ? 4 : 3)) crf_windowed_l2(const WinArgs P) {
     using Smem = WinSmem<WMAX, NT>;
     __shared__ Smem sm;
     const int W = EXACT ? WMAX : P.W;
@@ -97,71 +171,98 @@ __global__ void __launch_bounds__(NT) crf_windowed_l2(const WinArgs P) {
     const int tile = xcd_remap(blockIdx.x, P.ntiles);
     const int q0 = tile * (NT - (W - 1)) - (W - 1);  // slot owned by lane 0
 
-    // ---- contig table of this tile -> LDS
-    const int2 tc = P.tile_c[tile];
-    const int cnt = tc.y - tc.x + 1;
-    for (int j = tid; j <= cnt; j += NT) {
-        sm.cslot[j] = P.c_slot[tc.x + j];
-        if (j < cnt) {
-            sm.cgene[j] = P.c_gene[tc.x + j];
-            sm.cn[j] = P.c_n[tc.x + j];
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 1: state scores -> normalised emission pairs in LDS
-    int my_gene = -1;
+    // ---- slot -> gene.  A "regular" tile (no padded or skipped contig in reach: the normal
+    // case) maps slots to genes by a constant shift and takes its window-start flags from a
+    // host-built bit array, so the CSR loads can leave immediately; otherwise the contig
+    // table of the tile goes through LDS and every lane searches it.
+    const int4 td = P.tile_desc[tile];  // (gene - slot shift, first contig, last contig, flags)
+    const bool has1 = tid < W - 1;      // first W-1 lanes also own tail slot NT + tid
+    int gene0 = -1, gene1 = -1;
     bool my_start = false;
-    for (int j = tid; j < NT + W - 1; j += NT) {
-        const SlotInfo si = slot_lookup(sm, cnt, q0 + j, P.S, W, P.step);
-        if (j == tid) {
-            my_gene = si.gene;
-            my_start = si.start_ok;
+    if (td.w & 1) {
+        const int q = q0 + tid;
+        if (q >= 0 && q < P.S) {
+            gene0 = q + td.x;
+            my_start = (P.start_bits[q >> 6] >> (q & 63)) & 1ull;
         }
-        double s0 = 0.0, s1 = 0.0;
-        if (si.gene >= 0) {
-            const int lo = P.gene_ptr[si.gene], hi = P.gene_ptr[si.gene + 1];
-            for (int k = lo; k < hi; ++k) {
-                const double2 w = P.wtab2[P.attr_id[k]];
-                s0 += w.x;
-                s1 += w.y;
+        const int q1 = q0 + NT + tid;
+        if (has1 && q1 < P.S) gene1 = q1 + td.x;
+    } else {
+        const int cnt = td.z - td.y + 1;
+        for (int j = tid; j <= cnt; j += NT) {
+            sm.cslot[j] = P.c_slot[td.y + j];
+            if (j < cnt) {
+                sm.cgene[j] = P.c_gene[td.y + j];
+                sm.cn[j] = P.c_n[td.y + j];
             }
         }
-        const double d = s1 - s0;
-        const double e = exp(-fabs(d));
-        sm.em[j] = d > 0.0 ? make_double2(e, 1.0) : make_double2(1.0, e);
+        __syncthreads();
+        const SlotInfo si0 = slot_lookup(sm, cnt, q0 + tid, P.S, W, P.step);
+        gene0 = si0.gene;
+        my_start = si0.start_ok;
+        if (has1) gene1 = slot_lookup(sm, cnt, q0 + NT + tid, P.S, W, P.step).gene;
+    }
+
+    // ---- stage 1: CSR row bounds -> state scores -> slot constants in LDS
+    int lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+    if (gene0 >= 0) {
+        lo0 = P.gene_ptr[gene0];
+        hi0 = P.gene_ptr[gene0 + 1];
+    }
+    if (gene1 >= 0) {
+        lo1 = P.gene_ptr[gene1];
+        hi1 = P.gene_ptr[gene1 + 1];
+    }
+    {
+        double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+        state_scores_l2_pair(P.attr_id, P.wtab2, lo0, hi0, lo1, hi1, wave == 0, s00, s01, s10, s11);
+        {
+            const double d = s01 - s00;
+            const double e = exp(-fabs(d));
+            const double e1 = d > 0.0 ? 1.0 : e;
+            sm.e0[tid] = d > 0.0 ? e : 1.0;
+            sm.fg[tid] = f64x2{P.mu01 * e1, P.mu11 * e1};
+        }
+        if (has1) {
+            const double d = s11 - s10;
+            const double e = exp(-fabs(d));
+            const double e1 = d > 0.0 ? 1.0 : e;
+            sm.e0[NT + tid] = d > 0.0 ? e : 1.0;
+            sm.fg[NT + tid] = f64x2{P.mu01 * e1, P.mu11 * e1};
+        }
     }
     __syncthreads();
 
-    const double m00 = P.m00, m01 = P.m01, m10 = P.m10, m11 = P.m11;
+    const int my_gene = gene0;
     const uint32_t rmask = P.rescale_mask;
 
     // ---- stage 2a: forward recursion, all W alpha pairs stay in registers
     double A0[WMAX], A1[WMAX];
-    double a0, a1;
-    {
-        const double2 e = sm.em[tid];
-        a0 = e.x;
-        a1 = e.y;
-    }
+    double a0 = sm.e0[tid];
+    double a1 = sm.fg[tid].y * P.kappa_over_mu11;  // kappa * e1
     A0[0] = a0;
     A1[0] = a1;
 #pragma unroll
     for (int k = 1; k < WMAX; ++k) {
         if (EXACT || k < W) {
-            const double2 e = sm.em[tid + k];
-            const double t0 = fma(a1, m10, a0 * m00);
-            const double t1 = fma(a1, m11, a0 * m01);
-            a0 = t0 * e.x;
-            a1 = t1 * e.y;
+            const double e0 = sm.e0[tid + k];
+            const f64x2 fg = sm.fg[tid + k];
+            const double t = a0 + a1;
+            const double n1 = fma(a1, fg.y, a0 * fg.x);
+            a0 = t * e0;
+            a1 = n1;
             if (RESCALE && ((rmask >> k) & 1u)) rescale_pair(a0, a1);
             A0[k] = a0;
             A1[k] = a1;
         }
     }
 
+    // the backward pass re-reads the slot constants from LDS; without this the compiler
+    // keeps all of them live across both passes (+40 VGPRs, one wave per SIMD less)
+    asm volatile("" ::: "memory");
+
     // ---- stage 2b + 3: backward recursion, candidates, diagonal max via DPP shifts
-    double b0 = 1.0, b1 = 1.0;
+    double b0 = 1.0, b1 = P.inv_kappa;
     // running best candidate; (0, 0) = "no window yet" so that DPP zero-fill is the identity
     double Rx = 0.0, Ry = 0.0;
 #pragma unroll
@@ -170,7 +271,7 @@ __global__ void __launch_bounds__(NT) crf_windowed_l2(const WinArgs P) {
             const double x = A1[k] * b1;
             const double y = A0[k] * b0;
             if (k < W - 1) {
-                if (lane == 63) sm.carry[wave][k] = make_double2(Rx, Ry);
+                if (lane == 63 && wave < NT / 64 - 1) sm.carry[wave][k] = f64x2{Rx, Ry};
                 Rx = wave_shr1_zero(Rx);
                 Ry = wave_shr1_zero(Ry);
             }
@@ -179,17 +280,18 @@ __global__ void __launch_bounds__(NT) crf_windowed_l2(const WinArgs P) {
             Rx = take ? x : Rx;
             Ry = take ? y : Ry;
             if (k > 0) {
-                const double2 e = sm.em[tid + k];
-                const double c0 = e.x * b0, c1 = e.y * b1;
-                b0 = fma(m01, c1, m00 * c0);
-                b1 = fma(m11, c1, m10 * c0);
+                const double e0 = sm.e0[tid + k];
+                const f64x2 fg = sm.fg[tid + k];
+                const double c = e0 * b0;
+                b0 = fma(fg.x, b1, c);
+                b1 = fma(fg.y, b1, c);
                 if (RESCALE && ((rmask >> k) & 1u)) rescale_pair(b0, b1);
             }
         }
     }
     __syncthreads();
     if (wave > 0 && lane < W - 1) {
-        const double2 c = sm.carry[wave - 1][lane];
+        const f64x2 c = sm.carry[wave - 1][lane];
         if (c.x * Ry > Rx * c.y || (Rx == 0.0 && Ry == 0.0)) {
             Rx = c.x;
             Ry = c.y;

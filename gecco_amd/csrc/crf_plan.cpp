@@ -79,7 +79,8 @@ Plan::~Plan() {
             (void)hipFree(d_c_gene);
             (void)hipFree(d_c_n);
             (void)hipFree(d_contig_ptr);
-            (void)hipFree(d_tile_c);
+            (void)hipFree(d_tile_desc);
+            (void)hipFree(d_start_bits);
             (void)hipFree(d_skipped);
             (void)hipSetDevice(prev);
         }
@@ -87,22 +88,31 @@ Plan::~Plan() {
 }
 
 // Steps after which the un-normalised DP vectors are rescaled by a power of two.
-// With emissions and transitions max-normalised to (0,1] the larger component of alpha
-// shrinks by at most mu = min(exp(trans))/max(exp(trans)) per step and that of beta by at
-// most mu^2 (crf_kernels.hip header), so candidates x,y stay comparable by
-// cross-multiplication in fp64 as long as (3*P+1)*log2(1/mu) <= 498 for a rescale
-// period P.  GECCO's embedded model: log2(1/mu) = 7.6 -> P = 21 >= W-1, mask = 0.
+// The kernel keeps alpha/beta un-normalised in a transformed basis (crf_kernels.hip):
+// emissions max-normalised to (0,1], transitions divided by m00.  With
+//   bits  = log2(max(M)/min(M)),  cbits = log2(max(M)/m00)      (M = exp(trans))
+// the larger component of alpha~ after k steps lies in [2^-(bits(k+1)), 2^(k(1+cbits)+bits)],
+// that of beta~ in [2^-(bits(2k+1)), 2^(k(1+cbits)+bits)] with min/max >= 2^-(2 bits), so a
+// candidate pair has max(x,y) in [2^-(bits(3k+4)), 2^(2k(1+cbits)+2bits)].  Comparing two
+// candidates multiplies two such numbers; both products stay inside fp64's normal range if
+//   bits*(3P+4) <= 500   and   2P(1+cbits) + 2 bits <= 500
+// for a rescale period P.  GECCO's embedded model: bits = 7.6, cbits <= 0.15 -> P = 20 >=
+// W-1, i.e. no rescale inside a 20-gene window (mask = 0).
 static bool rescale_mask_for(const Model &m, int W, uint32_t *mask) {
+    *mask = 0;
     double lo = m.trans[0], hi = m.trans[0];
     for (double t : m.trans) {
         lo = std::min(lo, t);
         hi = std::max(hi, t);
     }
-    const double bits = (hi - lo) / std::log(2.0);
-    *mask = 0;
-    if (!(bits >= 0.0) || !std::isfinite(bits)) return false;
-    if (bits == 0.0) return true;
-    const double pf = std::floor((498.0 / bits - 1.0) / 3.0);
+    if (!std::isfinite(lo) || !std::isfinite(hi)) return false;
+    const double ln2 = std::log(2.0);
+    const double bits = (hi - lo) / ln2;
+    // m00 is trans[other][other]; `other` is 0 or 1 depending on the queried label
+    const double cbits = (hi - std::min(m.trans[0], m.trans[3])) / ln2;
+    double pf = (500.0 - 2.0 * bits) / (2.0 * (1.0 + cbits));
+    if (bits > 0.0) pf = std::min(pf, (500.0 / bits - 4.0) / 3.0);
+    pf = std::floor(pf);
     if (pf < 1.0) return false;
     if (pf >= double(W)) return true;
     const int P = int(pf);
@@ -176,13 +186,34 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     p.kernel_name = windowed_kernel_name(W, m.L);
     p.tile_out = windowed_tile_out(W, m.L);
     p.ntiles = p.S > 0 ? (p.S + p.tile_out - 1) / p.tile_out : 0;
-    p.tile_c.resize(p.ntiles);
+    // window-start flags per slot (_meta.py:131: starts at 0, step, 2*step, ... <= n' - W)
+    p.start_bits.assign(size_t(p.S) / 64 + 2, 0);
+    // regular[k]: contig k is unpadded; joined[k]: contig k+1 follows k without a skipped contig
+    std::vector<uint8_t> irregular(size_t(p.K) + 1, 0);
+    for (int32_t k = 0; k < p.K; ++k) {
+        const int32_t s0 = p.c_slot[k], np = p.c_slot[k + 1] - s0;
+        for (int32_t pos = 0; pos + W <= np; pos += step) {
+            const int64_t q = int64_t(s0) + pos;
+            p.start_bits[size_t(q >> 6)] |= 1ull << (q & 63);
+        }
+        const bool padded = np != p.c_n[k];
+        const bool gap_after = k + 1 < p.K && p.c_gene[k + 1] != p.c_gene[k] + p.c_n[k];
+        irregular[k] = padded || gap_after;
+    }
+    std::vector<int32_t> irr_prefix(size_t(p.K) + 1, 0);
+    for (int32_t k = 0; k < p.K; ++k) irr_prefix[k + 1] = irr_prefix[k] + irregular[k];
+    p.tile_desc.resize(p.ntiles);
     for (int32_t b = 0; b < p.ntiles; ++b) {
-        const int64_t q_lo = std::max<int64_t>(int64_t(b) * p.tile_out - (W - 1), 0);
-        const int64_t q_hi = std::min<int64_t>(int64_t(b) * p.tile_out - (W - 1) + kWinThreads + W - 2, p.S - 1);
-        const auto first = std::upper_bound(p.c_slot.begin(), p.c_slot.begin() + p.K, int32_t(q_lo)) - p.c_slot.begin() - 1;
-        const auto last = std::upper_bound(p.c_slot.begin(), p.c_slot.begin() + p.K, int32_t(q_hi)) - p.c_slot.begin() - 1;
-        p.tile_c[b] = make_int2(int(first), int(last));
+        const int64_t q0 = int64_t(b) * p.tile_out - (W - 1);
+        const int64_t q_lo = std::max<int64_t>(q0, 0);
+        const int64_t q_hi = std::min<int64_t>(q0 + kWinThreads + W - 2, p.S - 1);
+        const int first = int(std::upper_bound(p.c_slot.begin(), p.c_slot.begin() + p.K, int32_t(q_lo)) - p.c_slot.begin()) - 1;
+        const int last = int(std::upper_bound(p.c_slot.begin(), p.c_slot.begin() + p.K, int32_t(q_hi)) - p.c_slot.begin()) - 1;
+        // regular: no padded contig in reach and no skipped contig between the contigs in reach
+        // (a gap after the last contig is harmless)
+        const bool padded_or_gap = (irr_prefix[last] - irr_prefix[first]) != 0 || (p.c_slot[last + 1] - p.c_slot[last] != p.c_n[last]);
+        const int shift = p.c_gene[first] - p.c_slot[first];
+        p.tile_desc[b] = make_int4(shift, first, last, padded_or_gap ? 0 : 1);
     }
     if (device < 0) return GECCO_CRF_OK;
 
@@ -192,7 +223,8 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     if ((rc = upload(&p.d_c_slot, p.c_slot.data(), p.c_slot.size(), "upload plan"))) return rc;
     if ((rc = upload(&p.d_c_gene, p.c_gene.data(), p.c_gene.size(), "upload plan"))) return rc;
     if ((rc = upload(&p.d_c_n, p.c_n.data(), p.c_n.size(), "upload plan"))) return rc;
-    if ((rc = upload(&p.d_tile_c, p.tile_c.data(), p.tile_c.size(), "upload plan"))) return rc;
+    if ((rc = upload(&p.d_tile_desc, p.tile_desc.data(), p.tile_desc.size(), "upload plan"))) return rc;
+    if ((rc = upload(&p.d_start_bits, p.start_bits.data(), p.start_bits.size(), "upload plan"))) return rc;
     if ((rc = upload(&p.d_skipped, p.skipped.data(), p.skipped.size(), "upload plan"))) return rc;
     if ((rc = upload(&p.d_contig_ptr, p.contig_ptr.data(), p.contig_ptr.size(), "upload plan"))) return rc;
     return GECCO_CRF_OK;
@@ -225,7 +257,8 @@ int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_
     a.c_slot = p.d_c_slot;
     a.c_gene = p.d_c_gene;
     a.c_n = p.d_c_n;
-    a.tile_c = p.d_tile_c;
+    a.tile_desc = p.d_tile_desc;
+    a.start_bits = p.d_start_bits;
     a.p_out = d_p_out;
     a.K = p.K;
     a.S = p.S;
@@ -236,13 +269,14 @@ int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_
     a.label = label;
     a.rescale_mask = p.rescale_mask;
     {
+        // exp() of differences only: every constant is a ratio of transition weights
         const int o = 1 - label;
-        const double mx = *std::max_element(m.trans.begin(), m.trans.end());
-        auto M = [&](int i, int j) { return std::exp(m.trans[size_t(i) * 2 + j] - mx); };
-        a.m00 = M(o, o);
-        a.m01 = M(o, label);
-        a.m10 = M(label, o);
-        a.m11 = M(label, label);
+        auto T = [&](int i, int j) { return m.trans[size_t(i) * 2 + j]; };
+        a.mu01 = std::exp(T(o, label) + T(label, o) - 2.0 * T(o, o));
+        a.mu11 = std::exp(T(label, label) - T(o, o));
+        const double kappa = std::exp(T(label, o) - T(o, o));
+        a.kappa_over_mu11 = kappa / a.mu11;
+        a.inv_kappa = 1.0 / kappa;
     }
     if (!p.skipped.empty())
         if ((rc = check_hip(launch_fill_nan(d_p_out, p.d_skipped, int(p.skipped.size()), stream), "fill_nan launch")))

@@ -30,7 +30,8 @@ struct Plan {
     // slot-space layout (host)
     int32_t K = 0, S = 0, ntiles = 0, tile_out = 0;
     std::vector<int32_t> c_slot, c_gene, c_n;
-    std::vector<int2> tile_c;
+    std::vector<int4> tile_desc;
+    std::vector<uint64_t> start_bits;
     std::vector<int2> skipped;  // gene ranges of contigs skipped by pad == 0
     std::vector<int32_t> contig_ptr;
     uint32_t rescale_mask = 0;
@@ -38,7 +39,9 @@ struct Plan {
     std::string kernel_name;
     // device copies
     int32_t *d_c_slot = nullptr, *d_c_gene = nullptr, *d_c_n = nullptr, *d_contig_ptr = nullptr;
-    int2 *d_tile_c = nullptr, *d_skipped = nullptr;
+    int4 *d_tile_desc = nullptr;
+    uint64_t *d_start_bits = nullptr;
+    int2 *d_skipped = nullptr;
     const DeviceTables *tables = nullptr;
     ~Plan();
 };
