@@ -1,0 +1,379 @@
+"""Drop-in ``ClusterCRF`` for GECCO's ``crf_type=`` injection point, backed by the HIP engine.
+
+Mirror of ``/root/reference/gecco/crf/__init__.py:55-273`` (the inference half): same class
+surface -- ``trained`` / ``__init__`` / ``predict_probabilities`` / ``fit`` / ``save`` and the
+attributes ``feature_type window_size window_step algorithm significance
+significant_features model`` -- same argument meaning, same warnings and errors.  GECCO hands
+a *class* down its CLI (``gecco/cli/commands/__init__.py:127-137,160-163``) and calls
+``crf_type.trained(model)`` then ``.predict_probabilities(genes, pad=, progress=)``
+(``gecco/cli/commands/_common.py:577,588-592``); use it as::
+
+    import gecco.cli, gecco_amd.crf
+    gecco.cli.main(crf_type=gecco_amd.crf.ClusterCRF)
+
+What differs is where the arithmetic runs: instead of one python-crfsuite call per sliding
+window (``:253``), every contig of the call is packed into one CSR batch and scored by the
+HIP kernels through the C ABI (``include/gecco_crf.h``).  There is no CPU fallback.
+"""
+import itertools
+import operator
+import os
+import warnings
+from typing import Any, Callable, Dict, FrozenSet, Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _native, packing, pickle_model
+
+__all__ = ["ClusterCRF", "NotFittedError"]
+
+try:  # the reference documents sklearn's NotFittedError (crf/__init__.py:176)
+    from sklearn.exceptions import NotFittedError
+except Exception:  # pragma: no cover
+
+    class NotFittedError(ValueError, AttributeError):  # type: ignore
+        pass
+
+
+class _CRFSuiteModelView:
+    """What ``ClusterCRF.model`` exposes of a fitted ``sklearn_crfsuite.CRF`` [EXT], rebuilt
+    from the CRFsuite model blob: ``classes_``, ``attributes_``, ``state_features_``,
+    ``transition_features_``, ``predict_marginals_single`` / ``predict_single``.
+    Hyper-parameters of the pickled estimator (``c1``, ``c2`` ...) are kept as attributes."""
+
+    def __init__(self, native_model: "_native.Model", params: Optional[Dict[str, Any]] = None,
+                 training_log: Any = None):
+        self.native = native_model
+        self.training_log_ = training_log
+        for k, v in (params or {}).items():
+            if not hasattr(self, k):
+                setattr(self, k, v)
+        self.classes_: List[str] = native_model.labels()
+        self.attributes_: List[str] = native_model.attrs()
+        self._attr_index: Dict[str, int] = {a: i for i, a in enumerate(self.attributes_)}
+        self._state: Optional[Dict[Tuple[str, str], float]] = None
+        self._trans: Optional[Dict[Tuple[str, str], float]] = None
+
+    # [EXT] sklearn-crfsuite parses these back from CRFsuite's text dump, which prints weights
+    # with "%f": values are rounded to 6 decimals there, and so they are here.
+    @property
+    def state_features_(self) -> Dict[Tuple[str, str], float]:
+        if self._state is None:
+            w, present = self.native.state_weights()
+            a_idx, l_idx = np.nonzero(present)
+            self._state = {
+                (self.attributes_[a], self.classes_[l]): float("%f" % w[a, l]) for a, l in zip(a_idx.tolist(), l_idx.tolist())
+            }
+        return self._state
+
+    @property
+    def transition_features_(self) -> Dict[Tuple[str, str], float]:
+        if self._trans is None:
+            w, present = self.native.trans_weights()
+            self._trans = {
+                (self.classes_[i], self.classes_[j]): float("%f" % w[i, j])
+                for i in range(len(self.classes_)) for j in range(len(self.classes_)) if present[i, j]
+            }
+        return self._trans
+
+    @property
+    def num_attributes_(self) -> int:
+        return self.native.num_attrs
+
+    def _pack_single(self, xseq: Sequence[Dict[str, Any]]):
+        gene_ptr = [0]
+        attr: List[int] = []
+        for item in xseq:
+            for name, value in item.items():
+                if value is not True and value != 1:
+                    raise ValueError("only boolean/unit feature values are supported (GECCO emits {name: True})")
+                idx = self._attr_index.get(name)
+                if idx is not None:
+                    attr.append(idx)
+            gene_ptr.append(len(attr))
+        return np.array([0, len(xseq)], dtype=np.int32), np.array(gene_ptr, dtype=np.int32), np.array(attr, dtype=np.int32)
+
+    def predict_marginals_single(self, xseq: Sequence[Dict[str, Any]], device: int = 0) -> List[Dict[str, float]]:
+        """[EXT] ``CRF.predict_marginals_single``: whole-sequence marginals of every label."""
+        if len(xseq) == 0:
+            return []
+        cptr, gptr, attr = self._pack_single(xseq)
+        marg, _ = self.native.marginals_full(cptr, gptr, attr, device=device)
+        return [dict(zip(self.classes_, row.tolist())) for row in marg]
+
+    def predict_single(self, xseq: Sequence[Dict[str, Any]], device: int = 0) -> List[str]:
+        """[EXT] ``CRF.predict_single``: Viterbi labels."""
+        if len(xseq) == 0:
+            return []
+        cptr, gptr, attr = self._pack_single(xseq)
+        y, _ = self.native.viterbi(cptr, gptr, attr, device=device)
+        return [self.classes_[i] for i in y.tolist()]
+
+
+def _default_devices() -> List[int]:
+    env = os.environ.get("GECCO_HIP_DEVICES", "").strip()
+    if env:
+        return [int(x) for x in env.split(",") if x.strip() != ""]
+    return [0]
+
+
+class ClusterCRF(object):
+    """A GECCO-compatible CRF whose inference runs on MI355X."""
+
+    _FILENAME = pickle_model.MODEL_FILENAME
+    #: contigs are scored in launches of at most this many genes, `progress` is called after each
+    _BATCH_GENES = 1 << 22
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def trained(cls, model_path: Union[str, os.PathLike, Any, None] = None) -> "ClusterCRF":
+        """Load a pre-trained model directory (``model.pkl`` + ``model.pkl.md5``).
+
+        Must be overridden rather than inherited: the pickle hard-codes
+        ``gecco.crf.ClusterCRF``.  Raises ``ValueError("MD5 hash of model data does not match
+        signature")`` like the reference (``gecco/crf/__init__.py:96-97``).
+        """
+        if model_path is None:
+            model_path = cls._embedded_model_dir()
+        record = pickle_model.load_model_dir(model_path)
+        st = record.state
+        self = cls.__new__(cls)
+        self.feature_type = st.get("feature_type", "protein")
+        self.window_size = st.get("window_size", 5)
+        self.window_step = st.get("window_step", 1)
+        self.algorithm = st.get("algorithm", "lbfgs")
+        self.significance = st.get("significance")
+        self.significant_features = st.get("significant_features")
+        self._options = st.get("_options", {"algorithm": self.algorithm})
+        self._record = record
+        self.devices = _default_devices()
+        crf_state = st["model"].state if st.get("model") is not None else None
+        if crf_state is None:
+            self.model = None
+        else:
+            params = {k: v for k, v in crf_state.items() if k not in ("modelfile", "training_log_", "_tagger", "_info_cached")}
+            native = _native.Model.from_lcrf(pickle_model.crfsuite_blob(record))
+            self.model = _CRFSuiteModelView(native, params, crf_state.get("training_log_"))
+        return self
+
+    @staticmethod
+    def _embedded_model_dir():
+        """Directory of the embedded model: GECCO's own package data when GECCO is installed
+        (``files("gecco.crf")``, crf/__init__.py:78), else $GECCO_AMD_MODEL_DIR."""
+        env = os.environ.get("GECCO_AMD_MODEL_DIR")
+        if env:
+            return env
+        try:
+            from importlib.resources import files
+            import importlib.util
+
+            spec = importlib.util.find_spec("gecco")
+            if spec is not None and spec.submodule_search_locations:
+                import pathlib
+
+                for loc in spec.submodule_search_locations:
+                    cand = pathlib.Path(loc) / "crf"
+                    if (cand / "model.pkl").exists():
+                        return cand
+            return files("gecco.crf")
+        except Exception as err:
+            raise FileNotFoundError(
+                "no embedded model: GECCO is not installed; pass a model directory or set GECCO_AMD_MODEL_DIR"
+            ) from err
+
+    def __init__(self, feature_type: str = "protein", algorithm: str = "lbfgs", window_size: int = 5,
+                 window_step: int = 1, **kwargs: Any) -> None:
+        # same checks, same messages as gecco/crf/__init__.py:132-137
+        if feature_type not in {"protein", "domain"}:
+            raise ValueError(f"invalid feature type: {feature_type!r}")
+        if window_size <= 0:
+            raise ValueError("Window size must be strictly positive")
+        if window_step <= 0 or window_step > window_size:
+            raise ValueError("Window step must be strictly positive and under `window_size`")
+        self.feature_type = feature_type
+        self.window_size = window_size
+        self.window_step = window_step
+        self.algorithm = algorithm
+        self.significance: Optional[Dict[str, float]] = None
+        self.significant_features: Optional[FrozenSet[str]] = None
+        self.model: Optional[_CRFSuiteModelView] = None
+        self._options = {"algorithm": algorithm, **kwargs}
+        self._record = None
+        self.devices = _default_devices()
+
+    # ------------------------------------------------------------------ inference
+    def predict_probabilities(self, genes: Iterable[Any], *, pad: bool = True,
+                              progress: Optional[Callable[[int, int], None]] = None) -> List[Any]:
+        """Predict how likely each gene is to be part of a gene cluster.
+
+        Same contract as ``gecco/crf/__init__.py:148-273``: genes are sorted by
+        ``(source.id, start)`` and their domains by ``start`` (in place, like the reference),
+        grouped by contig; contigs shorter than the window are centre-padded (``pad=True``,
+        with the reference's warning) or skipped; every gene gets the maximum, over the
+        sliding windows covering it, of the window-local marginal P(label '1'); domains get
+        ``cluster_weight`` from the model's state features; new ``Gene`` objects are returned
+        in sorted order.
+        """
+        _progress = progress or (lambda x, y: None)
+        if self.model is None:
+            raise NotFittedError("This ClusterCRF instance is not fitted yet.")
+        if self.feature_type not in ("protein", "domain"):
+            raise ValueError(f"invalid feature type: {self.feature_type!r}")
+
+        # :199-206 -- sort (mutating the caller's domain lists, as the reference does), group
+        genes = sorted(genes, key=operator.attrgetter("source.id", "start"))
+        for gene in genes:
+            gene.protein.domains.sort(key=operator.attrgetter("start"))
+        contigs: List[List[Any]] = [list(g) for _, g in itertools.groupby(genes, key=operator.attrgetter("source.id"))]
+
+        # :209-236 -- features -> CSR items; decide padding / skipping per contig
+        W, step = self.window_size, self.window_step
+        batch = packing.pack_contigs(contigs, self.model._attr_index, self.feature_type)
+        scored = np.ones(len(contigs), dtype=bool)
+        total = 0
+        for ci, contig in enumerate(contigs):
+            n_items = int(batch.item_ptr[ci + 1] - batch.item_ptr[ci])
+            if n_items < W:
+                if pad:
+                    unit = self.feature_type if W - n_items == 1 else f"{self.feature_type}s"
+                    warnings.warn(
+                        f"Contig {contig[0].source.id!r} does not contain enough"
+                        f" {self.feature_type}s ({len(contig)}) for sliding window"
+                        f" of size {W}, padding with"
+                        f" {W - n_items} {unit}"
+                    )
+                else:
+                    warnings.warn(
+                        f"Contig {contig[0].source.id!r} does not contain enough"
+                        f" {self.feature_type}s ({len(contig)}) for sliding window"
+                        f" of size {W}"
+                    )
+                    scored[ci] = False
+                    continue
+            total += max(n_items, W) - W + 1  # :239
+        _progress(0, total)
+
+        # :244-258 -- windowed marginals of label '1', batched over contigs
+        label = self.model.native.label_id("1")
+        if label < 0:
+            raise ValueError("the model has no label '1'")
+        p_items = self._score(batch, W, step, label, pad, _progress, total)
+
+        # :258, features.py:74-120 -- annotate genes; skipped contigs pass through unchanged
+        predicted: List[Any] = []
+        for ci, contig in enumerate(contigs):
+            if not scored[ci]:
+                predicted.extend(contig)
+                continue
+            i0 = int(batch.item_ptr[ci])
+            if self.feature_type == "protein":
+                for k, gene in enumerate(contig):
+                    predicted.append(gene.with_probability(float(p_items[i0 + k])))
+            else:
+                k = i0
+                for gene in contig:
+                    doms = gene.protein.domains
+                    if doms:
+                        predicted.append(gene.with_protein(gene.protein.with_domains(
+                            [d.with_probability(float(p_items[k + j])) for j, d in enumerate(doms)])))
+                        k += len(doms)
+                    else:
+                        predicted.append(gene.with_probability(float(p_items[k])))
+                        k += 1
+
+        # :261-269 -- cluster weight = state feature weight of (domain, '1'), None if absent
+        weights = self.model.state_features_
+        return [
+            gene.with_protein(gene.protein.with_domains(
+                domain.with_cluster_weight(weights.get((domain.name, "1"))) for domain in gene.protein.domains
+            ))
+            for gene in predicted
+        ]
+
+    def predict_probabilities_csr(self, contig_ptr, gene_ptr, attr_id, *, pad: bool = True, label: str = "1",
+                                  device: Optional[int] = None) -> np.ndarray:
+        """Columnar entry point: the same scores for an already packed CSR batch (ids from
+        ``self.model.attributes_``); returns one float64 per gene (NaN = contig skipped)."""
+        if self.model is None:
+            raise NotFittedError("This ClusterCRF instance is not fitted yet.")
+        lab = self.model.native.label_id(label)
+        return self.model.native.windowed_marginals(contig_ptr, gene_ptr, attr_id, self.window_size, self.window_step,
+                                                    lab, pad, device=self.devices[0] if device is None else device)
+
+    def _score(self, batch: "packing.PackedBatch", W: int, step: int, label: int, pad: bool,
+               progress: Callable[[int, int], None], total: int) -> np.ndarray:
+        """Run the batch through the HIP engine in launches of <= _BATCH_GENES items, sharded
+        over ``self.devices`` (greedy by item count, independent launches, no collective)."""
+        n_contigs = len(batch.item_ptr) - 1
+        out = np.full(int(batch.item_ptr[-1]), np.nan, dtype=np.float64)
+        if n_contigs == 0:
+            return out
+        native = self.model.native
+        # split into contiguous contig ranges of bounded size
+        ranges: List[Tuple[int, int]] = []
+        c0 = 0
+        while c0 < n_contigs:
+            c1 = c0 + 1
+            while c1 < n_contigs and batch.item_ptr[c1 + 1] - batch.item_ptr[c0] <= self._BATCH_GENES:
+                c1 += 1
+            ranges.append((c0, c1))
+            c0 = c1
+        done = 0
+
+        def run(rng: Tuple[int, int], device: int) -> Tuple[Tuple[int, int], np.ndarray]:
+            a, b = rng
+            i0, i1 = int(batch.item_ptr[a]), int(batch.item_ptr[b])
+            cptr = (batch.item_ptr[a:b + 1] - i0).astype(np.int32)
+            gptr = (batch.attr_ptr[i0:i1 + 1] - batch.attr_ptr[i0]).astype(np.int32)
+            attr = batch.attr_id[int(batch.attr_ptr[i0]):int(batch.attr_ptr[i1])]
+            return rng, native.windowed_marginals(cptr, gptr, attr, W, step, label, pad, device=device)
+
+        devices = self.devices or [0]
+        if len(devices) == 1 or len(ranges) == 1:
+            results = (run(r, devices[0]) for r in ranges)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+
+            pool = ThreadPoolExecutor(max_workers=len(devices))
+            futs = [pool.submit(run, r, devices[i % len(devices)]) for i, r in enumerate(ranges)]
+            results = (f.result() for f in futs)
+        for (a, b), p in results:
+            i0, i1 = int(batch.item_ptr[a]), int(batch.item_ptr[b])
+            out[i0:i1] = p
+            for ci in range(a, b):
+                n_items = int(batch.item_ptr[ci + 1] - batch.item_ptr[ci])
+                if n_items >= W or pad:
+                    done += max(n_items, W) - W + 1
+            progress(done, total)
+        return out
+
+    # ------------------------------------------------------------------ training (delegated)
+    def fit(self, genes: Iterable[Any], **kwargs: Any) -> None:
+        """Training is outside this engine's scope: delegate to the reference
+        implementation when sklearn-crfsuite is importable (``gecco/crf/__init__.py:275-378``)."""
+        try:
+            from gecco.crf import ClusterCRF as _Reference  # type: ignore
+        except Exception as err:
+            raise NotImplementedError(
+                "ClusterCRF.fit needs GECCO with sklearn-crfsuite (L-BFGS training runs in CRFsuite)"
+            ) from err
+        ref = _Reference(self.feature_type, self.algorithm, self.window_size, self.window_step,
+                         **{k: v for k, v in self._options.items() if k != "algorithm"})
+        ref.fit(genes, **kwargs)
+        import tempfile
+
+        with tempfile.TemporaryDirectory() as tmp:
+            ref.save(tmp)
+            fitted = type(self).trained(tmp)
+        self.__dict__.update(fitted.__dict__)
+
+    def save(self, model_path: Union[str, os.PathLike]) -> None:
+        """Write ``model.pkl`` (protocol 4) + ``model.pkl.md5`` loadable by stock GECCO
+        (``gecco/crf/__init__.py:380-402``)."""
+        if self._record is None:
+            raise NotFittedError("This ClusterCRF instance is not fitted yet.")
+        st = self._record.state
+        st.update(feature_type=self.feature_type, window_size=self.window_size, window_step=self.window_step,
+                  algorithm=self.algorithm, significance=self.significance,
+                  significant_features=self.significant_features)
+        pickle_model.dump_model_dir(self._record, model_path)

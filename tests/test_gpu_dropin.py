@@ -1,0 +1,72 @@
+"""GPU end-to-end: the drop-in ``ClusterCRF`` (real HIP engine, no stand-ins) reproduces the
+reference's golden tables for ``gecco run`` on BGC0001866 (features -> genes -> clusters)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from tests.helpers import GOLDEN, read_tsv
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_run_through_dropin_class():
+    from gecco_amd import _native, refine
+    from gecco_amd.crf import ClusterCRF
+    from tests.test_host_logic import _golden_genes
+
+    assert _native.device_count() >= 1
+    crf = ClusterCRF.trained(GOLDEN)
+    calls = []
+    out = crf.predict_probabilities(_golden_genes(), progress=lambda i, t: calls.append((i, t)))
+    rows = read_tsv(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))
+    assert [g.protein.id for g in out] == [r["protein_id"] for r in rows]
+    err = max(abs(g.average_probability - float(r["average_p"])) for g, r in zip(out, rows))
+    assert err <= 1e-14, err
+    assert calls[0] == (0, 4) and calls[-1] == (4, 4)
+    clusters = list(refine.ClusterRefiner(threshold=0.8, n_cds=3).iter_clusters(out))
+    row = read_tsv(os.path.join(GOLDEN, "BGC0001866.clusters.tsv"))[0]
+    assert len(clusters) == 1
+    c = clusters[0]
+    assert (c.id, c.start, c.end) == (row["cluster_id"], int(row["start"]), int(row["end"]))
+    assert abs(c.average_probability - float(row["average_p"])) <= 1e-14
+    assert abs(c.maximum_probability - float(row["max_p"])) <= 1e-14
+
+
+def test_many_contigs_objects_vs_oracle(oracle_model):
+    """Object-level API on a multi-contig batch incl. short contigs, batched launches."""
+    from gecco_amd.crf import ClusterCRF
+    from gecco_amd.model import Domain, Gene, Protein, Source, Strand
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(3)
+    attrs = oracle_model["attrs"]
+    genes, cptr, gptr, attr = [], [0], [0], []
+    for c in range(40):
+        n = int(rng.integers(3, 120))
+        for i in range(n):
+            k = int(rng.integers(0, 4))
+            ids = rng.integers(0, len(attrs), size=k)
+            doms = [Domain(attrs[a], 10 * j + 1, 10 * j + 9, "Pfam", 1e-10, 1e-12) for j, a in enumerate(ids)]
+            if rng.random() < 0.1:
+                doms.append(Domain("PF99999", 500, 510, "Pfam", 1e-10, 1e-12))  # unknown to the model
+            genes.append(Gene(Source(f"contig_{c:03d}"), 1000 * i, 1000 * i + 900, Strand.Coding, Protein(f"c{c:03d}_{i}", None, doms)))
+            seen = []
+            for a in ids.tolist():
+                if a not in seen:
+                    seen.append(a)
+            attr += seen
+            gptr.append(len(attr))
+        cptr.append(cptr[-1] + n)
+    crf = ClusterCRF.trained(GOLDEN)
+    crf._BATCH_GENES = 500  # force several launches
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = crf.predict_probabilities(list(reversed(genes)), pad=True)
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, True)
+    got = np.array([g.average_probability for g in out])
+    assert np.abs(got - exp).max() <= 1e-12
+    # columnar entry point gives the same numbers
+    p = crf.predict_probabilities_csr(cptr, gptr, attr)
+    assert np.abs(p - exp).max() <= 1e-12

@@ -1,0 +1,294 @@
+"""CPU tests of the host side of the drop-in: model pickle handling, packing, the
+``ClusterCRF`` wrapper semantics (sorting, padding, warnings, annotation, cluster weights),
+the refiner and the TSV tables.  Where a test needs window scores without a GPU the ORACLE
+stands in for the engine (tests may do that; the product never does)."""
+import math
+import os
+import pickle
+import shutil
+import statistics
+import warnings
+
+import numpy as np
+import pytest
+
+from gecco_amd import crf as crf_mod
+from gecco_amd import packing, pickle_model, refine, tables
+from gecco_amd.model import Cluster, Domain, Gene, Protein, Source, Strand
+from tests.helpers import GOLDEN, read_tsv
+
+
+@pytest.fixture(scope="module")
+def trained():
+    return crf_mod.ClusterCRF.trained(GOLDEN)
+
+
+@pytest.fixture()
+def oracle_engine(monkeypatch, oracle_model):
+    """Route Model.windowed_marginals to the CPU oracle so that host logic runs without a GPU."""
+    from gecco_amd import _native
+    from oracle import crf_oracle as orc
+
+    def fake(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True, device=0):
+        return orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], contig_ptr, gene_ptr, attr_id,
+                                      window, step, label, pad)
+
+    monkeypatch.setattr(_native.Model, "windowed_marginals", fake)
+
+
+def _gene(contig, pid, start, domains):
+    return Gene(Source(contig), start, start + 100, Strand.Coding,
+                Protein(pid, None, [Domain(n, s, s + 10, "Pfam", 1e-10, 1e-12) for n, s in domains]))
+
+
+# ---------------------------------------------------------------- model pickle
+def test_trained_attributes(trained):
+    assert (trained.feature_type, trained.window_size, trained.window_step, trained.algorithm) == ("protein", 20, 1, "lbfgs")
+    assert len(trained.significance) == 11064 and len(trained.significant_features) == 2766
+    m = trained.model
+    assert m.classes_ == ["0", "1"] and len(m.attributes_) == 2659
+    assert (m.c1, m.c2) == (0.4, 0.0)
+    sf = m.state_features_
+    assert len(sf) == 4211
+    # [EXT] %f-rounded like sklearn-crfsuite's parsed dump
+    assert sf[("PF13471", "1")] == 3.465119 and sf[("PF00750", "0")] == 0.042199
+    assert m.transition_features_ == {("0", "0"): 2.669891, ("0", "1"): -2.599572, ("1", "0"): -2.601921, ("1", "1"): 2.568323}
+
+
+def test_md5_mismatch(tmp_path):
+    shutil.copy(os.path.join(GOLDEN, "model.pkl"), tmp_path / "model.pkl")
+    (tmp_path / "model.pkl.md5").write_text("0" * 32)
+    with pytest.raises(ValueError, match="MD5 hash of model data does not match signature"):
+        crf_mod.ClusterCRF.trained(str(tmp_path))
+    # case-insensitive comparison like crf/__init__.py:96
+    (tmp_path / "model.pkl.md5").write_text(open(os.path.join(GOLDEN, "model.pkl.md5")).read().upper() + "\n")
+    assert crf_mod.ClusterCRF.trained(str(tmp_path)).window_size == 20
+
+
+def test_unpickler_refuses_foreign_globals(tmp_path):
+    import hashlib
+
+    data = pickle.dumps(os.system)
+    (tmp_path / "model.pkl").write_bytes(data)
+    (tmp_path / "model.pkl.md5").write_text(hashlib.md5(data).hexdigest())
+    with pytest.raises(pickle.UnpicklingError):
+        crf_mod.ClusterCRF.trained(str(tmp_path))
+
+
+def test_save_roundtrip_keeps_reference_class_paths(trained, tmp_path):
+    trained.save(tmp_path / "out")
+    data = (tmp_path / "out" / "model.pkl").read_bytes()
+    for path in (b"gecco.crf", b"ClusterCRF", b"sklearn_crfsuite.estimator", b"sklearn_crfsuite._fileresource",
+                 b"pycrfsuite._logparser"):
+        assert path in data
+    assert b"gecco_amd" not in data
+    again = crf_mod.ClusterCRF.trained(tmp_path / "out")
+    assert again.window_size == 20 and again.model.state_features_ == trained.model.state_features_
+
+
+def test_constructor_errors():
+    with pytest.raises(ValueError, match="invalid feature type: 'gene'"):
+        crf_mod.ClusterCRF("gene")
+    with pytest.raises(ValueError, match="Window size must be strictly positive"):
+        crf_mod.ClusterCRF(window_size=0)
+    with pytest.raises(ValueError, match="Window step must be strictly positive and under `window_size`"):
+        crf_mod.ClusterCRF(window_size=5, window_step=6)
+    c = crf_mod.ClusterCRF(window_size=7, c1=0.1)
+    assert c.model is None and c._options == {"algorithm": "lbfgs", "c1": 0.1}
+    with pytest.raises(crf_mod.NotFittedError):
+        c.predict_probabilities([])
+
+
+# ---------------------------------------------------------------- packing
+def test_feature_extraction_matches_reference_unit_test():
+    """tests/test_crf/test_features.py:49-64 of the reference: domain mode -> [{A},{B},{C}],
+    protein mode -> [{A,B},{C}]."""
+    genes = [_gene("c", "prot1", 0, [("A", 0), ("B", 0)]), _gene("c", "prot2", 1, [("C", 0)])]
+    idx = {"A": 0, "B": 1, "C": 2}
+    b = packing.pack_contigs([genes], idx, "protein")
+    assert b.item_ptr.tolist() == [0, 2] and b.attr_ptr.tolist() == [0, 2, 3] and b.attr_id.tolist() == [0, 1, 2]
+    b = packing.pack_contigs([genes], idx, "domain")
+    assert b.item_ptr.tolist() == [0, 3] and b.attr_ptr.tolist() == [0, 1, 2, 3] and b.attr_id.tolist() == [0, 1, 2]
+
+
+def test_packing_collapses_duplicates_and_drops_unknown():
+    genes = [_gene("c", "p1", 0, [("A", 0), ("X", 5), ("A", 9)]), _gene("c", "p2", 1, []), _gene("c", "p3", 2, [("X", 0)])]
+    b = packing.pack_contigs([genes], {"A": 7}, "protein")
+    assert b.attr_ptr.tolist() == [0, 1, 1, 1] and b.attr_id.tolist() == [7]
+    b = packing.pack_contigs([genes], {"A": 7}, "domain")  # empty gene -> one empty item
+    assert b.item_ptr.tolist() == [0, 5] and b.attr_ptr.tolist() == [0, 1, 1, 2, 2, 2]
+
+
+def test_columnar_packer_equals_object_packer(trained):
+    feats = tables.FeatureTable.load(os.path.join(GOLDEN, "BGC0001866.features.tsv"))
+    genes_t = tables.GeneTable.load(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))
+    idx = trained.model._attr_index
+    cids, order, cptr, gptr, attr, ann = packing.pack_columns(
+        feats.sequence_id, feats.protein_id, feats.start, feats.domain, feats.domain_start, idx,
+        genes_t.sequence_id, genes_t.protein_id, genes_t.start)
+    assert cids == ["BGC0001866.1"] and order == genes_t.protein_id and cptr.tolist() == [0, 23]
+    from tests.helpers import golden_csr
+
+    _, cptr2, gptr2, attr2, _, ann2 = golden_csr(idx)
+    assert gptr.tolist() == gptr2.tolist() and attr.tolist() == attr2.tolist() and ann.tolist() == ann2.tolist()
+
+
+# ---------------------------------------------------------------- predict_probabilities wrapper
+def _golden_genes():
+    feats = tables.FeatureTable.load(os.path.join(GOLDEN, "BGC0001866.features.tsv"))
+    genes_t = tables.GeneTable.load(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))
+    annotated = {g.protein.id: g for g in feats.to_genes()}
+    out = []
+    for g in genes_t.to_genes():  # genes.tsv also lists the genes without any domain
+        a = annotated.get(g.protein.id)
+        out.append(Gene(g.source, g.start, g.end, g.strand, a.protein if a else g.protein))
+    return out
+
+
+def test_predict_probabilities_reproduces_golden_tables(trained, oracle_engine):
+    genes = _golden_genes()
+    rng = np.random.default_rng(0)
+    shuffled = [genes[i] for i in rng.permutation(len(genes))]
+    calls = []
+    out = trained.predict_probabilities(shuffled, progress=lambda i, t: calls.append((i, t)))
+    assert [g.protein.id for g in out] == [r["protein_id"] for r in read_tsv(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))]
+    exp = [float(r["average_p"]) for r in read_tsv(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))]
+    assert max(abs(g.average_probability - e) for g, e in zip(out, exp)) <= 1e-15
+    assert calls[0] == (0, 4) and calls[-1] == (4, 4)  # 23 genes, W=20 -> 4 windows
+    # domains carry the gene's probability and the %f-rounded state weight of (name,'1')
+    sf = trained.model.state_features_
+    for g in out:
+        for d in g.protein.domains:
+            assert d.probability == g.average_probability
+            assert d.cluster_weight == sf.get((d.name, "1"))
+    # table writers reproduce the reference's files (numerically; text equality up to last-digit rounding)
+    import io
+
+    buf = io.StringIO()
+    tables.GeneTable.from_genes(out).dump(buf)
+    got = [l.split("\t") for l in buf.getvalue().strip().split("\n")]
+    ref = [l.split("\t") for l in open(os.path.join(GOLDEN, "BGC0001866.genes.tsv")).read().strip().split("\n")]
+    assert got[0] == ref[0] and len(got) == len(ref)
+    for a, b in zip(got[1:], ref[1:]):
+        assert a[:5] == b[:5] and abs(float(a[5]) - float(b[5])) <= 1e-15 and abs(float(a[6]) - float(b[6])) <= 1e-15
+    buf = io.StringIO()
+    tables.FeatureTable.from_genes(out).dump(buf)
+    got = [l.split("\t") for l in buf.getvalue().strip().split("\n")]
+    ref = [l.split("\t") for l in open(os.path.join(GOLDEN, "BGC0001866.features.tsv")).read().strip().split("\n")]
+    assert got[0] == ref[0] and len(got) == len(ref) == 38
+    for a, b in zip(got[1:], ref[1:]):
+        assert a[:7] == b[:7] and a[9:11] == b[9:11]
+        assert float(a[7]) == float(b[7]) and float(a[8]) == float(b[8]) and abs(float(a[11]) - float(b[11])) <= 1e-15
+
+    # cluster calling on top: exactly one cluster, same row as clusters.tsv (CRF/refiner columns)
+    clusters = list(refine.ClusterRefiner(threshold=0.8, n_cds=3, edge_distance=0, trim=True).iter_clusters(out))
+    row = read_tsv(os.path.join(GOLDEN, "BGC0001866.clusters.tsv"))[0]
+    assert len(clusters) == 1
+    c = clusters[0]
+    assert (c.source.id, c.id, c.start, c.end) == (row["sequence_id"], row["cluster_id"], int(row["start"]), int(row["end"]))
+    assert abs(c.average_probability - float(row["average_p"])) <= 2e-16
+    assert abs(c.maximum_probability - float(row["max_p"])) <= 1e-15
+    assert {g.protein.id for g in c.genes} == set(row["proteins"].split(";"))
+    assert sorted({d.name for g in c.genes for d in g.protein.domains}) == row["domains"].split(";")
+
+
+def test_padding_and_skipping_semantics(trained, oracle_engine):
+    short = [_gene("tiny", f"tiny_{i}", 10 * i, [("PF00109", 1)] if i % 2 else []) for i in range(7)]
+    long_ = [_gene("big", f"big_{i}", 10 * i, [("PF00106", 1), ("PF08659", 30)] if i % 3 == 0 else []) for i in range(25)]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = trained.predict_probabilities(short + long_, pad=True)
+    assert [str(x.message) for x in w] == [
+        "Contig 'tiny' does not contain enough proteins (7) for sliding window of size 20, padding with 13 proteins"
+    ]
+    assert [g.source.id for g in out] == ["big"] * 25 + ["tiny"] * 7  # sorted by contig id
+    assert all(g.average_probability is not None for g in out)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out2 = trained.predict_probabilities(short + long_, pad=False)
+    assert [str(x.message) for x in w] == [
+        "Contig 'tiny' does not contain enough proteins (7) for sliding window of size 20"
+    ]
+    tiny = [g for g in out2 if g.source.id == "tiny"]
+    assert all(g.average_probability is None for g in tiny)  # passed through without prediction
+    assert [g.average_probability for g in out2[:25]] == [g.average_probability for g in out[:25]]
+    # singular unit in the warning (window - len == 1)
+    c19 = [_gene("n19", f"n19_{i}", i, []) for i in range(19)]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        trained.predict_probabilities(c19)
+    assert str(w[0].message).endswith("padding with 1 protein")
+
+
+def test_domains_are_sorted_in_place_like_the_reference(trained, oracle_engine):
+    g = _gene("c", "p", 0, [("PF00106", 50), ("PF08659", 5)])
+    genes = [g] + [_gene("c", f"q{i}", 10 + i, []) for i in range(20)]
+    trained.predict_probabilities(genes)
+    assert [d.start for d in g.protein.domains] == [5, 50]  # caller's list mutated (crf/__init__.py:200-201)
+
+
+# ---------------------------------------------------------------- refiner
+def _pgene(contig, i, p, annotated=True):
+    return Gene(Source(contig), 100 * i, 100 * i + 90, Strand.Coding,
+                Protein(f"{contig}_{i}", None, [Domain("PF00109", 1, 9, "Pfam", 1e-9, 1e-9)] if annotated else []),
+                _probability=p)
+
+
+def test_refiner_matches_oracle_segment():
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(11)
+    genes, p_all, ann_all, cptr = [], [], [], [0]
+    for c in range(30):
+        n = int(rng.integers(1, 60))
+        base = rng.random() < 0.5
+        p = np.clip(rng.normal(0.85 if base else 0.3, 0.3, size=n), 0, 1)
+        p[rng.random(n) < 0.05] = np.nan
+        ann = rng.random(n) < 0.7
+        for i in range(n):
+            genes.append(_pgene(f"ctg{c:03d}", i, None if np.isnan(p[i]) else float(p[i]), bool(ann[i])))
+        p_all += p.tolist()
+        ann_all += ann.tolist()
+        cptr.append(cptr[-1] + n)
+    for n_cds, edge, trim in [(3, 0, True), (1, 0, False), (2, 2, True), (5, 1, True)]:
+        seg = orc.segment(np.array(p_all), np.array(ann_all, dtype=np.uint8), np.array(cptr), 0.8, n_cds, edge, trim)
+        rng.shuffle(genes)
+        got = list(refine.ClusterRefiner(threshold=0.8, n_cds=n_cds, edge_distance=edge, trim=trim,
+                                         cluster_type=Cluster).iter_clusters(genes))
+        exp = [(f"ctg{c:03d}_cluster_{k}", [f"ctg{c:03d}_{g - cptr[c]}" for g in range(a, b)]) for c, k, a, b in seg.tolist()]
+        assert [(c.id, [g.id for g in c.genes]) for c in got] == exp
+
+
+def test_refiner_defaults_and_antismash():
+    r = refine.ClusterRefiner()
+    assert (r.threshold, r.criterion, r.n_cds, r.n_biopfams, r.average_threshold, r.edge_distance, r.trim) == \
+        (0.8, "gecco", 5, 5, 0.6, 0, True)
+    assert len(refine.BIO_PFAMS) == 130 and "PF00109" in refine.BIO_PFAMS
+    names = ["PF00109", "PF02801", "PF08659", "PF00378", "PF08541", "PF00550"]
+    genes = [Gene(Source("c"), 10 * i, 10 * i + 5, Strand.Coding,
+                  Protein(f"g{i}", None, [Domain(names[i], 1, 2, "Pfam", 0, 0)]), _probability=0.9) for i in range(6)]
+    assert len(list(refine.ClusterRefiner(criterion="antismash", n_cds=5, n_biopfams=5, cluster_type=Cluster).iter_clusters(genes))) == 1
+    assert len(list(refine.ClusterRefiner(criterion="antismash", n_cds=5, n_biopfams=6, cluster_type=Cluster).iter_clusters(genes))) == 0
+    with pytest.raises(ValueError, match="Unknown cluster filtering criterion"):
+        list(refine.ClusterRefiner(criterion="x").iter_clusters(genes))
+
+
+def test_cluster_average_is_exactly_rounded():
+    ps = [float(r["average_p"]) for r in read_tsv(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))]
+    c = Cluster("x", [_pgene("c", i, p) for i, p in enumerate(ps)])
+    assert c.average_probability == statistics.mean(ps) == 0.9958958770931705
+
+
+# ---------------------------------------------------------------- tables
+def test_tables_roundtrip(tmp_path):
+    for cls, name in ((tables.FeatureTable, "features"), (tables.GeneTable, "genes")):
+        src = os.path.join(GOLDEN, f"BGC0001866.{name}.tsv")
+        t = cls.load(src)
+        t.dump(str(tmp_path / f"{name}.tsv"))
+        assert open(src).read() == open(tmp_path / f"{name}.tsv").read()
+    g = tables.GeneTable.from_genes([_pgene("c", 0, None), _pgene("c", 1, None)])
+    import io
+
+    buf = io.StringIO()
+    g.dump(buf)  # all-NaN probability columns are dropped (gecco/_base.py:138-146)
+    assert buf.getvalue().split("\n")[0] == "sequence_id\tprotein_id\tstart\tend\tstrand"

@@ -1,0 +1,112 @@
+"""CPU-side checks of the native boundary: the library loads, exports every symbol the header
+declares, parses the shipped model exactly like the independent oracle parser, and fails
+loudly (no CPU fallback) when asked to compute without a HIP device."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gecco_amd import _native as nat
+from tests.helpers import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def blob():
+    from oracle import lcrf
+
+    return lcrf.load_pickle(os.path.join(GOLDEN, "model.pkl"))["blob"]
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "gecco_crf.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(gecco_crf_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 30
+    lib = nat.load_library()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gecco_crf.h but not exported"
+    assert declared == set(nat.SIGNATURES), declared ^ set(nat.SIGNATURES)
+    assert lib.gecco_crf_version() >= 100
+
+
+def test_model_tables_match_oracle_parser(blob, oracle_model):
+    m = nat.Model.from_lcrf(blob)
+    assert (m.num_labels, m.num_attrs, m.num_features) == (2, 2659, 4215)
+    assert m.labels() == oracle_model["labels"] and m.attrs() == oracle_model["attrs"]
+    w, present = m.state_weights()
+    np.testing.assert_array_equal(w, oracle_model["state"])
+    np.testing.assert_array_equal(present, oracle_model["state_mask"])
+    t, tp = m.trans_weights()
+    np.testing.assert_array_equal(t, oracle_model["trans"])
+    assert tp.all()
+    assert m.attr_id("PF00750") == 0 and m.attr_id("nope") == -1 and m.label_id("1") == 1
+    ids = m.map_attrs(["PF00750", "zzz", "PF13471"])
+    assert ids.tolist() == [0, -1, oracle_model["attr_index"]["PF13471"]]
+
+
+@pytest.mark.parametrize("mutate", ["magic", "size", "version", "truncate", "feat", "cqdb"])
+def test_malformed_models_are_rejected(blob, mutate):
+    b = bytearray(blob)
+    if mutate == "magic":
+        b[0:4] = b"XXXX"
+    elif mutate == "size":
+        b[4:8] = (len(b) + 1).to_bytes(4, "little")
+    elif mutate == "version":
+        b[12:16] = (99).to_bytes(4, "little")
+    elif mutate == "truncate":
+        b = b[:1000]
+    elif mutate == "feat":
+        b[48:52] = b"TAEF"
+    elif mutate == "cqdb":
+        off = int.from_bytes(b[36:40], "little")
+        b[off:off + 4] = b"BDQC"
+    with pytest.raises(ValueError):
+        nat.Model.from_lcrf(bytes(b))
+
+
+def test_from_tables_roundtrip():
+    rng = np.random.default_rng(0)
+    w = rng.normal(size=(17, 3))
+    t = rng.normal(size=(3, 3))
+    m = nat.Model.from_tables(w, t)
+    w2, _ = m.state_weights()
+    t2, _ = m.trans_weights()
+    np.testing.assert_array_equal(w, w2)
+    np.testing.assert_array_equal(t, t2)
+    assert m.labels() == ["0", "1", "2"] and m.attrs()[5] == "a5"
+
+
+def test_argument_errors_mirror_reference_messages(blob):
+    m = nat.Model.from_lcrf(blob)
+    with pytest.raises(ValueError, match="Window size must be strictly positive"):
+        m.windowed_marginals([0, 3], [0, 1, 2, 3], [1, 2, 3], 0)
+    with pytest.raises(ValueError, match="Window step must be strictly positive and under `window_size`"):
+        m.windowed_marginals([0, 3], [0, 1, 2, 3], [1, 2, 3], 5, step=6)
+    with pytest.raises(ValueError, match="label out of range"):
+        m.windowed_marginals([0, 3], [0, 1, 2, 3], [1, 2, 3], 5, label=2)
+
+
+def test_host_only_plan_layout(blob):
+    m = nat.Model.from_lcrf(blob)
+    # contigs of 50, 10 (padded to 20) and 240 genes: windows = 31 + 1 + 221 (crf/__init__.py:239)
+    p = nat.Plan(m, [0, 50, 60, 300], 20, 1, True, device=-1)
+    assert (p.num_genes, p.num_windows) == (300, 253)
+    assert p.num_tiles == 2 and "crf_windowed" in p.kernel_name
+    p = nat.Plan(m, [0, 50, 60, 300], 20, 1, False, device=-1)
+    assert p.num_windows == 252
+    p = nat.Plan(m, [0], 20, device=-1)
+    assert p.num_genes == 0 and p.num_tiles == 0
+    with pytest.raises(nat.NativeError) as ei:
+        nat.Plan(m, [0, 50], 20, device=-1).run_windowed(0, 0, 0)
+    assert ei.value.code == nat.ENODEV
+
+
+@pytest.mark.skipif(nat.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback(blob):
+    m = nat.Model.from_lcrf(blob)
+    with pytest.raises(nat.NativeError) as ei:
+        m.windowed_marginals([0, 30], np.arange(31), np.zeros(30, dtype=np.int32), 20)
+    assert ei.value.code == nat.ENODEV
