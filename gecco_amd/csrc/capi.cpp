@@ -202,15 +202,17 @@ GECCO_API int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_g
     return rc;
 }
 
-GECCO_API int gecco_crf_plan_run_marginals_full(gecco_crf_plan *, const int32_t *, const int32_t *, double *, double *,
-                                                void *) {
-    set_error("full-sequence marginals: not built yet");
-    return GECCO_CRF_EUNSUPPORTED;
+GECCO_API int gecco_crf_plan_run_marginals_full(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                                double *d_marg, double *d_lognorm, void *stream) {
+    if (!p) return GECCO_CRF_EINVAL;
+    DeviceGuard guard;
+    return plan_run_marginals_full(p->p, d_gene_ptr, d_attr_id, d_marg, d_lognorm, static_cast<hipStream_t>(stream));
 }
-GECCO_API int gecco_crf_plan_run_viterbi(gecco_crf_plan *, const int32_t *, const int32_t *, int8_t *, double *,
-                                         void *) {
-    set_error("viterbi: not built yet");
-    return GECCO_CRF_EUNSUPPORTED;
+GECCO_API int gecco_crf_plan_run_viterbi(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                         int8_t *d_y, double *d_score, void *stream) {
+    if (!p) return GECCO_CRF_EINVAL;
+    DeviceGuard guard;
+    return plan_run_viterbi(p->p, d_gene_ptr, d_attr_id, d_y, d_score, static_cast<hipStream_t>(stream));
 }
 
 // ---- one-shot host entry points ------------------------------------------------------------
@@ -261,15 +263,75 @@ GECCO_API int gecco_crf_windowed_marginals(const gecco_crf_model *m, int32_t dev
     return GECCO_CRF_OK;
 }
 
-GECCO_API int gecco_crf_marginals_full(const gecco_crf_model *, int32_t, const int32_t *, int32_t, const int32_t *,
-                                       const int32_t *, double *, double *) {
-    set_error("full-sequence marginals: not built yet");
-    return GECCO_CRF_EUNSUPPORTED;
+namespace {
+// shared front half of the one-shot whole-contig entry points: plan + CSR upload
+struct OneShot {
+    gecco_crf_plan h;
+    DevBuf<int32_t> d_gp, d_at;
+    int32_t n = 0;
+    int prepare(const gecco_crf_model *m, int32_t device, const int32_t *contig_ptr, int32_t n_contigs,
+                const int32_t *gene_ptr, const int32_t *attr_id) {
+        if (!m) return GECCO_CRF_EINVAL;
+        int rc = check_device(device);
+        if (rc) return rc;
+        if ((rc = plan_build(m->m, device, contig_ptr, n_contigs, 1, 1, 1, h.p))) return rc;
+        n = h.p.n_genes;
+        if (n == 0) return GECCO_CRF_OK;
+        if (!gene_ptr) {
+            set_error("null buffer");
+            return GECCO_CRF_EINVAL;
+        }
+        const size_t nnz = size_t(gene_ptr[n]);
+        for (size_t k = 0; k < nnz; ++k)
+            if (attr_id[k] < 0 || attr_id[k] >= m->m.A) {
+                set_error("attr_id out of range (unknown attributes must be dropped by the packer)");
+                return GECCO_CRF_EINVAL;
+            }
+        if ((rc = d_gp.alloc(size_t(n) + 1, "hipMalloc gene_ptr"))) return rc;
+        if ((rc = d_at.alloc(nnz, "hipMalloc attr_id"))) return rc;
+        if ((rc = check_hip(hipMemcpy(d_gp.p, gene_ptr, (size_t(n) + 1) * 4, hipMemcpyHostToDevice), "H2D gene_ptr"))) return rc;
+        if (nnz && (rc = check_hip(hipMemcpy(d_at.p, attr_id, nnz * 4, hipMemcpyHostToDevice), "H2D attr_id"))) return rc;
+        return GECCO_CRF_OK;
+    }
+};
+}  // namespace
+
+GECCO_API int gecco_crf_marginals_full(const gecco_crf_model *m, int32_t device, const int32_t *contig_ptr,
+                                       int32_t n_contigs, const int32_t *gene_ptr, const int32_t *attr_id,
+                                       double *marg, double *lognorm) {
+    DeviceGuard guard;
+    OneShot os;
+    int rc = os.prepare(m, device, contig_ptr, n_contigs, gene_ptr, attr_id);
+    if (rc) return rc;
+    if (n_contigs == 0) return GECCO_CRF_OK;
+    const size_t n = size_t(os.n), L = 2;
+    DevBuf<double> d_m, d_ln;
+    if ((rc = d_m.alloc(n * L, "hipMalloc marginals"))) return rc;
+    if ((rc = d_ln.alloc(size_t(n_contigs), "hipMalloc lognorm"))) return rc;
+    if ((rc = plan_run_marginals_full(os.h.p, os.d_gp.p, os.d_at.p, d_m.p, d_ln.p, nullptr))) return rc;
+    if (n && marg && (rc = check_hip(hipMemcpy(marg, d_m.p, n * L * 8, hipMemcpyDeviceToHost), "D2H marginals"))) return rc;
+    if (lognorm && (rc = check_hip(hipMemcpy(lognorm, d_ln.p, size_t(n_contigs) * 8, hipMemcpyDeviceToHost), "D2H lognorm")))
+        return rc;
+    return check_hip(hipDeviceSynchronize(), "sync");
 }
-GECCO_API int gecco_crf_viterbi(const gecco_crf_model *, int32_t, const int32_t *, int32_t, const int32_t *,
-                                const int32_t *, int8_t *, double *) {
-    set_error("viterbi: not built yet");
-    return GECCO_CRF_EUNSUPPORTED;
+
+GECCO_API int gecco_crf_viterbi(const gecco_crf_model *m, int32_t device, const int32_t *contig_ptr, int32_t n_contigs,
+                                const int32_t *gene_ptr, const int32_t *attr_id, int8_t *y_out, double *score) {
+    DeviceGuard guard;
+    OneShot os;
+    int rc = os.prepare(m, device, contig_ptr, n_contigs, gene_ptr, attr_id);
+    if (rc) return rc;
+    if (n_contigs == 0) return GECCO_CRF_OK;
+    const size_t n = size_t(os.n);
+    DevBuf<int8_t> d_y;
+    DevBuf<double> d_sc;
+    if ((rc = d_y.alloc(n, "hipMalloc labels"))) return rc;
+    if ((rc = d_sc.alloc(size_t(n_contigs), "hipMalloc scores"))) return rc;
+    if ((rc = plan_run_viterbi(os.h.p, os.d_gp.p, os.d_at.p, d_y.p, d_sc.p, nullptr))) return rc;
+    if (n && y_out && (rc = check_hip(hipMemcpy(y_out, d_y.p, n, hipMemcpyDeviceToHost), "D2H labels"))) return rc;
+    if (score && (rc = check_hip(hipMemcpy(score, d_sc.p, size_t(n_contigs) * 8, hipMemcpyDeviceToHost), "D2H scores")))
+        return rc;
+    return check_hip(hipDeviceSynchronize(), "sync");
 }
 GECCO_API int gecco_crf_segment(int32_t, const double *, const uint8_t *, const int32_t *, int32_t, double, int32_t,
                                 int32_t, int32_t, int32_t *, int32_t, int32_t *) {

@@ -82,6 +82,11 @@ Plan::~Plan() {
             (void)hipFree(d_tile_desc);
             (void)hipFree(d_start_bits);
             (void)hipFree(d_skipped);
+            (void)hipFree(d_ch_start);
+            (void)hipFree(d_ch_len);
+            (void)hipFree(d_ct_chunk0);
+            (void)hipFree(d_ch_first);
+            (void)hipFree(d_seq_ws);
             (void)hipSetDevice(prev);
         }
     }
@@ -282,6 +287,123 @@ int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_
         if ((rc = check_hip(launch_fill_nan(d_p_out, p.d_skipped, int(p.skipped.size()), stream), "fill_nan launch")))
             return rc;
     return check_hip(launch_windowed(a, stream), "windowed launch");
+}
+
+// ---- whole-contig scans (rows F, V) ------------------------------------------------------
+namespace {
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+int ensure_seq(Plan &p) {
+    if (p.seq_ready) return GECCO_CRF_OK;
+    std::vector<int32_t> ch_start, ch_len, ct_chunk0(size_t(p.n_contigs) + 1, 0);
+    std::vector<uint8_t> ch_first;
+    for (int32_t c = 0; c < p.n_contigs; ++c) {
+        ct_chunk0[c] = int32_t(ch_start.size());
+        const int32_t g0 = p.contig_ptr[c], g1 = p.contig_ptr[c + 1];
+        for (int32_t g = g0; g < g1; g += kSeqChunk) {
+            ch_start.push_back(g);
+            ch_len.push_back(std::min(kSeqChunk, g1 - g));
+            ch_first.push_back(g == g0);
+        }
+    }
+    ct_chunk0[p.n_contigs] = int32_t(ch_start.size());
+    p.n_chunks = int32_t(ch_start.size());
+    int rc;
+    if ((rc = upload(&p.d_ch_start, ch_start.data(), ch_start.size(), "upload chunk table"))) return rc;
+    if ((rc = upload(&p.d_ch_len, ch_len.data(), ch_len.size(), "upload chunk table"))) return rc;
+    if ((rc = upload(&p.d_ch_first, ch_first.data(), ch_first.size(), "upload chunk table"))) return rc;
+    if ((rc = upload(&p.d_ct_chunk0, ct_chunk0.data(), ct_chunk0.size(), "upload chunk table"))) return rc;
+    const size_t n = size_t(p.n_genes), nc = size_t(p.n_chunks);
+    const size_t bytes = align256(n * 16) * 2 + align256(nc * 32) + align256(nc * 16) * 3 + align256(nc * 2) + align256(nc) + 256;
+    if ((rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_seq_ws), bytes), "hipMalloc scan workspace"))) return rc;
+    p.seq_ready = true;
+    return GECCO_CRF_OK;
+}
+
+int fill_seq_args(Plan &p, SeqArgs &a) {
+    if (p.device < 0) {
+        set_error("host-only plan: no HIP device bound (there is no CPU fallback)");
+        return GECCO_CRF_ENODEV;
+    }
+    if (p.model->L != 2) {
+        set_error("whole-contig kernels support 2-label models only");
+        return GECCO_CRF_EUNSUPPORTED;
+    }
+    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
+    if (rc) return rc;
+    if ((rc = ensure_seq(p))) return rc;
+    const Model &m = *p.model;
+    const size_t n = size_t(p.n_genes), nc = size_t(p.n_chunks);
+    char *w = p.d_seq_ws;
+    auto take = [&](size_t bytes) {
+        char *r = w;
+        w += align256(bytes);
+        return r;
+    };
+    a = SeqArgs{};
+    a.state = reinterpret_cast<double2 *>(take(n * 16));
+    a.alpha = reinterpret_cast<double2 *>(take(n * 16));
+    a.chP = reinterpret_cast<Mat2 *>(take(nc * 32));
+    a.chAux = reinterpret_cast<double2 *>(take(nc * 16));
+    a.chIn = reinterpret_cast<double2 *>(take(nc * 16));
+    a.chOut = reinterpret_cast<double2 *>(take(nc * 16));
+    a.chMap = reinterpret_cast<int8_t *>(take(nc * 2));
+    a.chEnd = reinterpret_cast<int8_t *>(take(nc));
+    a.ch_start = p.d_ch_start;
+    a.ch_len = p.d_ch_len;
+    a.ch_first = p.d_ch_first;
+    a.ct_chunk0 = p.d_ct_chunk0;
+    a.n_chunks = p.n_chunks;
+    a.n_contigs = p.n_contigs;
+    a.n_genes = p.n_genes;
+    a.mx = *std::max_element(m.trans.begin(), m.trans.end());
+    a.t00 = m.trans[0];
+    a.t01 = m.trans[1];
+    a.t10 = m.trans[2];
+    a.t11 = m.trans[3];
+    a.m00 = std::exp(a.t00 - a.mx);
+    a.m01 = std::exp(a.t01 - a.mx);
+    a.m10 = std::exp(a.t10 - a.mx);
+    a.m11 = std::exp(a.t11 - a.mx);
+    return GECCO_CRF_OK;
+}
+}  // namespace
+
+int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, double *d_marg,
+                            double *d_lognorm, hipStream_t stream) {
+    SeqArgs a;
+    int rc = fill_seq_args(p, a);
+    if (rc) return rc;
+    if (p.n_contigs == 0) return GECCO_CRF_OK;
+    if (p.n_genes > 0 && (!d_gene_ptr || !d_marg)) {
+        set_error("null device buffer");
+        return GECCO_CRF_EINVAL;
+    }
+    a.marg = d_marg;
+    a.lognorm = d_lognorm;
+    // wtab2[1] holds (w[a][0], w[a][1]) = (other, label) pairs for label 1
+    if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables->wtab2[1], p.n_genes,
+                                         const_cast<double2 *>(a.state), stream), "state score launch")))
+        return rc;
+    return check_hip(launch_seq_marginals(a, stream), "marginals launch");
+}
+
+int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int8_t *d_y, double *d_score,
+                     hipStream_t stream) {
+    SeqArgs a;
+    int rc = fill_seq_args(p, a);
+    if (rc) return rc;
+    if (p.n_contigs == 0) return GECCO_CRF_OK;
+    if (p.n_genes > 0 && (!d_gene_ptr || !d_y)) {
+        set_error("null device buffer");
+        return GECCO_CRF_EINVAL;
+    }
+    a.y = d_y;
+    a.score = d_score;
+    if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables->wtab2[1], p.n_genes,
+                                         const_cast<double2 *>(a.state), stream), "state score launch")))
+        return rc;
+    return check_hip(launch_seq_viterbi(a, stream), "viterbi launch");
 }
 
 }  // namespace gecco

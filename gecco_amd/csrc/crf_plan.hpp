@@ -43,6 +43,12 @@ struct Plan {
     uint64_t *d_start_bits = nullptr;
     int2 *d_skipped = nullptr;
     const DeviceTables *tables = nullptr;
+    // whole-contig scans (rows F, V): chunk tables + workspace, built on first use
+    bool seq_ready = false;
+    int32_t n_chunks = 0;
+    int32_t *d_ch_start = nullptr, *d_ch_len = nullptr, *d_ct_chunk0 = nullptr;
+    uint8_t *d_ch_first = nullptr;
+    char *d_seq_ws = nullptr;
     ~Plan();
 };
 
@@ -50,6 +56,10 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
                int32_t pad, Plan &p);
 int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                       hipStream_t stream);
+int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, double *d_marg,
+                            double *d_lognorm, hipStream_t stream);
+int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int8_t *d_y, double *d_score,
+                     hipStream_t stream);
 // returns GECCO_CRF_* ; on HIP failure sets the error text
 int check_hip(hipError_t e, const char *what);
 int get_device_tables(const Model &m, int device, const DeviceTables **out);

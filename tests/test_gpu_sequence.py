@@ -1,0 +1,124 @@
+"""GPU parity of the whole-contig extensions (rows F and V): full-sequence marginals and
+Viterbi decoding vs the CPU oracle ([EXT] CRFsuite semantics)."""
+import numpy as np
+import pytest
+
+from tests.helpers import golden_csr, synth_contigs, synth_model
+
+pytestmark = pytest.mark.gpu
+
+LENGTHS = [1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 1000, 4097, 20000]
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from gecco_amd import _native
+
+    assert _native.device_count() >= 1
+    return _native
+
+
+@pytest.fixture(scope="module")
+def real(nat, oracle_model):
+    import os
+
+    from oracle import lcrf
+    from tests.helpers import GOLDEN
+
+    return nat.Model.from_lcrf(lcrf.load_pickle(os.path.join(GOLDEN, "model.pkl"))["blob"])
+
+
+def test_golden_contig(real, oracle_model):
+    from oracle import crf_oracle as orc
+
+    ids, cptr, gptr, attr, expected, ann = golden_csr(oracle_model["attr_index"])
+    marg, ln = real.marginals_full(cptr, gptr, attr)
+    emarg, eln = orc.full_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    assert np.abs(marg - emarg).max() <= 1e-12 and abs(ln[0] - eln[0]) <= 1e-9 * abs(eln[0])
+    y, sc = real.viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    assert y.tolist() == ey.tolist() == [1] * 23 and abs(sc[0] - esc[0]) <= 1e-9
+
+
+def test_full_marginals_random(real, oracle_model):
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(21)
+    cptr, gptr, attr = synth_contigs(rng, LENGTHS + list(rng.integers(1, 300, size=50)), oracle_model["state"].shape[0])
+    marg, ln = real.marginals_full(cptr, gptr, attr)
+    emarg, eln = orc.full_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    assert np.abs(marg - emarg).max() <= 1e-12
+    np.testing.assert_allclose(marg.sum(axis=1), 1.0, atol=1e-14)
+    assert np.abs(ln - eln).max() <= 1e-9 * np.abs(eln).max()
+
+
+def test_viterbi_random(real, oracle_model):
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(22)
+    cptr, gptr, attr = synth_contigs(rng, LENGTHS + list(rng.integers(1, 300, size=50)), oracle_model["state"].shape[0])
+    y, sc = real.viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    assert np.array_equal(y, ey.astype(np.int8))
+    assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_viterbi_exact_ties_integer_weights(nat, seed):
+    """Integer-valued weights: every addition is exact, so ties are real ties and CRFsuite's
+    first-argmax rule must be reproduced exactly, also across chunk boundaries."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(seed)
+    A = 6
+    w = rng.integers(-1, 2, size=(A, 2)).astype(float)
+    trans = rng.integers(-1, 2, size=(2, 2)).astype(float) if seed else np.zeros((2, 2))
+    cptr, gptr, attr = synth_contigs(rng, [1, 5, 64, 65, 130, 700, 3000], A)
+    model = nat.Model.from_tables(w, trans)
+    y, sc = model.viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y, ey.astype(np.int8))
+    assert np.array_equal(sc, esc)
+
+
+def test_synthetic_model_c2_shape(nat):
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(5)
+    A = 35000
+    w, trans = synth_model(A, rng)
+    lengths = np.clip(np.round(rng.lognormal(np.log(200), 0.5, size=300)), 5, 2000).astype(int)
+    cptr, gptr, attr = synth_contigs(rng, lengths, A)
+    model = nat.Model.from_tables(w, trans)
+    marg, ln = model.marginals_full(cptr, gptr, attr)
+    emarg, eln = orc.full_marginals(w, trans, cptr, gptr, attr)
+    assert np.abs(marg - emarg).max() <= 1e-12
+    y, sc = model.viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y, ey.astype(np.int8))
+
+
+def test_model_view_single_sequence_api(oracle_model):
+    """[EXT] CRF.predict_marginals_single / predict_single surface of ClusterCRF.model."""
+    from gecco_amd.crf import ClusterCRF
+    from oracle import crf_oracle as orc
+    from tests.helpers import GOLDEN
+
+    crf = ClusterCRF.trained(GOLDEN)
+    xseq = [{"PF00109": True, "PF02801": True}, {}, {"PF08659": True, "nope": True}, {"PF00106": True}]
+    marg = crf.model.predict_marginals_single(xseq)
+    ai = oracle_model["attr_index"]
+    gptr = [0, 2, 2, 3, 4]
+    attr = [ai["PF00109"], ai["PF02801"], ai["PF08659"], ai["PF00106"]]
+    emarg, _ = orc.full_marginals(oracle_model["state"], oracle_model["trans"], [0, 4], gptr, attr)
+    assert all(abs(m["1"] - e[1]) <= 1e-12 and abs(m["0"] - e[0]) <= 1e-12 for m, e in zip(marg, emarg))
+    ey, _ = orc.viterbi(oracle_model["state"], oracle_model["trans"], [0, 4], gptr, attr)
+    assert crf.model.predict_single(xseq) == [str(v) for v in ey.tolist()]
+    assert crf.model.predict_marginals_single([]) == [] and crf.model.predict_single([]) == []
+
+
+def test_empty_inputs(real):
+    marg, ln = real.marginals_full([0], [0], [])
+    assert marg.shape == (0, 2) and ln.shape == (0,)
+    y, sc = real.viterbi([0, 0, 3], [0, 1, 1, 2], [5, 7])
+    assert y.shape == (3,) and sc[0] == 0.0
