@@ -333,8 +333,44 @@ GECCO_API int gecco_crf_viterbi(const gecco_crf_model *m, int32_t device, const 
         return rc;
     return check_hip(hipDeviceSynchronize(), "sync");
 }
-GECCO_API int gecco_crf_segment(int32_t, const double *, const uint8_t *, const int32_t *, int32_t, double, int32_t,
-                                int32_t, int32_t, int32_t *, int32_t, int32_t *) {
-    set_error("segment: not built yet");
-    return GECCO_CRF_EUNSUPPORTED;
+GECCO_API int gecco_crf_segment(int32_t device, const double *p, const uint8_t *annotated, const int32_t *contig_ptr,
+                                int32_t n_contigs, double threshold, int32_t n_cds, int32_t edge_distance,
+                                int32_t trim, int32_t *seg_out, int32_t max_seg, int32_t *n_seg) {
+    if (!n_seg || n_contigs < 0 || (n_contigs > 0 && (!contig_ptr || !p || !annotated)) || max_seg < 0 ||
+        (max_seg > 0 && !seg_out)) {
+        set_error("gecco_crf_segment: bad arguments");
+        return GECCO_CRF_EINVAL;
+    }
+    *n_seg = 0;
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (n_contigs == 0) return GECCO_CRF_OK;
+    DeviceGuard guard;
+    if ((rc = check_hip(hipSetDevice(device), "hipSetDevice"))) return rc;
+    const size_t n = size_t(contig_ptr[n_contigs]), nc = size_t(n_contigs);
+    DevBuf<double> d_p;
+    DevBuf<uint8_t> d_a;
+    DevBuf<int32_t> d_c, d_seg, d_work, d_total;
+    if ((rc = d_p.alloc(n, "hipMalloc p"))) return rc;
+    if ((rc = d_a.alloc(n, "hipMalloc annotated"))) return rc;
+    if ((rc = d_c.alloc(nc + 1, "hipMalloc contig_ptr"))) return rc;
+    if ((rc = d_seg.alloc(size_t(max_seg) * 4, "hipMalloc segments"))) return rc;
+    if ((rc = d_work.alloc(nc * 3 + 4, "hipMalloc work"))) return rc;
+    if ((rc = d_total.alloc(1, "hipMalloc total"))) return rc;
+    if (n && (rc = check_hip(hipMemcpy(d_p.p, p, n * 8, hipMemcpyHostToDevice), "H2D p"))) return rc;
+    if (n && (rc = check_hip(hipMemcpy(d_a.p, annotated, n, hipMemcpyHostToDevice), "H2D annotated"))) return rc;
+    if ((rc = check_hip(hipMemcpy(d_c.p, contig_ptr, (nc + 1) * 4, hipMemcpyHostToDevice), "H2D contig_ptr"))) return rc;
+    if ((rc = check_hip(launch_segment(d_p.p, d_a.p, d_c.p, n_contigs, threshold, n_cds, edge_distance, trim, d_seg.p, max_seg,
+                                       d_work.p, d_total.p, nullptr), "segment launch")))
+        return rc;
+    int32_t total = 0;
+    if ((rc = check_hip(hipMemcpy(&total, d_total.p, 4, hipMemcpyDeviceToHost), "D2H count"))) return rc;
+    *n_seg = total;
+    if (total > max_seg) {
+        set_error("gecco_crf_segment: seg_out too small");
+        return GECCO_CRF_EINVAL;
+    }
+    if (total && (rc = check_hip(hipMemcpy(seg_out, d_seg.p, size_t(total) * 16, hipMemcpyDeviceToHost), "D2H segments")))
+        return rc;
+    return GECCO_CRF_OK;
 }

@@ -70,6 +70,11 @@ hipError_t launch_seq_state(const int32_t *gene_ptr, const int32_t *attr_id, con
 hipError_t launch_seq_marginals(const SeqArgs &a, hipStream_t stream);
 hipError_t launch_seq_viterbi(const SeqArgs &a, hipStream_t stream);
 
+// row R on packed arrays (crf_segment.hip); d_work: 2*n_contigs int32 + n_contigs bytes
+hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const int32_t *d_cptr, int n_contigs, double threshold,
+                          int n_cds, int edge_distance, int trim, int32_t *d_seg, int max_seg, int32_t *d_work,
+                          int32_t *d_total, hipStream_t stream);
+
 const char *windowed_kernel_name(int W, int L);
 // tile_out = output slots per workgroup for the kernel that (W, L) dispatches to.
 int windowed_tile_out(int W, int L);
