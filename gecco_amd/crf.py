@@ -290,6 +290,23 @@ class ClusterCRF(object):
             for gene in predicted
         ]
 
+    def predict_clusters(self, genes: Iterable[Any], *, pad: bool = True, threshold: float = 0.8,
+                         criterion: str = "gecco", n_cds: int = 3, edge_distance: int = 0, trim: bool = True,
+                         progress: Optional[Callable[[int, int], None]] = None) -> List[Any]:
+        """Probabilities + cluster calls in one go: ``predict_probabilities`` followed by
+        ``ClusterRefiner.iter_clusters`` with the CLI's defaults (threshold 0.8, cds 3, edge
+        distance 0, trim; ``gecco/cli/commands/_parser.py:277-335``, ``_common.py:595-625``).
+        Not a method of the reference class: a convenience of this one."""
+        from .refine import ClusterRefiner
+
+        annotated = self.predict_probabilities(genes, pad=pad, progress=progress)
+        refiner = ClusterRefiner(threshold=threshold, criterion=criterion, n_cds=n_cds,
+                                 edge_distance=edge_distance, trim=trim)
+        clusters: List[Any] = []
+        for _, group in itertools.groupby(annotated, key=lambda g: g.source.id):  # per contig, like the CLI
+            clusters.extend(refiner.iter_clusters(list(group)))
+        return clusters
+
     def predict_probabilities_csr(self, contig_ptr, gene_ptr, attr_id, *, pad: bool = True, label: str = "1",
                                   device: Optional[int] = None) -> np.ndarray:
         """Columnar entry point: the same scores for an already packed CSR batch (ids from

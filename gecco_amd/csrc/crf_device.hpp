@@ -25,6 +25,8 @@ struct WinArgs {
     // transitions in the transformed basis (rows/cols ordered (other, label)):
     //   mu01 = m01*m10/m00^2, mu11 = m11/m00, kappa = m10/m00  with m = exp(trans)
     double mu01, mu11, kappa_over_mu11, inv_kappa;
+    double g00, g01, g10, g11;  // exp(trans - max), (other, label) order: generic kernel
+    int32_t generic;            // 1: dispatch to the generic window kernel
     const double *exp_trans;   // [L*L] exp(trans) for the generic kernel
     double *scratch;           // generic kernel workspace
 };
@@ -75,7 +77,7 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const int32_t
                           int n_cds, int edge_distance, int trim, int32_t *d_seg, int max_seg, int32_t *d_work,
                           int32_t *d_total, hipStream_t stream);
 
-const char *windowed_kernel_name(int W, int L);
+const char *windowed_kernel_name(int W, int L, bool fast);
 // tile_out = output slots per workgroup for the kernel that (W, L) dispatches to.
 int windowed_tile_out(int W, int L);
 hipError_t launch_windowed(const WinArgs &a, hipStream_t stream);

@@ -301,6 +301,77 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 4 : 3)) crf_windowed_l2(cons
     if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = (Rx + Ry > 0.0) ? Rx / (Rx + Ry) : 0.0;
 }
 
+// ---- generic window kernel (2 labels, ANY window size, ANY transition spread) -------------
+// Fallback for shapes the register-resident kernel does not take (W > 32, or transition
+// weights so far apart that un-normalised vectors would need rescaling more than once per
+// step).  One lane per window start, CRFsuite-style: both DP vectors are renormalised (by an
+// exact power of two) after every step; alpha of every step is parked in a global scratch
+// laid out [step][window] (coalesced); the per-gene maximum is an atomic max on the bit
+// pattern of the (non-negative) probability.  Slow (a division and ~W*32 B of scratch traffic
+// per window position) but shape-agnostic; also used by the tests as an on-device cross-check
+// of the fast kernel.
+__device__ __forceinline__ double2 slot_emission(const WinArgs &P, int gene) {
+    double s0 = 0.0, s1 = 0.0;
+    if (gene >= 0) state_scores_l2(P.attr_id, P.wtab2, P.gene_ptr[gene], P.gene_ptr[gene + 1], s0, s1);
+    const double m = fmax(s0, s1);
+    return make_double2(exp(s0 - m), exp(s1 - m));  // (other, label)
+}
+
+__global__ void __launch_bounds__(256) crf_windowed_generic_l2(const WinArgs P) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= P.S) return;
+    if (!((P.start_bits[q >> 6] >> (q & 63)) & 1ull)) return;
+    // contig of this window: largest k with c_slot[k] <= q
+    int lo = 0, hi = P.K - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (P.c_slot[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    const int s0 = P.c_slot[lo], np = P.c_slot[lo + 1] - s0, n = P.c_n[lo], g0 = P.c_gene[lo];
+    const int pos = q - s0, lpad = (np - n) >> 1;
+    const int W = P.W;
+    const size_t stride = size_t(P.S);
+    double2 *scr = reinterpret_cast<double2 *>(P.scratch);
+    auto gene_of = [&](int k) {
+        const int gl = pos + k - lpad;
+        return (gl >= 0 && gl < n) ? g0 + gl : -1;
+    };
+    // plain max-normalised recurrences: alpha' = (alpha M') o e, beta = M' (e o beta')
+    const double m00 = P.g00, m01 = P.g01, m10 = P.g10, m11 = P.g11;
+    double a0, a1;
+    {
+        const double2 e = slot_emission(P, gene_of(0));
+        a0 = e.x;
+        a1 = e.y;
+    }
+    scr[q] = make_double2(a0, a1);
+    for (int k = 1; k < W; ++k) {
+        const double2 e = slot_emission(P, gene_of(k));
+        const double t0 = fma(a1, m10, a0 * m00), t1 = fma(a1, m11, a0 * m01);
+        a0 = t0 * e.x;
+        a1 = t1 * e.y;
+        rescale_pair(a0, a1);
+        scr[size_t(k) * stride + q] = make_double2(a0, a1);
+    }
+    double b0 = 1.0, b1 = 1.0;
+    for (int k = W - 1; k >= 0; --k) {
+        const double2 al = scr[size_t(k) * stride + q];
+        const double x = al.y * b1, y = al.x * b0;
+        const int gene = gene_of(k);
+        if (gene >= 0) {
+            const double pr = x / (x + y);
+            atomicMax(reinterpret_cast<unsigned long long *>(P.p_out + gene), (unsigned long long)__double_as_longlong(pr));
+        }
+        if (k > 0) {
+            const double2 e = slot_emission(P, gene);
+            const double c0 = e.x * b0, c1 = e.y * b1;
+            b0 = fma(m01, c1, m00 * c0);
+            b1 = fma(m11, c1, m10 * c0);
+            rescale_pair(b0, b1);
+        }
+    }
+}
+
 __global__ void fill_nan_kernel(double *p, const int2 *ranges, int n_ranges) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_ranges) return;
@@ -311,21 +382,24 @@ __global__ void fill_nan_kernel(double *p, const int2 *ranges, int n_ranges) {
 
 }  // namespace
 
-const char *windowed_kernel_name(int W, int L) {
-    if (L == 2 && W == 20) return "crf_windowed_l2<20,exact>";
-    if (L == 2 && W <= kWinMaxW) return "crf_windowed_l2<32,dynamic>";
+const char *windowed_kernel_name(int W, int L, bool fast) {
+    if (L == 2 && fast && W == 20) return "crf_windowed_l2<20,exact>";
+    if (L == 2 && fast && W <= kWinMaxW) return "crf_windowed_l2<32,dynamic>";
+    if (L == 2) return "crf_windowed_generic_l2";
     return "unsupported";
 }
 
 int windowed_tile_out(int W, int L) {
     if (L == 2 && W <= kWinMaxW) return kWinThreads - (W - 1);
-    return 0;
+    return kWinThreads;
 }
 
 hipError_t launch_windowed(const WinArgs &a, hipStream_t stream) {
     if (a.ntiles <= 0) return hipSuccess;
     const dim3 grid(a.ntiles), block(kWinThreads);
-    if (a.L == 2 && a.W == 20 && a.rescale_mask == 0) {
+    if (a.L == 2 && a.generic) {
+        hipLaunchKernelGGL(crf_windowed_generic_l2, dim3((a.S + 255) / 256), dim3(256), 0, stream, a);
+    } else if (a.L == 2 && a.W == 20 && a.rescale_mask == 0) {
         hipLaunchKernelGGL((crf_windowed_l2<20, true, false, kWinThreads>), grid, block, 0, stream, a);
     } else if (a.L == 2 && a.W == 20) {
         hipLaunchKernelGGL((crf_windowed_l2<20, true, true, kWinThreads>), grid, block, 0, stream, a);

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/gecco_crf.h"
@@ -87,6 +88,7 @@ Plan::~Plan() {
             (void)hipFree(d_ct_chunk0);
             (void)hipFree(d_ch_first);
             (void)hipFree(d_seq_ws);
+            (void)hipFree(d_win_scratch);
             (void)hipSetDevice(prev);
         }
     }
@@ -183,12 +185,17 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     p.S = int32_t(S);
     p.c_slot.push_back(p.S);
 
-    p.fast_ok = (m.L == 2 && W <= kWinMaxW && rescale_mask_for(m, W, &p.rescale_mask));
-    if (!p.fast_ok) {
-        set_error("no kernel for this model/window shape yet (need 2 labels, window <= 32)");
+    if (m.L != 2) {
+        set_error("only 2-label models are supported (GECCO's labels are '0' and '1')");
         return GECCO_CRF_EUNSUPPORTED;
     }
-    p.kernel_name = windowed_kernel_name(W, m.L);
+    p.fast_ok = (W <= kWinMaxW && rescale_mask_for(m, W, &p.rescale_mask));
+    {
+        const char *env = std::getenv("GECCO_CRF_FORCE_GENERIC");
+        p.force_generic = env && env[0] == '1';
+    }
+    if (p.force_generic) p.fast_ok = false;
+    p.kernel_name = windowed_kernel_name(W, m.L, p.fast_ok);
     p.tile_out = windowed_tile_out(W, m.L);
     p.ntiles = p.S > 0 ? (p.S + p.tile_out - 1) / p.tile_out : 0;
     // window-start flags per slot (_meta.py:131: starts at 0, step, 2*step, ... <= n' - W)
@@ -282,6 +289,25 @@ int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_
         const double kappa = std::exp(T(label, o) - T(o, o));
         a.kappa_over_mu11 = kappa / a.mu11;
         a.inv_kappa = 1.0 / kappa;
+    }
+    {
+        const int o = 1 - label;
+        const double mx = *std::max_element(m.trans.begin(), m.trans.end());
+        auto G = [&](int i, int j) { return std::exp(m.trans[size_t(i) * 2 + j] - mx); };
+        a.g00 = G(o, o);
+        a.g01 = G(o, label);
+        a.g10 = G(label, o);
+        a.g11 = G(label, label);
+    }
+    a.generic = p.fast_ok ? 0 : 1;
+    if (a.generic) {
+        if (!p.d_win_scratch &&
+            (rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_win_scratch), size_t(p.S) * size_t(p.W) * 16 + 16),
+                            "hipMalloc window scratch")))
+            return rc;
+        a.scratch = p.d_win_scratch;
+        // atomic-max accumulation starts from 0.0 (numpy.zeros, crf/__init__.py:251)
+        if ((rc = check_hip(hipMemsetAsync(d_p_out, 0, size_t(p.n_genes) * 8, stream), "memset p"))) return rc;
     }
     if (!p.skipped.empty())
         if ((rc = check_hip(launch_fill_nan(d_p_out, p.d_skipped, int(p.skipped.size()), stream), "fill_nan launch")))

@@ -35,7 +35,9 @@ struct Plan {
     std::vector<int2> skipped;  // gene ranges of contigs skipped by pad == 0
     std::vector<int32_t> contig_ptr;
     uint32_t rescale_mask = 0;
-    bool fast_ok = false;
+    bool fast_ok = false;       // the register-resident kernel takes this shape
+    bool force_generic = false; // GECCO_CRF_FORCE_GENERIC=1 (tests): always use the generic kernel
+    double *d_win_scratch = nullptr;
     std::string kernel_name;
     // device copies
     int32_t *d_c_slot = nullptr, *d_c_gene = nullptr, *d_c_n = nullptr, *d_contig_ptr = nullptr;

@@ -70,3 +70,11 @@ def test_many_contigs_objects_vs_oracle(oracle_model):
     # columnar entry point gives the same numbers
     p = crf.predict_probabilities_csr(cptr, gptr, attr)
     assert np.abs(p - exp).max() <= 1e-12
+
+
+def test_predict_clusters_convenience():
+    from gecco_amd.crf import ClusterCRF
+    from tests.test_host_logic import _golden_genes
+
+    clusters = ClusterCRF.trained(GOLDEN).predict_clusters(_golden_genes())
+    assert [c.id for c in clusters] == ["BGC0001866.1_cluster_1"] and len(clusters[0].genes) == 23

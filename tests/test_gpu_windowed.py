@@ -165,3 +165,40 @@ def test_extreme_state_scores(nat):
     assert np.isfinite(got).all() and (got >= 0).all() and (got <= 1).all()
     ref = _logspace_windowed(w, trans, cptr, gptr, attr, 20)
     assert np.abs(got - ref).max() <= 1e-9  # log-domain reference itself carries ~1e-13*|score| error
+
+
+@pytest.mark.parametrize("W,step", [(33, 1), (50, 1), (64, 7), (100, 1)])
+def test_large_windows_use_generic_kernel(nat, real_model, oracle_model, W, step):
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(W)
+    cptr, gptr, attr = synth_contigs(rng, [5, W - 1, W, W + 1, 300, 77, 1200], oracle_model["state"].shape[0])
+    plan = nat.Plan(real_model, cptr, W, step, True, device=-1)
+    assert plan.kernel_name == "crf_windowed_generic_l2"
+    got = real_model.windowed_marginals(cptr, gptr, attr, W, step)
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, W, step)
+    _cmp(got, exp)
+
+
+def test_huge_transition_spread_uses_generic_kernel(nat):
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(9)
+    A = 100
+    w, _ = synth_model(A, rng)
+    trans = np.array([[100.0, -120.0], [-90.0, 80.0]])
+    cptr, gptr, attr = synth_contigs(rng, [200, 20, 7], A)
+    model = nat.Model.from_tables(w, trans)
+    assert nat.Plan(model, cptr, 20, device=-1).kernel_name == "crf_windowed_generic_l2"
+    got = model.windowed_marginals(cptr, gptr, attr, 20)
+    exp = orc.windowed_marginals(w, trans, cptr, gptr, attr, 20)
+    _cmp(got, exp)
+
+
+def test_generic_kernel_cross_checks_fast_kernel(nat, real_model, oracle_model, monkeypatch):
+    rng = np.random.default_rng(31)
+    cptr, gptr, attr = synth_contigs(rng, list(rng.integers(1, 500, size=80)), oracle_model["state"].shape[0])
+    fast = real_model.windowed_marginals(cptr, gptr, attr, 20, pad=False)
+    monkeypatch.setenv("GECCO_CRF_FORCE_GENERIC", "1")
+    slow = real_model.windowed_marginals(cptr, gptr, attr, 20, pad=False)
+    _cmp(slow, fast)
