@@ -36,41 +36,41 @@ constexpr int kWinThreads = 256;  // lanes (= window starts) per workgroup
 constexpr int kWinMaxW = 32;      // largest window the register-resident kernel handles
 
 // ---- whole-contig kernels (crf_sequence.hip) ------------------------------------------------
-constexpr int kSeqChunk = 64;  // genes folded by one lane in the two-level scans
+constexpr int kSeqGenesPerLane = 8;  // genes folded sequentially by one lane of the flat scans
 
-struct Mat2 {
-    double a00, a01, a10, a11;
+// `rs` != 0: the span contains the first gene of a contig; everything before that gene is
+// forgotten (segmented scan), so rows are identical and hold the exact values since the reset.
+struct VE {  // max-plus 2x2 scan element
+    double a00, a01, a10, a11, rs;
+};
+struct FE {  // sum-product 2x2 scan element + power-of-two exponent + sum of emission maxima
+    double a00, a01, a10, a11, ex, ms, rs;
 };
 
 struct SeqArgs {
-    const double2 *state;      // [n_genes]    (s[label 0], s[label 1])
-    const int32_t *ch_start;   // [NC] first gene of chunk
-    const int32_t *ch_len;     // [NC]
-    const uint8_t *ch_first;   // [NC] chunk starts a contig
-    const int32_t *ct_chunk0;  // [n_contigs+1] first chunk of every contig
-    int32_t n_chunks, n_contigs, n_genes;
+    const double2 *state;    // [n_genes]  (s[label 0], s[label 1])
+    const uint8_t *flags;    // [n_genes]  bit0: first gene of a contig, bit1: last gene
+    int32_t n_contigs, n_genes;
     double m00, m01, m10, m11;  // exp(trans - mx)
     double t00, t01, t10, t11;  // raw transition weights (Viterbi)
     double mx;                  // max(trans)
-    // workspaces
-    Mat2 *chP;                  // [NC] chunk transfer matrices
-    double2 *chAux;             // [NC] F: (exponent removed, sum of emission maxima)
-    double2 *chIn;              // [NC] vector entering the chunk (alpha / delta just before it)
-    double2 *chOut;             // [NC] F: beta at the chunk's last gene
-    double2 *alpha;             // [n_genes] F: alpha_t
+    // workspaces: one element per lane (n_genes / kSeqGenesPerLane) or per workgroup
+    VE *vLane, *vBlock;
+    uint32_t *vMaps, *vLaneMap, *vBlockMap;
+    FE *fLane, *fBlock, *fLaneSuf, *fBlockSuf;
+    double2 *alpha;      // [n_genes] F: alpha_t
+    double2 *contigTmp;  // [n_genes] sparse: values parked at contig ends
     // outputs
-    double *marg;               // [n_genes*2]
-    double *lognorm;            // [n_contigs] or null
-    int8_t *y;                  // [n_genes]
-    double *score;              // [n_contigs] or null
-    int8_t *chMap;              // [NC*2] V: label before the chunk for each label at its end
-    int8_t *chEnd;              // [NC]   V: label at the chunk's last gene
+    double *marg;     // [n_genes*2]
+    double *lognorm;  // [n_contigs] or null
+    int8_t *y;        // [n_genes]
+    double *score;    // [n_contigs] or null
 };
 
 hipError_t launch_seq_state(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_genes,
                             double2 *state, hipStream_t stream);
-hipError_t launch_seq_marginals(const SeqArgs &a, hipStream_t stream);
-hipError_t launch_seq_viterbi(const SeqArgs &a, hipStream_t stream);
+hipError_t launch_seq_marginals(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream);
+hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream);
 
 // row R on packed arrays (crf_segment.hip); d_work: 2*n_contigs int32 + n_contigs bytes
 hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const int32_t *d_cptr, int n_contigs, double threshold,

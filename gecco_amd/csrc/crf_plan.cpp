@@ -83,10 +83,7 @@ Plan::~Plan() {
             (void)hipFree(d_tile_desc);
             (void)hipFree(d_start_bits);
             (void)hipFree(d_skipped);
-            (void)hipFree(d_ch_start);
-            (void)hipFree(d_ch_len);
-            (void)hipFree(d_ct_chunk0);
-            (void)hipFree(d_ch_first);
+            (void)hipFree(d_seq_flags);
             (void)hipFree(d_seq_ws);
             (void)hipFree(d_win_scratch);
             (void)hipSetDevice(prev);
@@ -319,29 +316,52 @@ int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_
 namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+struct SeqLayout {
+    size_t lanes, blocks, bytes;
+    size_t off_state, off_alpha, off_tmp, off_vlane, off_vblock, off_vmaps, off_vlanemap, off_vblockmap, off_flane,
+        off_fblock, off_flanesuf, off_fblocksuf;
+};
+SeqLayout seq_layout(size_t n) {
+    SeqLayout l{};
+    l.lanes = (n + kSeqGenesPerLane - 1) / kSeqGenesPerLane;
+    l.blocks = (l.lanes + 255) / 256;
+    const size_t lanes_pad = l.blocks * 256;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t r = o;
+        o += align256(bytes);
+        return r;
+    };
+    l.off_state = take((n + kSeqGenesPerLane) * 16);
+    l.off_alpha = take(n * 16);
+    l.off_tmp = take(n * 16);
+    l.off_vlane = take(lanes_pad * sizeof(VE));
+    l.off_vblock = take(l.blocks * sizeof(VE));
+    l.off_vmaps = take(lanes_pad * 4);
+    l.off_vlanemap = take(lanes_pad * 4);
+    l.off_vblockmap = take(l.blocks * 4);
+    l.off_flane = take(lanes_pad * sizeof(FE));
+    l.off_fblock = take(l.blocks * sizeof(FE));
+    l.off_flanesuf = take(lanes_pad * sizeof(FE));
+    l.off_fblocksuf = take(l.blocks * sizeof(FE));
+    l.bytes = o + 256;
+    return l;
+}
+
 int ensure_seq(Plan &p) {
     if (p.seq_ready) return GECCO_CRF_OK;
-    std::vector<int32_t> ch_start, ch_len, ct_chunk0(size_t(p.n_contigs) + 1, 0);
-    std::vector<uint8_t> ch_first;
+    std::vector<uint8_t> flags(size_t(p.n_genes) + 1, 0);
     for (int32_t c = 0; c < p.n_contigs; ++c) {
-        ct_chunk0[c] = int32_t(ch_start.size());
         const int32_t g0 = p.contig_ptr[c], g1 = p.contig_ptr[c + 1];
-        for (int32_t g = g0; g < g1; g += kSeqChunk) {
-            ch_start.push_back(g);
-            ch_len.push_back(std::min(kSeqChunk, g1 - g));
-            ch_first.push_back(g == g0);
+        if (g1 > g0) {
+            flags[g0] |= 1;
+            flags[g1 - 1] |= 2;
         }
     }
-    ct_chunk0[p.n_contigs] = int32_t(ch_start.size());
-    p.n_chunks = int32_t(ch_start.size());
     int rc;
-    if ((rc = upload(&p.d_ch_start, ch_start.data(), ch_start.size(), "upload chunk table"))) return rc;
-    if ((rc = upload(&p.d_ch_len, ch_len.data(), ch_len.size(), "upload chunk table"))) return rc;
-    if ((rc = upload(&p.d_ch_first, ch_first.data(), ch_first.size(), "upload chunk table"))) return rc;
-    if ((rc = upload(&p.d_ct_chunk0, ct_chunk0.data(), ct_chunk0.size(), "upload chunk table"))) return rc;
-    const size_t n = size_t(p.n_genes), nc = size_t(p.n_chunks);
-    const size_t bytes = align256(n * 16) * 2 + align256(nc * 32) + align256(nc * 16) * 3 + align256(nc * 2) + align256(nc) + 256;
-    if ((rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_seq_ws), bytes), "hipMalloc scan workspace"))) return rc;
+    if ((rc = upload(&p.d_seq_flags, flags.data(), flags.size(), "upload contig flags"))) return rc;
+    const SeqLayout l = seq_layout(size_t(p.n_genes));
+    if ((rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_seq_ws), l.bytes), "hipMalloc scan workspace"))) return rc;
     p.seq_ready = true;
     return GECCO_CRF_OK;
 }
@@ -359,27 +379,22 @@ int fill_seq_args(Plan &p, SeqArgs &a) {
     if (rc) return rc;
     if ((rc = ensure_seq(p))) return rc;
     const Model &m = *p.model;
-    const size_t n = size_t(p.n_genes), nc = size_t(p.n_chunks);
+    const SeqLayout l = seq_layout(size_t(p.n_genes));
     char *w = p.d_seq_ws;
-    auto take = [&](size_t bytes) {
-        char *r = w;
-        w += align256(bytes);
-        return r;
-    };
     a = SeqArgs{};
-    a.state = reinterpret_cast<double2 *>(take(n * 16));
-    a.alpha = reinterpret_cast<double2 *>(take(n * 16));
-    a.chP = reinterpret_cast<Mat2 *>(take(nc * 32));
-    a.chAux = reinterpret_cast<double2 *>(take(nc * 16));
-    a.chIn = reinterpret_cast<double2 *>(take(nc * 16));
-    a.chOut = reinterpret_cast<double2 *>(take(nc * 16));
-    a.chMap = reinterpret_cast<int8_t *>(take(nc * 2));
-    a.chEnd = reinterpret_cast<int8_t *>(take(nc));
-    a.ch_start = p.d_ch_start;
-    a.ch_len = p.d_ch_len;
-    a.ch_first = p.d_ch_first;
-    a.ct_chunk0 = p.d_ct_chunk0;
-    a.n_chunks = p.n_chunks;
+    a.state = reinterpret_cast<double2 *>(w + l.off_state);
+    a.alpha = reinterpret_cast<double2 *>(w + l.off_alpha);
+    a.contigTmp = reinterpret_cast<double2 *>(w + l.off_tmp);
+    a.vLane = reinterpret_cast<VE *>(w + l.off_vlane);
+    a.vBlock = reinterpret_cast<VE *>(w + l.off_vblock);
+    a.vMaps = reinterpret_cast<uint32_t *>(w + l.off_vmaps);
+    a.vLaneMap = reinterpret_cast<uint32_t *>(w + l.off_vlanemap);
+    a.vBlockMap = reinterpret_cast<uint32_t *>(w + l.off_vblockmap);
+    a.fLane = reinterpret_cast<FE *>(w + l.off_flane);
+    a.fBlock = reinterpret_cast<FE *>(w + l.off_fblock);
+    a.fLaneSuf = reinterpret_cast<FE *>(w + l.off_flanesuf);
+    a.fBlockSuf = reinterpret_cast<FE *>(w + l.off_fblocksuf);
+    a.flags = p.d_seq_flags;
     a.n_contigs = p.n_contigs;
     a.n_genes = p.n_genes;
     a.mx = *std::max_element(m.trans.begin(), m.trans.end());
@@ -411,7 +426,7 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
     if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables->wtab2[1], p.n_genes,
                                          const_cast<double2 *>(a.state), stream), "state score launch")))
         return rc;
-    return check_hip(launch_seq_marginals(a, stream), "marginals launch");
+    return check_hip(launch_seq_marginals(a, p.d_contig_ptr, stream), "marginals launch");
 }
 
 int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int8_t *d_y, double *d_score,
@@ -429,7 +444,7 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
     if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables->wtab2[1], p.n_genes,
                                          const_cast<double2 *>(a.state), stream), "state score launch")))
         return rc;
-    return check_hip(launch_seq_viterbi(a, stream), "viterbi launch");
+    return check_hip(launch_seq_viterbi(a, p.d_contig_ptr, stream), "viterbi launch");
 }
 
 }  // namespace gecco

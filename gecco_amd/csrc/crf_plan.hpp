@@ -47,9 +47,7 @@ struct Plan {
     const DeviceTables *tables = nullptr;
     // whole-contig scans (rows F, V): chunk tables + workspace, built on first use
     bool seq_ready = false;
-    int32_t n_chunks = 0;
-    int32_t *d_ch_start = nullptr, *d_ch_len = nullptr, *d_ct_chunk0 = nullptr;
-    uint8_t *d_ch_first = nullptr;
+    uint8_t *d_seq_flags = nullptr;
     char *d_seq_ws = nullptr;
     ~Plan();
 };

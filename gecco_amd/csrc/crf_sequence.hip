@@ -1,51 +1,167 @@
 // Whole-contig inference kernels (north-star extensions; rows F and V of SURVEY.md §8a):
-//   F  [EXT] CRF.predict_marginals_single(all feats)  = crf1dc_alpha/beta/marginal_point over a
-//      whole contig -- NOT what GECCO's predict path computes (that is the windowed kernel);
+//   F  [EXT] CRF.predict_marginals_single(all feats) = crf1dc_alpha_score / crf1dc_beta_score /
+//      crf1dc_marginal_point over a whole contig -- NOT what GECCO's predict path computes
+//      (that is the windowed kernel);
 //   V  [EXT] CRF.predict_single = crf1dc_viterbi, first-argmax tie-breaking.
-// Two-label models.  Contigs range from a handful of genes to 50 000 (BASELINE.json configs[4]),
-// so sequences are cut into chunks of kSeqChunk genes and scanned on two levels:
-//   1. one lane per chunk folds its genes into a 2x2 transfer matrix (sum-product for F with
-//      power-of-two rescaling, max-plus for V);
-//   2. one lane per contig walks its chunk matrices (n/64 steps) to get the DP vectors at every
-//      chunk boundary;
-//   3. one lane per chunk replays its genes from the boundary vector and emits results.
-// Contigs up to kSeqChunk genes are a single chunk, i.e. evaluated strictly sequentially.
-// For longer contigs boundary scores are composed through the chunk matrices: identical
-// whenever the additions are exact (e.g. integer-valued weights, ties included), equal to
-// rounding otherwise.
+// Two-label models.  Contigs range from a handful of genes to 50 000 (BASELINE.json
+// configs[4]: scan-length-bound), so nothing here is "one lane per contig": all genes of all
+// contigs form ONE flat sequence and both recursions are associative scans of 2x2 matrices
+// over it -- max-plus for V, sum-product with exact power-of-two rescaling for F.  A contig's
+// first gene contributes a matrix with identical rows (it ignores whatever came before), so
+// contig boundaries need no segmented-scan logic at all; the backward direction does the same
+// with the contig's last gene.
+//
+// Three scan levels: a lane folds kGPL consecutive genes (registers, sequential, coalesced
+// 128-B reads), a wave scans its 64 lane products with DPP row_shr/row_bcast (no LDS), the
+// four wave totals and then the per-workgroup totals are combined through LDS / a
+// single-workgroup kernel.  Every gene is then replayed from the exact vector entering its
+// lane, using CRFsuite's operation order inside the lane.  Scores entering a lane come from
+// matrix products, i.e. they equal the strictly sequential values whenever the additions are
+// exact (integer-valued weights: ties and first-argmax included) and to rounding otherwise.
 #include "crf_device.hpp"
 
 namespace gecco {
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kT = 256;                 // lanes per workgroup
+constexpr int kGPL = kSeqGenesPerLane;  // genes folded by one lane
+constexpr int kBlockGenes = kT * kGPL;
 
-__device__ __forceinline__ double max4(double a, double b, double c, double d) { return fmax(fmax(a, b), fmax(c, d)); }
+// ---------------------------------------------------------------- scan operators (elements: crf_device.hpp)
+struct VOp {
+    static __device__ __forceinline__ VE identity() {
+        const double ninf = -__builtin_huge_val();
+        return VE{0.0, ninf, ninf, 0.0, 0.0};
+    }
+    static __device__ __forceinline__ VE combine(const VE &a, const VE &b) {  // a earlier, b later
+        if (b.rs != 0.0) return b;  // b restarts a contig: nothing before it matters
+        return VE{fmax(a.a00 + b.a00, a.a01 + b.a10), fmax(a.a00 + b.a01, a.a01 + b.a11),
+                  fmax(a.a10 + b.a00, a.a11 + b.a10), fmax(a.a10 + b.a01, a.a11 + b.a11), a.rs};
+    }
+};
+struct FOp {
+    static __device__ __forceinline__ FE identity() { return FE{1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0}; }
+    static __device__ __forceinline__ FE combine(const FE &a, const FE &b) {
+        if (b.rs != 0.0) return b;
+        FE c;
+        c.a00 = fma(a.a01, b.a10, a.a00 * b.a00);
+        c.a01 = fma(a.a01, b.a11, a.a00 * b.a01);
+        c.a10 = fma(a.a11, b.a10, a.a10 * b.a00);
+        c.a11 = fma(a.a11, b.a11, a.a10 * b.a01);
+        int e;
+        (void)frexp(fmax(fmax(c.a00, c.a01), fmax(c.a10, c.a11)), &e);
+        c.a00 = ldexp(c.a00, -e);
+        c.a01 = ldexp(c.a01, -e);
+        c.a10 = ldexp(c.a10, -e);
+        c.a11 = ldexp(c.a11, -e);
+        c.ex = a.ex + b.ex + double(e);
+        c.ms = a.ms + b.ms;
+        c.rs = a.rs;
+        return c;
+    }
+};
+struct MapOp {  // maps {0,1}->{0,1} packed in 2 bits: bit x = image of x
+    static __device__ __forceinline__ uint32_t identity() { return 2u; }
+    // result(x) = a(b(x)): b is applied first.  In the backward label scans the element closer
+    // to the END of the sequence acts first.
+    static __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) {
+        return ((a >> (b & 1u)) & 1u) | (((a >> ((b >> 1) & 1u)) & 1u) << 1);
+    }
+};
 
-// exact power-of-two renormalisation; returns the exponent removed
-__device__ __forceinline__ int renorm(Mat2 &p) {
-    int ex;
-    (void)frexp(max4(p.a00, p.a01, p.a10, p.a11), &ex);
-    p.a00 = ldexp(p.a00, -ex);
-    p.a01 = ldexp(p.a01, -ex);
-    p.a10 = ldexp(p.a10, -ex);
-    p.a11 = ldexp(p.a11, -ex);
-    return ex;
+// ---------------------------------------------------------------- DPP plumbing
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_f64(double old, double src) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, RM, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, RM, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ int renorm2(double &u, double &v) {
-    int ex;
-    (void)frexp(fmax(u, v), &ex);
-    u = ldexp(u, -ex);
-    v = ldexp(v, -ex);
-    return ex;
+template <int CTRL, int RM>
+__device__ __forceinline__ VE dpp_elem(const VE &old, const VE &s) {
+    return VE{dpp_f64<CTRL, RM>(old.a00, s.a00), dpp_f64<CTRL, RM>(old.a01, s.a01), dpp_f64<CTRL, RM>(old.a10, s.a10),
+              dpp_f64<CTRL, RM>(old.a11, s.a11), dpp_f64<CTRL, RM>(old.rs, s.rs)};
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ FE dpp_elem(const FE &old, const FE &s) {
+    return FE{dpp_f64<CTRL, RM>(old.a00, s.a00), dpp_f64<CTRL, RM>(old.a01, s.a01), dpp_f64<CTRL, RM>(old.a10, s.a10),
+              dpp_f64<CTRL, RM>(old.a11, s.a11), dpp_f64<CTRL, RM>(old.ex, s.ex),   dpp_f64<CTRL, RM>(old.ms, s.ms),
+              dpp_f64<CTRL, RM>(old.rs, s.rs)};
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ uint32_t dpp_elem(const uint32_t &old, const uint32_t &s) {
+    return uint32_t(__builtin_amdgcn_update_dpp(int(old), int(s), CTRL, RM, 0xF, false));
 }
 
-// ---- row S for whole contigs: state scores of every gene, (s[label 0], s[label 1])
-__global__ void __launch_bounds__(kThreads) seq_state_scores(const int32_t *__restrict__ gene_ptr,
-                                                             const int32_t *__restrict__ attr_id,
-                                                             const double2 *__restrict__ wtab01, int n_genes,
-                                                             double2 *__restrict__ state) {
-    const int g = blockIdx.x * kThreads + threadIdx.x;
+// REV = false: out[l] = e[0] (x) e[1] (x) ... (x) e[l]   (lane order = sequence order)
+// REV = true : out[l] = e[l] (x) e[l-1] (x) ... (x) e[0]  (lanes hold the sequence back to front)
+template <class Op, bool REV, class E>
+__device__ __forceinline__ E comb(const E &earlier_lane, const E &later_lane) {
+    return REV ? Op::combine(later_lane, earlier_lane) : Op::combine(earlier_lane, later_lane);
+}
+template <class Op, bool REV, class E>
+__device__ __forceinline__ E wave_scan_inclusive(E v) {
+    const E id = Op::identity();
+    v = comb<Op, REV>(dpp_elem<0x111, 0xF>(id, v), v);  // row_shr:1
+    v = comb<Op, REV>(dpp_elem<0x112, 0xF>(id, v), v);  // row_shr:2
+    v = comb<Op, REV>(dpp_elem<0x114, 0xF>(id, v), v);  // row_shr:4
+    v = comb<Op, REV>(dpp_elem<0x118, 0xF>(id, v), v);  // row_shr:8
+    v = comb<Op, REV>(dpp_elem<0x142, 0xA>(id, v), v);  // row_bcast:15 -> rows 1,3
+    v = comb<Op, REV>(dpp_elem<0x143, 0xC>(id, v), v);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+template <class E>
+__device__ __forceinline__ E wave_shift_up(const E &id, const E &v) {  // lane l <- lane l-1, lane 0 <- id
+    return dpp_elem<0x138, 0xF>(id, v);                                 // wave_shr:1
+}
+// Workgroup-wide EXCLUSIVE scan of one element per lane (kT lanes); *total = product of all.
+template <class Op, bool REV, class E>
+__device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /* kT/64 */, E *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const E id = Op::identity();
+    const E incl = wave_scan_inclusive<Op, REV>(mine);
+    if (lane == 63) lds_totals[wave] = incl;
+    E excl = wave_shift_up(id, incl);
+    __syncthreads();
+    E pre = id, all = id;
+#pragma unroll
+    for (int w = 0; w < kT / 64; ++w) {
+        const E t = lds_totals[w];
+        if (w < wave) pre = comb<Op, REV>(pre, t);
+        all = comb<Op, REV>(all, t);
+    }
+    __syncthreads();  // lds_totals may be reused by the caller
+    *total = all;
+    return comb<Op, REV>(pre, excl);
+}
+
+// Single-workgroup exclusive scan over per-workgroup totals (in place).
+template <class Op, bool REV, class E>
+__global__ void __launch_bounds__(kT) scan_block_totals(E *agg, int n) {
+    __shared__ E lds[kT / 64];
+    __shared__ E carry_s;
+    if (threadIdx.x == 0) carry_s = Op::identity();
+    __syncthreads();
+    for (int base = 0; base < n; base += kT) {
+        // REV: element i of the scan is block n-1-i
+        const int i = base + threadIdx.x;
+        const int idx = REV ? n - 1 - i : i;
+        const E mine = i < n ? agg[idx] : Op::identity();
+        E total;
+        const E excl = block_scan_exclusive<Op, REV>(mine, lds, &total);
+        const E carry = carry_s;
+        if (i < n) agg[idx] = comb<Op, REV>(carry, excl);
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = comb<Op, REV>(carry, total);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- row S: state scores
+__global__ void __launch_bounds__(kT) seq_state_scores(const int32_t *__restrict__ gene_ptr,
+                                                       const int32_t *__restrict__ attr_id,
+                                                       const double2 *__restrict__ wtab01, int n_genes,
+                                                       double2 *__restrict__ state) {
+    const int g = blockIdx.x * kT + threadIdx.x;
     if (g >= n_genes) return;
     const int lo = gene_ptr[g], hi = gene_ptr[g + 1];
     double s0 = 0.0, s1 = 0.0;
@@ -65,252 +181,317 @@ __global__ void __launch_bounds__(kThreads) seq_state_scores(const int32_t *__re
     state[g] = make_double2(s0, s1);
 }
 
+// ---------------------------------------------------------------- lane-local loads
+// lane `slot` of the workgroup owns genes [g0, g0 + kGPL); flags bit0 = first gene of a contig,
+// bit1 = last gene of a contig.
+struct LaneGenes {
+    double2 s[kGPL];
+    uint32_t first, last;  // bit k
+    int g0, cnt;
+};
+__device__ __forceinline__ LaneGenes load_lane(const SeqArgs &A, int slot) {
+    LaneGenes L;
+    L.g0 = (blockIdx.x * kT + slot) * kGPL;
+    L.cnt = min(kGPL, A.n_genes - L.g0);
+    L.first = L.last = 0;
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        if (k < L.cnt) {
+            L.s[k] = A.state[L.g0 + k];
+            const uint32_t f = A.flags[L.g0 + k];
+            L.first |= (f & 1u) << k;
+            L.last |= ((f >> 1) & 1u) << k;
+        } else {
+            L.s[k] = make_double2(0.0, 0.0);
+        }
+    }
+    return L;
+}
+
 // =====================================================================================
-// F: sum-product.  alpha_t = (1,1) D_0 (M' D_1) ... (M' D_t),  beta_t = (M' D_{t+1}) ... (M' D_{n-1}) 1
-// with D_t = diag(exp(s_t - max s_t)), M' = exp(trans - max trans); all scale factors cancel in
-// P_t(y) = alpha_t[y] beta_t[y] / (alpha_t . beta_t) and are tracked only for log Z.
+// V: max-plus.  delta_0 = s_0; delta_t[j] = max_i(delta_{t-1}[i] + trans[i][j]) + s_t[j]; ties keep
+// the smaller i (CRFsuite updates on strict '<'); the end label is the first argmax.
+// =====================================================================================
+__global__ void __launch_bounds__(kT) v_fold(const SeqArgs A) {
+    __shared__ VE lds[kT / 64];
+    const LaneGenes L = load_lane(A, threadIdx.x);
+    VE P = VOp::identity();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        if (k < L.cnt) {
+            const bool first = (L.first >> k) & 1u;
+            const VE S{(first ? 0.0 : A.t00) + L.s[k].x, (first ? 0.0 : A.t01) + L.s[k].y,
+                       (first ? 0.0 : A.t10) + L.s[k].x, (first ? 0.0 : A.t11) + L.s[k].y, first ? 1.0 : 0.0};
+            P = VOp::combine(P, S);
+        }
+    }
+    VE total;
+    const VE excl = block_scan_exclusive<VOp, false>(P, lds, &total);
+    A.vLane[blockIdx.x * kT + threadIdx.x] = excl;
+    if (threadIdx.x == 0) A.vBlock[blockIdx.x] = total;
+}
+
+// replay with the exact entering delta; per gene the map label_{t+1} -> label_t (its own end label
+// for a contig's last gene, else the back-pointers the NEXT gene will compute from delta_t); fold
+// the lane's maps and scan them back to front
+__global__ void __launch_bounds__(kT) v_replay(const SeqArgs A) {
+    __shared__ uint32_t lds[kT / 64];
+    const int slot = threadIdx.x;
+    const LaneGenes L = load_lane(A, slot);
+    const VE M = VOp::combine(A.vBlock[blockIdx.x], A.vLane[blockIdx.x * kT + slot]);
+    double d0 = M.a00, d1 = M.a01;  // rows are identical once a contig has started (M.rs)
+    uint32_t maps = 0;                                         // 2 bits per gene
+    uint32_t lane_map = MapOp::identity();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        if (k < L.cnt) {
+            if ((L.first >> k) & 1u) {
+                d0 = L.s[k].x;
+                d1 = L.s[k].y;
+            } else {
+                const double a0 = d0 + A.t00, b0 = d1 + A.t10, a1 = d0 + A.t01, b1 = d1 + A.t11;
+                d0 = (a0 < b0 ? b0 : a0) + L.s[k].x;
+                d1 = (a1 < b1 ? b1 : a1) + L.s[k].y;
+            }
+            uint32_t m;
+            if ((L.last >> k) & 1u) {
+                const uint32_t end = d0 < d1 ? 1u : 0u;  // first argmax
+                m = end | (end << 1);
+                A.contigTmp[L.g0 + k] = make_double2(fmax(d0, d1), 0.0);
+            } else {
+                m = ((d0 + A.t00 < d1 + A.t10) ? 1u : 0u) | ((d0 + A.t01 < d1 + A.t11) ? 2u : 0u);
+            }
+            maps |= m << (2 * k);
+        }
+    }
+    // lane map: label entering from the right -> label of the lane's first gene
+#pragma unroll
+    for (int k = kGPL - 1; k >= 0; --k)
+        if (k < L.cnt) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
+    A.vMaps[blockIdx.x * kT + slot] = maps;
+    // back-to-front scan: scan position p = kT-1-slot, so hand the element to the mirrored lane
+    __shared__ uint32_t xch[kT];
+    xch[kT - 1 - slot] = lane_map;
+    __syncthreads();
+    const uint32_t mine = xch[slot];
+    uint32_t total;
+    const uint32_t excl = block_scan_exclusive<MapOp, true>(mine, lds, &total);
+    __syncthreads();
+    xch[kT - 1 - slot] = excl;  // back to natural lane order
+    __syncthreads();
+    A.vLaneMap[blockIdx.x * kT + slot] = xch[slot];
+    if (slot == 0) A.vBlockMap[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kT) v_labels(const SeqArgs A) {
+    const int slot = threadIdx.x;
+    const int g0 = (blockIdx.x * kT + slot) * kGPL;
+    const int cnt = min(kGPL, A.n_genes - g0);
+    if (cnt <= 0) return;
+    // suffix map of everything to the right of this lane, applied to a dummy label (the last gene
+    // of the batch ends a contig, so the composition is constant)
+    const uint32_t suf = MapOp::combine(A.vLaneMap[blockIdx.x * kT + slot], A.vBlockMap[blockIdx.x]);
+    uint32_t lab = suf & 1u;
+    const uint32_t maps = A.vMaps[blockIdx.x * kT + slot];
+    uint64_t packed = 0;
+#pragma unroll
+    for (int k = kGPL - 1; k >= 0; --k) {
+        if (k < cnt) {
+            lab = (maps >> (2 * k + lab)) & 1u;
+            packed |= uint64_t(lab) << (8 * k);
+        }
+    }
+    if (cnt == kGPL) {
+        *reinterpret_cast<uint64_t *>(A.y + g0) = packed;
+    } else {
+        for (int k = 0; k < cnt; ++k) A.y[g0 + k] = int8_t((packed >> (8 * k)) & 0xff);
+    }
+}
+
+__global__ void __launch_bounds__(kT) v_scores(const SeqArgs A, const int32_t *__restrict__ contig_ptr) {
+    const int c = blockIdx.x * kT + threadIdx.x;
+    if (c >= A.n_contigs) return;
+    const int g1 = contig_ptr[c + 1];
+    A.score[c] = g1 > contig_ptr[c] ? A.contigTmp[g1 - 1].x : 0.0;
+}
+
+// =====================================================================================
+// F: sum-product.  T_t = M' D_t (first gene of a contig: 1 e_t^T, which forgets the past),
+// D_t = diag(exp(s_t - max s_t)), M' = exp(trans - max trans).  alpha_t ~ (1,1) T_0..T_t,
+// beta_t ~ B_t B_{t+1} ... 1 with B_t = T_{t+1} (last gene of a contig: 1 1^T).  All scale
+// factors cancel in P_t(y) = alpha_t[y] beta_t[y] / (alpha_t . beta_t); exponents and emission
+// maxima are carried along only for log Z.
 // =====================================================================================
 __device__ __forceinline__ double2 emit_norm(double2 s, double &m) {
     m = fmax(s.x, s.y);
     return make_double2(exp(s.x - m), exp(s.y - m));
 }
-
-__global__ void __launch_bounds__(kThreads) f_chunk_product(const SeqArgs A) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= A.n_chunks) return;
-    const int g0 = A.ch_start[c], len = A.ch_len[c];
-    Mat2 P{1.0, 0.0, 0.0, 1.0};
-    double ex = 0.0, sm = 0.0;
-    for (int k = 0; k < len; ++k) {
-        double m;
-        const double2 e = emit_norm(A.state[g0 + k], m);
-        sm += m;
-        Mat2 Q;
-        if (k == 0 && A.ch_first[c]) {  // first gene of the contig: no transition in front
-            Q = P;
-        } else {
-            Q.a00 = fma(P.a01, A.m10, P.a00 * A.m00);
-            Q.a01 = fma(P.a01, A.m11, P.a00 * A.m01);
-            Q.a10 = fma(P.a11, A.m10, P.a10 * A.m00);
-            Q.a11 = fma(P.a11, A.m11, P.a10 * A.m01);
-        }
-        P.a00 = Q.a00 * e.x;
-        P.a01 = Q.a01 * e.y;
-        P.a10 = Q.a10 * e.x;
-        P.a11 = Q.a11 * e.y;
-        ex += double(renorm(P));
-    }
-    A.chP[c] = P;
-    A.chAux[c] = make_double2(ex, sm);
+__device__ __forceinline__ FE f_step(const SeqArgs &A, double2 s, bool first) {
+    double m;
+    const double2 e = emit_norm(s, m);
+    return FE{(first ? 1.0 : A.m00) * e.x, (first ? 1.0 : A.m01) * e.y, (first ? 1.0 : A.m10) * e.x,
+              (first ? 1.0 : A.m11) * e.y, 0.0, m, first ? 1.0 : 0.0};
 }
 
-__global__ void __launch_bounds__(kThreads) f_contig_scan(const SeqArgs A) {
-    const int ci = blockIdx.x * kThreads + threadIdx.x;
-    if (ci >= A.n_contigs) return;
-    const int c0 = A.ct_chunk0[ci], c1 = A.ct_chunk0[ci + 1];
-    if (c0 == c1) {
-        if (A.lognorm) A.lognorm[ci] = 0.0;
+__global__ void __launch_bounds__(kT) f_fold(const SeqArgs A) {
+    __shared__ FE lds[kT / 64];
+    const LaneGenes L = load_lane(A, threadIdx.x);
+    FE P = FOp::identity();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k)
+        if (k < L.cnt) P = FOp::combine(P, f_step(A, L.s[k], (L.first >> k) & 1u));
+    FE total;
+    const FE excl = block_scan_exclusive<FOp, false>(P, lds, &total);
+    A.fLane[blockIdx.x * kT + threadIdx.x] = excl;
+    if (threadIdx.x == 0) A.fBlock[blockIdx.x] = total;
+}
+
+// forward replay (alpha of every gene, cumulative log-mass at contig ends) + fold of the
+// backward matrices B_t, scanned back to front
+__global__ void __launch_bounds__(kT) f_replay(const SeqArgs A) {
+    __shared__ FE lds[kT / 64];
+    __shared__ FE xch[kT];
+    const int slot = threadIdx.x;
+    const LaneGenes L = load_lane(A, slot);
+    const FE M = FOp::combine(A.fBlock[blockIdx.x], A.fLane[blockIdx.x * kT + slot]);
+    // alpha entering the lane = a row of M (rows are identical once a contig has started), with the
+    // exponent and emission-maximum sums accumulated since that contig's first gene
+    double a0 = M.a00, a1 = M.a01, ex = M.ex, ms = M.ms;
+    const double2 s_next = (L.cnt == kGPL && L.g0 + kGPL < A.n_genes) ? A.state[L.g0 + kGPL] : make_double2(0.0, 0.0);
+    FE Bfold = FOp::identity();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        if (k < L.cnt) {
+            double m;
+            const double2 e = emit_norm(L.s[k], m);
+            double n0, n1;
+            if ((L.first >> k) & 1u) {  // alpha_0 = exp(s_0): restart exactly
+                n0 = n1 = 1.0;
+                ex = 0.0;
+                ms = 0.0;
+            } else {
+                n0 = fma(a1, A.m10, a0 * A.m00);
+                n1 = fma(a1, A.m11, a0 * A.m01);
+            }
+            a0 = n0 * e.x;
+            a1 = n1 * e.y;
+            int ee;
+            (void)frexp(fmax(a0, a1), &ee);
+            a0 = ldexp(a0, -ee);
+            a1 = ldexp(a1, -ee);
+            ex += double(ee);
+            ms += m;
+            A.alpha[L.g0 + k] = make_double2(a0, a1);
+            if ((L.last >> k) & 1u) {
+                // log Z' of the contig (max-normalised emissions / transitions) and its emission maxima
+                A.contigTmp[L.g0 + k] = make_double2(ex * 0.6931471805599453 + log(a0 + a1), ms);
+            }
+            // backward matrix of this gene
+            const bool last = (L.last >> k) & 1u;
+            const double2 sn = k + 1 < kGPL ? L.s[k + 1 < kGPL ? k + 1 : k] : s_next;
+            FE B;
+            if (last) {
+                B = FE{1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0};
+            } else {
+                B = f_step(A, sn, false);
+            }
+            Bfold = FOp::combine(Bfold, B);  // B_{g0} B_{g0+1} ... in sequence order
+        }
+    }
+    xch[kT - 1 - slot] = Bfold;
+    __syncthreads();
+    const FE mine = xch[slot];
+    FE total;
+    const FE excl = block_scan_exclusive<FOp, true>(mine, lds, &total);
+    __syncthreads();
+    xch[kT - 1 - slot] = excl;
+    __syncthreads();
+    A.fLaneSuf[blockIdx.x * kT + slot] = xch[slot];
+    if (slot == 0) A.fBlockSuf[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kT) f_marginals(const SeqArgs A) {
+    const int slot = threadIdx.x;
+    const LaneGenes L = load_lane(A, slot);
+    if (L.cnt <= 0) return;
+    // beta entering from the right of the lane: (suffix of the lanes to the right) 1
+    const FE S = FOp::combine(A.fLaneSuf[blockIdx.x * kT + slot], A.fBlockSuf[blockIdx.x]);
+    double b0 = S.a00 + S.a01, b1 = S.a10 + S.a11;
+    const double2 s_next = (L.cnt == kGPL && L.g0 + kGPL < A.n_genes) ? A.state[L.g0 + kGPL] : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int k = kGPL - 1; k >= 0; --k) {
+        if (k < L.cnt) {
+            // beta_k = B_k beta_{k+1}
+            if ((L.last >> k) & 1u) {
+                b0 = b1 = 1.0;
+            } else {
+                double m;
+                const double2 e = emit_norm(k + 1 < kGPL ? L.s[k + 1 < kGPL ? k + 1 : k] : s_next, m);
+                const double c0 = e.x * b0, c1 = e.y * b1;
+                b0 = fma(A.m01, c1, A.m00 * c0);
+                b1 = fma(A.m11, c1, A.m10 * c0);
+                int ee;
+                (void)frexp(fmax(b0, b1), &ee);
+                b0 = ldexp(b0, -ee);
+                b1 = ldexp(b1, -ee);
+            }
+            const double2 al = A.alpha[L.g0 + k];
+            const double x0 = al.x * b0, x1 = al.y * b1, z = x0 + x1;
+            *reinterpret_cast<double2 *>(A.marg + 2 * size_t(L.g0 + k)) = make_double2(x0 / z, x1 / z);
+        }
+    }
+}
+
+// log Z of contig c = log Z' + its emission maxima + (n-1) max(trans)
+__global__ void __launch_bounds__(kT) f_lognorm(const SeqArgs A, const int32_t *__restrict__ contig_ptr) {
+    const int c = blockIdx.x * kT + threadIdx.x;
+    if (c >= A.n_contigs) return;
+    const int g0 = contig_ptr[c], g1 = contig_ptr[c + 1];
+    if (g1 <= g0) {
+        A.lognorm[c] = 0.0;
         return;
     }
-    double a0 = 1.0, a1 = 1.0, ex = 0.0, sm = 0.0;
-    int n = 0;
-    for (int c = c0; c < c1; ++c) {
-        A.chIn[c] = make_double2(a0, a1);
-        const Mat2 P = A.chP[c];
-        const double2 aux = A.chAux[c];
-        const double n0 = fma(a1, P.a10, a0 * P.a00);
-        const double n1 = fma(a1, P.a11, a0 * P.a01);
-        a0 = n0;
-        a1 = n1;
-        ex += aux.x + double(renorm2(a0, a1));
-        sm += aux.y;
-        n += A.ch_len[c];
-    }
-    if (A.lognorm) A.lognorm[ci] = sm + double(n - 1) * A.mx + log(a0 + a1) + ex * 0.6931471805599453;
-    double b0 = 1.0, b1 = 1.0;
-    for (int c = c1 - 1; c >= c0; --c) {
-        A.chOut[c] = make_double2(b0, b1);
-        const Mat2 P = A.chP[c];  // includes the transition INTO the chunk's first gene
-        const double n0 = fma(P.a01, b1, P.a00 * b0);
-        const double n1 = fma(P.a11, b1, P.a10 * b0);
-        b0 = n0;
-        b1 = n1;
-        (void)renorm2(b0, b1);
-    }
-}
-
-__global__ void __launch_bounds__(kThreads) f_chunk_marginals(const SeqArgs A) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= A.n_chunks) return;
-    const int g0 = A.ch_start[c], len = A.ch_len[c];
-    const double2 in = A.chIn[c];
-    double a0 = in.x, a1 = in.y;
-    for (int k = 0; k < len; ++k) {
-        double m;
-        const double2 e = emit_norm(A.state[g0 + k], m);
-        double n0 = a0, n1 = a1;
-        if (!(k == 0 && A.ch_first[c])) {
-            n0 = fma(a1, A.m10, a0 * A.m00);
-            n1 = fma(a1, A.m11, a0 * A.m01);
-        }
-        a0 = n0 * e.x;
-        a1 = n1 * e.y;
-        (void)renorm2(a0, a1);
-        A.alpha[g0 + k] = make_double2(a0, a1);
-    }
-    const double2 out = A.chOut[c];
-    double b0 = out.x, b1 = out.y;
-    for (int k = len - 1; k >= 0; --k) {
-        const double2 al = A.alpha[g0 + k];
-        const double x0 = al.x * b0, x1 = al.y * b1;
-        const double z = x0 + x1;
-        A.marg[2 * size_t(g0 + k)] = x0 / z;
-        A.marg[2 * size_t(g0 + k) + 1] = x1 / z;
-        if (k > 0) {  // beta_{t-1} = M' (D_t o beta_t); never crosses the chunk's first gene
-            double m;
-            const double2 e = emit_norm(A.state[g0 + k], m);
-            const double c0 = e.x * b0, c1 = e.y * b1;
-            b0 = fma(A.m01, c1, A.m00 * c0);
-            b1 = fma(A.m11, c1, A.m10 * c0);
-            (void)renorm2(b0, b1);
-        }
-    }
-}
-
-// =====================================================================================
-// V: max-plus.  delta_0 = s_0; delta_t[j] = max_i(delta_{t-1}[i] + trans[i][j]) + s_t[j], ties -> the
-// smaller i (CRFsuite updates on strict '<'); last label = first argmax; backtrack.
-// =====================================================================================
-__global__ void __launch_bounds__(kThreads) v_chunk_product(const SeqArgs A) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= A.n_chunks) return;
-    const int g0 = A.ch_start[c], len = A.ch_len[c];
-    // V[i][j]: best score from label i just before the chunk to label j at its current gene
-    double v00 = 0.0, v01 = 0.0, v10 = 0.0, v11 = 0.0;
-    for (int k = 0; k < len; ++k) {
-        const double2 s = A.state[g0 + k];
-        if (k == 0) {
-            if (A.ch_first[c]) {  // delta_0 = s_0 whatever the (virtual) previous label
-                v00 = s.x; v01 = s.y; v10 = s.x; v11 = s.y;
-            } else {
-                v00 = A.t00 + s.x; v01 = A.t01 + s.y; v10 = A.t10 + s.x; v11 = A.t11 + s.y;
-            }
-        } else {
-            const double n00 = fmax(v00 + A.t00, v01 + A.t10) + s.x;
-            const double n01 = fmax(v00 + A.t01, v01 + A.t11) + s.y;
-            const double n10 = fmax(v10 + A.t00, v11 + A.t10) + s.x;
-            const double n11 = fmax(v10 + A.t01, v11 + A.t11) + s.y;
-            v00 = n00; v01 = n01; v10 = n10; v11 = n11;
-        }
-    }
-    A.chP[c] = Mat2{v00, v01, v10, v11};
-}
-
-__global__ void __launch_bounds__(kThreads) v_contig_scan(const SeqArgs A) {
-    const int ci = blockIdx.x * kThreads + threadIdx.x;
-    if (ci >= A.n_contigs) return;
-    const int c0 = A.ct_chunk0[ci], c1 = A.ct_chunk0[ci + 1];
-    double d0 = 0.0, d1 = 0.0;  // virtual delta before the contig (ignored by a first chunk)
-    for (int c = c0; c < c1; ++c) {
-        A.chIn[c] = make_double2(d0, d1);
-        const Mat2 V = A.chP[c];
-        const double n0 = fmax(d0 + V.a00, d1 + V.a10);
-        const double n1 = fmax(d0 + V.a01, d1 + V.a11);
-        d0 = n0;
-        d1 = n1;
-    }
-    if (A.score) A.score[ci] = c0 == c1 ? 0.0 : fmax(d0, d1);
-}
-
-// replays a chunk from the delta entering it, leaves the two back-pointer bits of every gene in
-// y[] (bit0: best predecessor of label 0, bit1: of label 1) and the chunk's end->entry label map
-__global__ void __launch_bounds__(kThreads) v_chunk_backpointers(const SeqArgs A) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= A.n_chunks) return;
-    const int g0 = A.ch_start[c], len = A.ch_len[c];
-    const double2 in = A.chIn[c];
-    double d0 = in.x, d1 = in.y;
-    for (int k = 0; k < len; ++k) {
-        const double2 s = A.state[g0 + k];
-        int bp = 0;
-        if (k == 0 && A.ch_first[c]) {
-            d0 = s.x;
-            d1 = s.y;
-        } else {
-            const double a0 = d0 + A.t00, b0 = d1 + A.t10;  // into label 0
-            const double a1 = d0 + A.t01, b1 = d1 + A.t11;  // into label 1
-            const bool p0 = a0 < b0, p1 = a1 < b1;           // strict: ties keep predecessor 0
-            bp = (p0 ? 1 : 0) | (p1 ? 2 : 0);
-            d0 = (p0 ? b0 : a0) + s.x;
-            d1 = (p1 ? b1 : a1) + s.y;
-        }
-        A.y[g0 + k] = int8_t(bp);
-    }
-    // end label j -> label just before the chunk
-    for (int j = 0; j < 2; ++j) {
-        int lab = j;
-        for (int k = len - 1; k >= 0; --k) lab = (A.y[g0 + k] >> lab) & 1;
-        A.chMap[2 * c + j] = int8_t(lab);
-    }
-    // last chunk of a contig also fixes the end label: first argmax (strict '<' update from label 0)
-    A.chEnd[c] = int8_t(d0 < d1 ? 1 : 0);
-}
-
-__global__ void __launch_bounds__(kThreads) v_contig_backtrack(const SeqArgs A) {
-    const int ci = blockIdx.x * kThreads + threadIdx.x;
-    if (ci >= A.n_contigs) return;
-    const int c0 = A.ct_chunk0[ci], c1 = A.ct_chunk0[ci + 1];
-    if (c0 == c1) return;
-    int lab = A.chEnd[c1 - 1];
-    for (int c = c1 - 1; c >= c0; --c) {
-        const int entry = A.chMap[2 * c + lab];
-        A.chEnd[c] = int8_t(lab);
-        lab = entry;
-    }
-}
-
-__global__ void __launch_bounds__(kThreads) v_chunk_labels(const SeqArgs A) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= A.n_chunks) return;
-    const int g0 = A.ch_start[c], len = A.ch_len[c];
-    int lab = A.chEnd[c];
-    for (int k = len - 1; k >= 0; --k) {
-        const int bp = A.y[g0 + k];
-        A.y[g0 + k] = int8_t(lab);
-        lab = (bp >> lab) & 1;
-    }
+    const double2 cur = A.contigTmp[g1 - 1];
+    A.lognorm[c] = cur.x + cur.y + double(g1 - g0 - 1) * A.mx;
 }
 
 }  // namespace
 
 // ---- launchers ---------------------------------------------------------------------------
-static inline dim3 grid_for(int n) { return dim3((n + kThreads - 1) / kThreads); }
+static inline dim3 grid_for(int n, int per) { return dim3((n + per - 1) / per); }
 
 hipError_t launch_seq_state(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_genes,
                             double2 *state, hipStream_t stream) {
     if (n_genes <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seq_state_scores, grid_for(n_genes), dim3(kThreads), 0, stream, gene_ptr, attr_id, wtab01, n_genes,
-                       state);
+    hipLaunchKernelGGL(seq_state_scores, grid_for(n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_genes, state);
     return hipGetLastError();
 }
 
-hipError_t launch_seq_marginals(const SeqArgs &a, hipStream_t stream) {
+hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream) {
     if (a.n_contigs <= 0) return hipSuccess;
-    if (a.n_chunks > 0) hipLaunchKernelGGL(f_chunk_product, grid_for(a.n_chunks), dim3(kThreads), 0, stream, a);
-    hipLaunchKernelGGL(f_contig_scan, grid_for(a.n_contigs), dim3(kThreads), 0, stream, a);
-    if (a.n_chunks > 0) hipLaunchKernelGGL(f_chunk_marginals, grid_for(a.n_chunks), dim3(kThreads), 0, stream, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_seq_viterbi(const SeqArgs &a, hipStream_t stream) {
-    if (a.n_contigs <= 0) return hipSuccess;
-    if (a.n_chunks > 0) hipLaunchKernelGGL(v_chunk_product, grid_for(a.n_chunks), dim3(kThreads), 0, stream, a);
-    hipLaunchKernelGGL(v_contig_scan, grid_for(a.n_contigs), dim3(kThreads), 0, stream, a);
-    if (a.n_chunks > 0) {
-        hipLaunchKernelGGL(v_chunk_backpointers, grid_for(a.n_chunks), dim3(kThreads), 0, stream, a);
-        hipLaunchKernelGGL(v_contig_backtrack, grid_for(a.n_contigs), dim3(kThreads), 0, stream, a);
-        hipLaunchKernelGGL(v_chunk_labels, grid_for(a.n_chunks), dim3(kThreads), 0, stream, a);
+    if (a.n_genes > 0) {
+        const int nb = (a.n_genes + kBlockGenes - 1) / kBlockGenes;
+        hipLaunchKernelGGL(v_fold, dim3(nb), dim3(kT), 0, stream, a);
+        hipLaunchKernelGGL((scan_block_totals<VOp, false, VE>), dim3(1), dim3(kT), 0, stream, reinterpret_cast<VE *>(a.vBlock), nb);
+        hipLaunchKernelGGL(v_replay, dim3(nb), dim3(kT), 0, stream, a);
+        hipLaunchKernelGGL((scan_block_totals<MapOp, true, uint32_t>), dim3(1), dim3(kT), 0, stream, a.vBlockMap, nb);
+        hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, a);
     }
+    if (a.score) hipLaunchKernelGGL(v_scores, grid_for(a.n_contigs, kT), dim3(kT), 0, stream, a, d_contig_ptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_seq_marginals(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream) {
+    if (a.n_contigs <= 0) return hipSuccess;
+    if (a.n_genes > 0) {
+        const int nb = (a.n_genes + kBlockGenes - 1) / kBlockGenes;
+        hipLaunchKernelGGL(f_fold, dim3(nb), dim3(kT), 0, stream, a);
+        hipLaunchKernelGGL((scan_block_totals<FOp, false, FE>), dim3(1), dim3(kT), 0, stream, reinterpret_cast<FE *>(a.fBlock), nb);
+        hipLaunchKernelGGL(f_replay, dim3(nb), dim3(kT), 0, stream, a);
+        hipLaunchKernelGGL((scan_block_totals<FOp, true, FE>), dim3(1), dim3(kT), 0, stream, reinterpret_cast<FE *>(a.fBlockSuf), nb);
+        hipLaunchKernelGGL(f_marginals, dim3(nb), dim3(kT), 0, stream, a);
+    }
+    if (a.lognorm) hipLaunchKernelGGL(f_lognorm, grid_for(a.n_contigs, kT), dim3(kT), 0, stream, a, d_contig_ptr);
     return hipGetLastError();
 }
 
