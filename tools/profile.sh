@@ -9,13 +9,13 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
 B="python bench.py --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B --steps 20 --warmup 3 > $O/kt.log 2>&1
+timeout 180 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B --steps 20 --warmup 3 > $O/kt.log 2>&1
 S="--steps 3 --warmup 1 --kernel-iters 3"
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc1 -o pmc1 -- $B $S > $O/pmc1.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc2 -o pmc2 -- $B $S > $O/pmc2.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc3 -o pmc3 -- $B $S > $O/pmc3.log 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM -d $O/pmc4 -o pmc4 -- $B $S > $O/pmc4.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc5 -o pmc5 -- $B $S > $O/pmc5.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $O/pmc6 -o pmc6 -- $B $S > $O/pmc6.log 2>&1
+timeout 180 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc1 -o pmc1 -- $B $S > $O/pmc1.log 2>&1
+timeout 180 rocprofv3 --pmc FETCH_SIZE -d $O/pmc2 -o pmc2 -- $B $S > $O/pmc2.log 2>&1
+timeout 180 rocprofv3 --pmc WRITE_SIZE -d $O/pmc3 -o pmc3 -- $B $S > $O/pmc3.log 2>&1
+timeout 180 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM -d $O/pmc4 -o pmc4 -- $B $S > $O/pmc4.log 2>&1
+timeout 180 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc5 -o pmc5 -- $B $S > $O/pmc5.log 2>&1
+timeout 180 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $O/pmc6 -o pmc6 -- $B $S > $O/pmc6.log 2>&1
 python tools/prof_summary.py $O crf_ > $O/summary.txt 2>&1
 cat $O/summary.txt
