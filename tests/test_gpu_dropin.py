@@ -78,3 +78,56 @@ def test_predict_clusters_convenience():
 
     clusters = ClusterCRF.trained(GOLDEN).predict_clusters(_golden_genes())
     assert [c.id for c in clusters] == ["BGC0001866.1_cluster_1"] and len(clusters[0].genes) == 23
+
+
+def test_columnar_predict_cli_reproduces_golden_tables(tmp_path):
+    """python -m gecco_amd.predict on the reference's fixture inputs -> the reference's outputs."""
+    from gecco_amd import predict
+
+    rc = predict.main(["--genes", os.path.join(GOLDEN, "BGC0001866.genes.tsv"),
+                       "--features", os.path.join(GOLDEN, "BGC0001866.features.tsv"),
+                       "--model", GOLDEN, "-o", str(tmp_path)])
+    assert rc == 0
+    got = read_tsv(str(tmp_path / "BGC0001866.genes.tsv"))
+    ref = read_tsv(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))
+    assert [r["protein_id"] for r in got] == [r["protein_id"] for r in ref]
+    for a, b in zip(got, ref):
+        assert all(a[k] == b[k] for k in ("sequence_id", "start", "end", "strand"))
+        assert abs(float(a["average_p"]) - float(b["average_p"])) <= 1e-14
+        assert abs(float(a["max_p"]) - float(b["max_p"])) <= 1e-14
+    got = read_tsv(str(tmp_path / "BGC0001866.features.tsv"))
+    ref = read_tsv(os.path.join(GOLDEN, "BGC0001866.features.tsv"))
+    assert len(got) == len(ref) == 37
+    for a, b in zip(got, ref):
+        assert all(a[k] == b[k] for k in ("protein_id", "domain", "hmm", "i_evalue", "pvalue", "domain_start", "domain_end"))
+        assert abs(float(a["cluster_probability"]) - float(b["cluster_probability"])) <= 1e-14
+    got = read_tsv(str(tmp_path / "BGC0001866.clusters.tsv"))
+    ref = read_tsv(os.path.join(GOLDEN, "BGC0001866.clusters.tsv"))
+    assert len(got) == len(ref) == 1
+    a, b = got[0], ref[0]
+    assert all(a[k] == b[k] for k in ("sequence_id", "cluster_id", "start", "end"))
+    assert abs(float(a["average_p"]) - float(b["average_p"])) <= 1e-14 and abs(float(a["max_p"]) - float(b["max_p"])) <= 1e-14
+    assert set(a["proteins"].split(";")) == set(b["proteins"].split(";"))
+    assert set(a["domains"].split(";")) == set(b["domains"].split(";"))
+
+
+def test_multi_device_sharding_code_path(oracle_model):
+    """ClusterCRF.devices with more than one entry shards launches over a thread pool; exercised
+    here with the same physical device twice."""
+    from gecco_amd.crf import ClusterCRF
+    from gecco_amd.model import Domain, Gene, Protein, Source, Strand
+
+    rng = np.random.default_rng(8)
+    attrs = oracle_model["attrs"]
+    genes = []
+    for c in range(12):
+        for i in range(int(rng.integers(25, 90))):
+            doms = [Domain(attrs[a], 1, 9, "Pfam", 1e-10, 1e-12) for a in rng.integers(0, len(attrs), size=int(rng.integers(0, 3)))]
+            genes.append(Gene(Source(f"k{c:02d}"), 100 * i, 100 * i + 90, Strand.Coding, Protein(f"k{c:02d}_{i}", None, doms)))
+    one = ClusterCRF.trained(GOLDEN)
+    two = ClusterCRF.trained(GOLDEN)
+    two.devices = [0, 0]
+    two._BATCH_GENES = 150
+    a = [g.average_probability for g in one.predict_probabilities(list(genes))]
+    b = [g.average_probability for g in two.predict_probabilities(list(genes))]
+    assert a == b

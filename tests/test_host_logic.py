@@ -292,3 +292,27 @@ def test_tables_roundtrip(tmp_path):
     buf = io.StringIO()
     g.dump(buf)  # all-NaN probability columns are dropped (gecco/_base.py:138-146)
     assert buf.getvalue().split("\n")[0] == "sequence_id\tprotein_id\tstart\tend\tstrand"
+
+
+def test_domain_feature_mode(oracle_engine, trained, monkeypatch):
+    """feature_type='domain': one item per domain (one empty item for a gene without domains);
+    every domain gets its own probability, genes without domains their item's
+    (features.py:38-48,99-120)."""
+    import copy
+
+    crf = copy.copy(trained)
+    crf.feature_type = "domain"
+    genes = []
+    for i in range(30):
+        doms = [("PF00109", 1), ("PF02801", 40)] if i % 4 == 0 else ([("PF00106", 5)] if i % 4 == 1 else [])
+        genes.append(_gene("ctg", f"g{i:02d}", 10 * i, doms))
+    out = crf.predict_probabilities(genes)
+    n_items = sum(max(1, len(g.protein.domains)) for g in genes)
+    assert n_items == 8 * 2 + 8 * 1 + 14 * 1 + 0  # sanity on the construction
+    for g in out:
+        if g.protein.domains:
+            assert g._probability is None and all(d.probability is not None for d in g.protein.domains)
+        else:
+            assert g._probability is not None
+    two = [g for g in out if len(g.protein.domains) == 2]
+    assert any(g.protein.domains[0].probability != g.protein.domains[1].probability for g in two)
