@@ -8,7 +8,7 @@
 //
 // Design (two-label models, window <= 32: `crf_windowed_l2`):
 //   * slot space: genes of all scored contigs end to end, short contigs centre-padded to W
-//     slots (:216-227).  A 256-lane workgroup owns 256 consecutive slots as window starts;
+//     slots (:216-227).  A 512-lane workgroup owns 512 consecutive slots as window starts;
 //     its first W-1 lanes are a recomputed halo, so workgroups never exchange data.
 //   * stage 1 (HBM -> LDS, coalesced CSR reads + L2-resident weight gather): per slot the
 //     state scores s[y] = sum_a w[a][y] ([EXT] crf1dt_state_score): the tile's attribute
