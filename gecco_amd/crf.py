@@ -110,6 +110,41 @@ class _CRFSuiteModelView:
         return [self.classes_[i] for i in y.tolist()]
 
 
+def _annotate(gene: Any, gene_p: Optional[float], domain_p: Optional[List[float]],
+              weights: Dict[Tuple[str, str], float]) -> Any:
+    """New gene carrying the probabilities and the domains' cluster weights.
+
+    Equivalent to the reference's chain ``gene.with_probability(p)`` (``model.py:364-375``; or
+    per-domain ``with_probability`` in domain mode, ``features.py:109-117``) followed by
+    ``with_protein(protein.with_domains(d.with_cluster_weight(w) ...))`` (``crf/__init__.py:261-269``),
+    but for dataclass models (GECCO's and this package's) each object is rebuilt once instead of
+    twice; any other duck-typed model goes through its own ``with_*`` methods."""
+    import dataclasses
+
+    doms = gene.protein.domains
+    if dataclasses.is_dataclass(gene) and all(dataclasses.is_dataclass(d) for d in doms):
+        new_doms = []
+        for j, d in enumerate(doms):
+            changes: Dict[str, Any] = {"cluster_weight": weights.get((d.name, "1")), "qualifiers": d.qualifiers.copy()}
+            if gene_p is not None:
+                changes["probability"] = gene_p
+            elif domain_p is not None:
+                changes["probability"] = domain_p[j]
+            new_doms.append(dataclasses.replace(d, **changes))
+        protein = dataclasses.replace(gene.protein, domains=new_doms)
+        gchanges: Dict[str, Any] = {"protein": protein, "qualifiers": gene.qualifiers.copy()}
+        if gene_p is not None:
+            gchanges["_probability"] = gene_p
+        return dataclasses.replace(gene, **gchanges)
+    if gene_p is not None:
+        gene = gene.with_probability(gene_p)
+    elif domain_p is not None:
+        gene = gene.with_protein(gene.protein.with_domains(
+            [d.with_probability(p) for d, p in zip(gene.protein.domains, domain_p)]))
+    return gene.with_protein(gene.protein.with_domains(
+        d.with_cluster_weight(weights.get((d.name, "1"))) for d in gene.protein.domains))
+
+
 def _default_devices() -> List[int]:
     env = os.environ.get("GECCO_HIP_DEVICES", "").strip()
     if env:
@@ -259,36 +294,30 @@ class ClusterCRF(object):
             raise ValueError("the model has no label '1'")
         p_items = self._score(batch, W, step, label, pad, _progress, total)
 
-        # :258, features.py:74-120 -- annotate genes; skipped contigs pass through unchanged
+        # :258, features.py:74-120 (probabilities) and :261-269 (cluster weight = state feature
+        # weight of (domain, '1'), None if absent) -- new Gene/Protein/Domain objects; contigs that
+        # were skipped keep their probabilities and only get the weights.
+        weights = self.model.state_features_
         predicted: List[Any] = []
         for ci, contig in enumerate(contigs):
             if not scored[ci]:
-                predicted.extend(contig)
+                predicted.extend(_annotate(gene, None, None, weights) for gene in contig)
                 continue
             i0 = int(batch.item_ptr[ci])
             if self.feature_type == "protein":
                 for k, gene in enumerate(contig):
-                    predicted.append(gene.with_probability(float(p_items[i0 + k])))
+                    predicted.append(_annotate(gene, float(p_items[i0 + k]), None, weights))
             else:
                 k = i0
                 for gene in contig:
                     doms = gene.protein.domains
                     if doms:
-                        predicted.append(gene.with_protein(gene.protein.with_domains(
-                            [d.with_probability(float(p_items[k + j])) for j, d in enumerate(doms)])))
+                        predicted.append(_annotate(gene, None, [float(x) for x in p_items[k:k + len(doms)]], weights))
                         k += len(doms)
                     else:
-                        predicted.append(gene.with_probability(float(p_items[k])))
+                        predicted.append(_annotate(gene, float(p_items[k]), None, weights))
                         k += 1
-
-        # :261-269 -- cluster weight = state feature weight of (domain, '1'), None if absent
-        weights = self.model.state_features_
-        return [
-            gene.with_protein(gene.protein.with_domains(
-                domain.with_cluster_weight(weights.get((domain.name, "1"))) for domain in gene.protein.domains
-            ))
-            for gene in predicted
-        ]
+        return predicted
 
     def predict_clusters(self, genes: Iterable[Any], *, pad: bool = True, threshold: float = 0.8,
                          criterion: str = "gecco", n_cds: int = 3, edge_distance: int = 0, trim: bool = True,

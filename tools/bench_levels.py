@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Throughput of the windowed-marginals path at three levels:
+kernel only (resident inputs) / one-shot C ABI with host buffers (H2D + kernel + D2H) /
+Python object API (ClusterCRF.predict_probabilities on Gene objects, incl. host packing).
+Run on the GPU box; prints one JSON object."""
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from gecco_amd import _native as nat, synth  # noqa: E402
+from gecco_amd.crf import ClusterCRF  # noqa: E402
+from gecco_amd.model import Domain, Gene, Protein, Source, Strand  # noqa: E402
+
+
+def main():
+    out = {}
+    wl = synth.workload("C3")
+    n = int(wl["contig_ptr"][-1])
+    model = nat.Model.from_tables(wl["w"], wl["trans"])
+    dev = torch.device("cuda", 0)
+    plan = nat.Plan(model, wl["contig_ptr"], 20, 1, True, device=0)
+    gp = torch.from_numpy(wl["gene_ptr"]).to(dev)
+    at = torch.from_numpy(wl["attr_id"]).to(dev)
+    p = torch.zeros(n, dtype=torch.float64, device=dev)
+    ms = plan.time_windowed(gp.data_ptr(), at.data_ptr(), p.data_ptr(), 1, 0, warmup=3, iters=20)
+    out["kernel_only"] = {"genes": n, "ms": ms, "genes_per_s": n / ms * 1e3}
+    # one-shot ABI: plan build + H2D + kernel + D2H, host numpy buffers
+    model.windowed_marginals(wl["contig_ptr"], wl["gene_ptr"], wl["attr_id"], 20)  # warm
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        model.windowed_marginals(wl["contig_ptr"], wl["gene_ptr"], wl["attr_id"], 20)
+    dt = (time.perf_counter() - t0) / reps
+    out["one_shot_host_buffers"] = {"genes": n, "ms": dt * 1e3, "genes_per_s": n / dt,
+                                    "note": "plan build + hipMalloc + H2D + kernel + D2H per call"}
+    # object API on the real model: 500 contigs x 200 genes of Gene objects
+    golden = os.path.join(ROOT, "tests", "golden")
+    crf = ClusterCRF.trained(golden)
+    attrs = crf.model.attributes_
+    rng = np.random.default_rng(0)
+    genes = []
+    for c in range(500):
+        src = Source(f"contig_{c:04d}")
+        for i in range(200):
+            k = int(rng.integers(0, 4))
+            doms = [Domain(attrs[a], 10 * j + 1, 10 * j + 9, "Pfam", 1e-10, 1e-12) for j, a in enumerate(rng.integers(0, len(attrs), size=k))]
+            genes.append(Gene(src, 1000 * i, 1000 * i + 900, Strand.Coding, Protein(f"c{c:04d}_{i}", None, doms)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        crf.predict_probabilities(genes[:2000])  # warm
+        t0 = time.perf_counter()
+        crf.predict_probabilities(genes)
+        dt = time.perf_counter() - t0
+    out["python_object_api"] = {"genes": len(genes), "ms": dt * 1e3, "genes_per_s": len(genes) / dt,
+                                "note": "sort + pack Gene objects + one-shot ABI + new Gene/Domain objects"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
