@@ -14,7 +14,7 @@
 //     state scores s[y] = sum_a w[a][y] ([EXT] crf1dt_state_score): the tile's attribute
 //     range is read flat and coalesced, weight pairs are gathered and staged in LDS, then
 //     every slot sums its run in CSR order.  Scores are reduced to e = exp(s - max(s)) and
-//     parked in LDS pre-multiplied with the transition constants (24 B/slot).  A per-position scale factor
+//     parked in LDS pre-multiplied with the transition constant (16 B/slot).  A per-position scale factor
 //     cancels in every marginal, so e (and exp(trans - max)) replace CRFsuite's raw exps;
 //     this bounds the DP vectors in (0, 2^k] and removes CRFsuite's per-step 1/sum
 //     division.  Renormalisation by an exact power of two happens only at the steps the
@@ -66,8 +66,7 @@ constexpr int kGatherUnroll = 8;  // attribute loads in flight per slot before t
 
 template <int WMAX, int NT>
 struct WinSmem {
-    f64x2 fg[NT + WMAX - 1];        // per slot: (mu01*e1, mu11*e1)
-    double e0[NT + WMAX - 1];       // per slot: e0         (e = exp(s - max s), "other" first)
+    f64x2 ef[NT + WMAX - 1];        // per slot: (e0, f = mu01*e1)   with e = exp(s - max s), "other" first
     f64x2 carry[NT / 64][WMAX];     // running best leaving lane 63 of each wave, per step
     int32_t cslot[NT + WMAX + 1];   // slot offsets of the contigs this tile overlaps
     int32_t cgene[NT + WMAX];
@@ -159,6 +158,10 @@ __device__ __forceinline__ void state_scores_l2_pair(const int32_t *__restrict__
 //   alpha~ = alpha * diag(1, kappa), beta~ = diag(1, 1/kappa) * beta, transitions divided by
 //   m00 and conjugated so that their first column is (1, 1):  M~ = [[1, mu01], [1, mu11]].
 //   forward : t = a0 + a1;  a0' = t * e0;  a1' = a0 * f + a1 * g        (f = mu01 e1, g = mu11 e1)
+//   Only (e0, f) is kept per slot (16 B, one ds_read_b128): g = rho * f with rho = mu11/mu01, so
+//     a1' = f * (a0 + rho a1)         and        u = f b1;  b0' = c + u;  b1' = c + rho u.
+//   That is 4 + 4 VALU ops per step instead of 4 + 3, but a third less LDS traffic -- the DP is
+//   LDS-read bound as much as VALU bound (tools/ubench/dp_variants.hip: 38.7 -> 33.2 us).
 //   backward: c = e0 * b0;  b0' = c + f * b1;  b1' = c + g * b1
 //   candidate for slot s+k: x = a1 * b1 (label), y = a0 * b0 (other); all scale factors cancel
 //   in x / (x + y).
@@ -220,15 +223,13 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 4 : 3)) crf_windowed_l2(cons
             const double d = s01 - s00;
             const double e = exp(-fabs(d));
             const double e1 = d > 0.0 ? 1.0 : e;
-            sm.e0[tid] = d > 0.0 ? e : 1.0;
-            sm.fg[tid] = f64x2{P.mu01 * e1, P.mu11 * e1};
+            sm.ef[tid] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
         }
         if (has1) {
             const double d = s11 - s10;
             const double e = exp(-fabs(d));
             const double e1 = d > 0.0 ? 1.0 : e;
-            sm.e0[NT + tid] = d > 0.0 ? e : 1.0;
-            sm.fg[NT + tid] = f64x2{P.mu01 * e1, P.mu11 * e1};
+            sm.ef[NT + tid] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
         }
     }
     __syncthreads();
@@ -238,18 +239,22 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 4 : 3)) crf_windowed_l2(cons
 
     // ---- stage 2a: forward recursion, all W alpha pairs stay in registers
     double A0[WMAX], A1[WMAX];
-    double a0 = sm.e0[tid];
-    double a1 = sm.fg[tid].y * P.kappa_over_mu11;  // kappa * e1
+    const double rho = P.rho;
+    double a0, a1;
+    {
+        const f64x2 ef = sm.ef[tid];
+        a0 = ef.x;
+        a1 = ef.y * P.kappa_over_mu01;  // kappa * e1
+    }
     A0[0] = a0;
     A1[0] = a1;
 #pragma unroll
     for (int k = 1; k < WMAX; ++k) {
         if (EXACT || k < W) {
-            const double e0 = sm.e0[tid + k];
-            const f64x2 fg = sm.fg[tid + k];
+            const f64x2 ef = sm.ef[tid + k];
             const double t = a0 + a1;
-            const double n1 = fma(a1, fg.y, a0 * fg.x);
-            a0 = t * e0;
+            const double n1 = fma(a1, rho, a0) * ef.y;
+            a0 = t * ef.x;
             a1 = n1;
             if (RESCALE && ((rmask >> k) & 1u)) rescale_pair(a0, a1);
             A0[k] = a0;
@@ -280,11 +285,10 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 4 : 3)) crf_windowed_l2(cons
             Rx = take ? x : Rx;
             Ry = take ? y : Ry;
             if (k > 0) {
-                const double e0 = sm.e0[tid + k];
-                const f64x2 fg = sm.fg[tid + k];
-                const double c = e0 * b0;
-                b0 = fma(fg.x, b1, c);
-                b1 = fma(fg.y, b1, c);
+                const f64x2 ef = sm.ef[tid + k];
+                const double c = ef.x * b0, u = ef.y * b1;
+                b0 = c + u;
+                b1 = fma(u, rho, c);
                 if (RESCALE && ((rmask >> k) & 1u)) rescale_pair(b0, b1);
             }
         }

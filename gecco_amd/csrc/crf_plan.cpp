@@ -282,9 +282,9 @@ int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_
         const int o = 1 - label;
         auto T = [&](int i, int j) { return m.trans[size_t(i) * 2 + j]; };
         a.mu01 = std::exp(T(o, label) + T(label, o) - 2.0 * T(o, o));
-        a.mu11 = std::exp(T(label, label) - T(o, o));
+        a.rho = std::exp(T(label, label) + T(o, o) - T(o, label) - T(label, o));  // mu11 / mu01
         const double kappa = std::exp(T(label, o) - T(o, o));
-        a.kappa_over_mu11 = kappa / a.mu11;
+        a.kappa_over_mu01 = std::exp(T(o, o) - T(o, label));                       // kappa / mu01
         a.inv_kappa = 1.0 / kappa;
     }
     {
