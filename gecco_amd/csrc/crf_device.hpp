@@ -32,7 +32,7 @@ struct WinArgs {
 };
 
 // Geometry of the fast L==2 kernel.
-constexpr int kWinThreads = 512;  // lanes (= window starts) per workgroup; 256: +4 % time (7.4 % halo), 1024: +18 % (one workgroup per CU)
+constexpr int kWinThreads = 256;  // lanes (= window starts) per workgroup: 4 waves, 5 workgroups per CU at <= 96 VGPRs
 constexpr int kWinMaxW = 32;      // largest window the register-resident kernel handles
 
 // ---- whole-contig kernels (crf_sequence.hip) ------------------------------------------------

@@ -8,7 +8,7 @@
 //
 // Design (two-label models, window <= 32: `crf_windowed_l2`):
 //   * slot space: genes of all scored contigs end to end, short contigs centre-padded to W
-//     slots (:216-227).  A 512-lane workgroup owns 512 consecutive slots as window starts;
+//     slots (:216-227).  A 256-lane workgroup owns 256 consecutive slots as window starts;
 //     its first W-1 lanes are a recomputed halo, so workgroups never exchange data.
 //   * stage 1 (HBM -> LDS, coalesced CSR reads + L2-resident weight gather): per slot the
 //     state scores s[y] = sum_a w[a][y] ([EXT] crf1dt_state_score): the tile's attribute
@@ -166,7 +166,7 @@ __device__ __forceinline__ void state_scores_l2_pair(const int32_t *__restrict__
 //   candidate for slot s+k: x = a1 * b1 (label), y = a0 * b0 (other); all scale factors cancel
 //   in x / (x + y).
 template <int WMAX, bool EXACT, bool RESCALE, int NT>
-__global__ void __launch_bounds__(NT, (WMAX <= 20 ? 4 : 3)) crf_windowed_l2(const WinArgs P) {
+__global__ void __launch_bounds__(NT, (WMAX <= 20 ? 5 : 3)) crf_windowed_l2(const WinArgs P) {
     using Smem = WinSmem<WMAX, NT>;
     __shared__ Smem sm;
     const int W = EXACT ? WMAX : P.W;
