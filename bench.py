@@ -30,7 +30,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C5"])
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C5", "Cinf"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=20)
     args = ap.parse_args()
@@ -187,6 +187,18 @@ def main() -> None:
             "sample": f"first {nc} contigs ({ng} genes) of the same workload: windowed marginals {dt_win:.2f} s"
                       + (f" + Viterbi {dt_vit:.2f} s" if have_viterbi else "") + ", C oracle driven window by window like the reference",
         }
+        # SURVEY.md 8d also asks for the same restatement on all host cores (contigs over threads)
+        ncpu = os.cpu_count() or 1
+        best = None
+        for _ in range(2):  # first threaded pass wakes the cores up
+            t0 = time.perf_counter()
+            orc.windowed_marginals_mt(wl["w"], wl["trans"], cp, wl["gene_ptr"][: ng + 1], wl["attr_id"], W, STEP, LABEL, True, threads=ncpu)
+            if have_viterbi:
+                orc.viterbi_mt(wl["w"], wl["trans"], cp, wl["gene_ptr"][: ng + 1], wl["attr_id"], threads=ncpu)
+            d = time.perf_counter() - t0
+            best = d if best is None else min(best, d)
+        out["cpu_baseline_all_cores"] = {"value": ng / best, "unit": "genes/s", "cores": ncpu, "kind": "port",
+                                         "sample": "same sample, contigs spread over all host threads, best of 2"}
         out["parity"] = {
             "max_abs_dp_vs_oracle": float(np.abs(got - p_ref).max()),
             "cluster_call_mismatches": int(((got > 0.8) != (p_ref > 0.8)).sum()),

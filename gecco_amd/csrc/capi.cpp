@@ -304,7 +304,7 @@ GECCO_API int gecco_crf_marginals_full(const gecco_crf_model *m, int32_t device,
     int rc = os.prepare(m, device, contig_ptr, n_contigs, gene_ptr, attr_id);
     if (rc) return rc;
     if (n_contigs == 0) return GECCO_CRF_OK;
-    const size_t n = size_t(os.n), L = 2;
+    const size_t n = size_t(os.n), L = size_t(m->m.L);
     DevBuf<double> d_m, d_ln;
     if ((rc = d_m.alloc(n * L, "hipMalloc marginals"))) return rc;
     if ((rc = d_ln.alloc(size_t(n_contigs), "hipMalloc lognorm"))) return rc;

@@ -77,6 +77,37 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const int32_t
                           int n_cds, int edge_distance, int trim, int32_t *d_seg, int max_seg, int32_t *d_work,
                           int32_t *d_total, hipStream_t stream);
 
+// ---- any number of labels (crf_general.hip) -------------------------------------------------
+constexpr int kGenMaxL = 32;  // labels: a group of next-pow2(L) lanes must fit in half a wave
+constexpr int kGenMaxW = 48;  // window length: alpha-hat of a whole window lives in LDS (<= 3 KB per step)
+struct GenArgs {
+    const int32_t *gene_ptr, *attr_id;
+    const double *wtab;       // [A*L] state weights
+    const double *exp_trans;  // [L*L] exp(trans)
+    const double *trans;      // [L*L] raw transition weights (Viterbi)
+    const int32_t *contig_ptr;
+    int32_t L, n_genes, n_contigs;
+    // per-gene workspace
+    double *state;  // [n*L] raw state scores            (Viterbi)
+    double *E;      // [n*L] exp(state - max_y state)    (marginals)
+    double *smax;   // [n]   max_y state
+    double *alpha;  // [n*L] scaled forward vectors
+    double *scale;  // [n]
+    uint8_t *back;  // [n*L] Viterbi back-pointers
+    // outputs
+    double *marg, *lognorm, *score;
+    int8_t *y;
+    // windowed path: slot space of the plan
+    const int32_t *c_slot, *c_gene, *c_n;
+    const uint64_t *start_bits;
+    double *p_out;
+    int32_t K, S, W, label;
+};
+hipError_t launch_gen_state(const GenArgs &a, hipStream_t stream);
+hipError_t launch_gen_windowed(const GenArgs &a, hipStream_t stream);   // p_out must be zeroed first
+hipError_t launch_gen_marginals(const GenArgs &a, hipStream_t stream);
+hipError_t launch_gen_viterbi(const GenArgs &a, hipStream_t stream);
+
 const char *windowed_kernel_name(int W, int L, bool fast);
 // tile_out = output slots per workgroup for the kernel that (W, L) dispatches to.
 int windowed_tile_out(int W, int L);

@@ -1,0 +1,350 @@
+// Any number of labels (1 <= L <= 32): rows S, A/B, P, W, F and V of SURVEY.md §8a for CRFsuite
+// models other than GECCO's 2-label one.  GECCO's own model never comes
+// here; `GECCO_CRF_FORCE_GENERAL=1` routes 2-label models through these kernels so the tests can
+// cross-check the specialised kernels on the device.
+//
+// Layout: LP = L rounded up to a power of two; LP consecutive lanes ("a group", never straddling
+// a wave) own one window or one contig, lane j holds component j of the alpha / beta / delta
+// vector.  A step is a vector x (L x L) product: the previous vector goes through one LDS slot
+// per lane and comes back as L broadcast reads; the lane's column (forward) and row (backward)
+// of the transition matrix stay in registers.  LDS traffic of one wave is in order and groups
+// live inside a wave, so no barrier is needed and groups may run different trip counts.
+//
+// Arithmetic follows [EXT] CRFsuite crf1d_context.c in its own order (alpha: sum over the
+// source label in index order, then * exp(state), then 1/sum scaling; beta: row . (beta o exp(state))
+// then * scale; marginal = alpha * beta / scale; Viterbi: strict `<` update, first arg max), with
+// one deliberate difference: exp(state - max_y state) instead of exp(state), which cancels in
+// every marginal and is added back to the log-partition.
+#include "crf_device.hpp"
+
+#include <cfloat>
+
+namespace gecco {
+namespace {
+
+constexpr int kGT = 256;  // lanes per workgroup
+
+template <int LP>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LP);
+    return v;
+}
+template <int LP>
+__device__ __forceinline__ double group_max(double v) {
+#pragma unroll
+    for (int o = LP / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, LP));
+    return v;
+}
+
+// ---- row S: state scores of every gene (CSR order, bit-identical to sequential addition) ----
+// state[g][y] = sum_a w[a][y]; E[g][y] = exp(state - max_y); smax[g] = max_y state.
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_state(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
+                                                const double *__restrict__ wtab, int L, int n_genes,
+                                                double *__restrict__ state, double *__restrict__ E,
+                                                double *__restrict__ smax) {
+    const int j = threadIdx.x & (LP - 1);
+    const long long g = (static_cast<long long>(blockIdx.x) * kGT + threadIdx.x) / LP;
+    if (g >= n_genes) return;
+    const int lo = gene_ptr[g], hi = gene_ptr[g + 1];
+    const int jj = j < L ? j : 0;
+    double acc = 0.0;
+    for (int a = lo; a < hi; ++a) acc += wtab[static_cast<size_t>(attr_id[a]) * L + jj];
+    const double m = group_max<LP>(j < L ? acc : -DBL_MAX);
+    if (j < L) {
+        if (state) state[static_cast<size_t>(g) * L + j] = acc;
+        if (E) E[static_cast<size_t>(g) * L + j] = exp(acc - m);
+    }
+    if (j == 0 && smax) smax[g] = m;
+}
+
+// ---- rows A/B, P, W: one group per window start ------------------------------------------------
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_windowed(GenArgs a) {
+    extern __shared__ double lds[];
+    constexpr int G = kGT / LP;
+    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
+    const int W = a.W, L = a.L;
+    double *al = lds + static_cast<size_t>(grp) * W * LP;        // alpha-hat of every step
+    double *sc = lds + static_cast<size_t>(G) * W * LP + grp * W; // scale factors
+    double *vec = lds + static_cast<size_t>(G) * W * (LP + 1) + grp * LP;
+    const long long q = static_cast<long long>(blockIdx.x) * G + grp;
+    bool active = q < a.S && ((a.start_bits[q >> 6] >> (q & 63)) & 1);
+    int g0 = 0, n = 0, off = 0;
+    if (active) {
+        int lo = 0, hi = a.K - 1;  // scored contig owning slot q
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.c_slot[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        const int s0 = a.c_slot[lo], np = a.c_slot[lo + 1] - s0;
+        n = a.c_n[lo];
+        g0 = a.c_gene[lo];
+        off = int(q - s0) - ((np - n) >> 1);  // gene index (within the contig) of window position 0
+    }
+    const bool lane_on = active && j < L;
+    double mcol[LP], mrow[LP];
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        const bool ok = i < L && j < L;
+        mcol[i] = ok ? a.exp_trans[i * L + j] : 0.0;
+        mrow[i] = ok ? a.exp_trans[j * L + i] : 0.0;
+    }
+    // emission of window position t: padding items have no attributes -> state 0 -> exp(0-0) = 1
+    auto emis = [&](int t) -> double {
+        if (!lane_on) return 0.0;
+        const int gi = off + t;
+        return (gi >= 0 && gi < n) ? a.E[static_cast<size_t>(g0 + gi) * L + j] : 1.0;
+    };
+    // forward
+    double e = emis(0), v = 0.0, c = 1.0;
+    for (int t = 0; t < W; ++t) {
+        const double e_next = t + 1 < W ? emis(t + 1) : 0.0;
+        if (t == 0) {
+            v = e;
+        } else {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < LP; ++i) acc = fma(al[(t - 1) * LP + i], mcol[i], acc);
+            v = acc * e;
+        }
+        const double s = group_sum<LP>(v);
+        c = s != 0.0 ? 1.0 / s : 1.0;
+        v *= c;
+        al[t * LP + j] = v;
+        if (j == 0) sc[t] = c;
+        e = e_next;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // backward + marginal of `label` + per-gene maximum over windows
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(a.p_out);
+    double b = c;  // beta_{W-1} = scale_{W-1}
+    for (int t = W - 1; t >= 0; --t) {
+        const double ct = sc[t];
+        if (t < W - 1) {
+            vec[j] = b * emis(t + 1);
+            __builtin_amdgcn_wave_barrier();
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < LP; ++i) acc = fma(mrow[i], vec[i], acc);
+            b = acc * ct;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int gi = off + t;
+        if (lane_on && j == a.label && gi >= 0 && gi < n) {
+            const double pr = al[t * LP + j] * b / ct;
+            atomicMax(out + g0 + gi, static_cast<unsigned long long>(__double_as_longlong(pr)));
+        }
+    }
+}
+
+// ---- row F: whole-contig marginals, one group per contig, CRFsuite's own sequential recursion ----
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_marginals_seq(GenArgs a) {
+    __shared__ double vecs[kGT];
+    constexpr int G = kGT / LP;
+    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
+    double *vec = vecs + grp * LP;
+    const long long ci = static_cast<long long>(blockIdx.x) * G + grp;
+    if (ci >= a.n_contigs) return;
+    const int L = a.L;
+    const int g0 = a.contig_ptr[ci], T = a.contig_ptr[ci + 1] - g0;
+    if (T <= 0) {
+        if (j == 0 && a.lognorm) a.lognorm[ci] = 0.0;
+        return;
+    }
+    const bool on = j < L;
+    const int jj = on ? j : 0;
+    double mcol[LP], mrow[LP];
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        const bool ok = i < L && on;
+        mcol[i] = ok ? a.exp_trans[i * L + j] : 0.0;
+        mrow[i] = ok ? a.exp_trans[j * L + i] : 0.0;
+    }
+    const double *E = a.E + static_cast<size_t>(g0) * L;
+    double *alpha = a.alpha + static_cast<size_t>(g0) * L;
+    double *scale = a.scale + g0;
+    double lognorm = 0.0, v = 0.0, c = 1.0;
+    double e = on ? E[jj] : 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double e_next = (t + 1 < T && on) ? E[static_cast<size_t>(t + 1) * L + jj] : 0.0;
+        const double sm = a.smax[g0 + t];
+        if (t == 0) {
+            v = e;
+        } else {
+            vec[j] = v;
+            __builtin_amdgcn_wave_barrier();
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < LP; ++i) acc = fma(vec[i], mcol[i], acc);
+            __builtin_amdgcn_wave_barrier();
+            v = acc * e;
+        }
+        const double s = group_sum<LP>(v);
+        c = s != 0.0 ? 1.0 / s : 1.0;
+        v *= c;
+        if (on) alpha[static_cast<size_t>(t) * L + j] = v;
+        if (j == 0) scale[t] = c;
+        lognorm += sm - log(c);
+        e = e_next;
+    }
+    if (j == 0 && a.lognorm) a.lognorm[ci] = lognorm;
+    // backward; alpha/scale of step t were written by this very lane / this group's lane 0
+    double *marg = a.marg + static_cast<size_t>(g0) * L;
+    double b = c;
+    if (on) marg[static_cast<size_t>(T - 1) * L + j] = v * b / c;
+    double al_p = (T >= 2 && on) ? alpha[static_cast<size_t>(T - 2) * L + j] : 0.0;
+    double c_p = T >= 2 ? __shfl(j == 0 ? scale[T - 2] : 0.0, 0, LP) : 1.0;
+    double e1 = (T >= 2 && on) ? E[static_cast<size_t>(T - 1) * L + jj] : 0.0;
+    for (int t = T - 2; t >= 0; --t) {
+        const double al_t = al_p, ct = c_p, et1 = e1;
+        if (t > 0) {  // prefetch step t-1 while step t computes
+            al_p = on ? alpha[static_cast<size_t>(t - 1) * L + j] : 0.0;
+            c_p = __shfl(j == 0 ? scale[t - 1] : 0.0, 0, LP);
+            e1 = on ? E[static_cast<size_t>(t) * L + jj] : 0.0;
+        }
+        vec[j] = b * et1;
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < LP; ++i) acc = fma(mrow[i], vec[i], acc);
+        __builtin_amdgcn_wave_barrier();
+        b = acc * ct;
+        if (on) marg[static_cast<size_t>(t) * L + j] = al_t * b / ct;
+    }
+}
+
+// ---- row V: whole-contig Viterbi, one group per contig ------------------------------------------
+constexpr int kBackRows = 32;  // back-pointer rows walked from LDS per global round trip
+
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_viterbi_seq(GenArgs a) {
+    __shared__ double vecs[kGT];
+    __shared__ uint8_t rows[kGT * kBackRows];
+    constexpr int G = kGT / LP;
+    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
+    double *vec = vecs + grp * LP;
+    uint8_t *row = rows + grp * LP * kBackRows;
+    const long long ci = static_cast<long long>(blockIdx.x) * G + grp;
+    if (ci >= a.n_contigs) return;
+    const int L = a.L;
+    const int g0 = a.contig_ptr[ci], T = a.contig_ptr[ci + 1] - g0;
+    if (T <= 0) {
+        if (j == 0 && a.score) a.score[ci] = 0.0;
+        return;
+    }
+    const bool on = j < L;
+    const int jj = on ? j : 0;
+    double tcol[LP];
+#pragma unroll
+    for (int i = 0; i < LP; ++i) tcol[i] = (i < L && on) ? a.trans[i * L + j] : 0.0;
+    const double *st = a.state + static_cast<size_t>(g0) * L;
+    uint8_t *back = a.back + static_cast<size_t>(g0) * L;
+    double d = on ? st[jj] : -DBL_MAX;
+    double s_next = (T > 1 && on) ? st[static_cast<size_t>(L) + jj] : 0.0;
+    for (int t = 1; t < T; ++t) {
+        const double s_t = s_next;
+        if (t + 1 < T) s_next = on ? st[static_cast<size_t>(t + 1) * L + jj] : 0.0;
+        vec[j] = d;
+        __builtin_amdgcn_wave_barrier();
+        double best = -DBL_MAX;
+        int arg = -1;
+#pragma unroll
+        for (int i = 0; i < LP; ++i) {
+            if (i < L) {
+                const double s = vec[i] + tcol[i];
+                if (best < s) {
+                    best = s;
+                    arg = i;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (on) back[static_cast<size_t>(t) * L + j] = static_cast<uint8_t>(arg < 0 ? 0 : arg);
+        d = best + s_t;
+    }
+    // end label = first arg max; back-tracking by lane 0, rows staged through LDS in chunks
+    vec[j] = d;
+    __builtin_amdgcn_wave_barrier();
+    int y = 0;
+    {
+        double best = -DBL_MAX;
+        for (int i = 0; i < L; ++i)
+            if (best < vec[i]) {
+                best = vec[i];
+                y = i;
+            }
+        if (j == 0 && a.score) a.score[ci] = best;
+    }
+    int8_t *yout = a.y + g0;
+    if (j == 0) yout[T - 1] = static_cast<int8_t>(y);
+    __threadfence();
+    for (int hi = T - 1; hi >= 1; hi -= kBackRows) {
+        const int lo = hi - kBackRows + 1 > 1 ? hi - kBackRows + 1 : 1;  // rows lo..hi
+        const int nb = (hi - lo + 1) * L;
+        const uint8_t *src = back + static_cast<size_t>(lo) * L;
+        for (int k = j; k < nb; k += LP) row[k] = src[k];
+        __builtin_amdgcn_wave_barrier();
+        if (j == 0) {
+            for (int t = hi; t >= lo; --t) {
+                y = row[(t - lo) * L + y];
+                yout[t - 1] = static_cast<int8_t>(y);
+            }
+        }
+        y = __shfl(y, 0, LP);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int LP>
+hipError_t launch_lp(int what, const GenArgs &a, hipStream_t stream) {
+    constexpr int G = kGT / LP;
+    auto blocks = [](long long items, int per) { return dim3(unsigned((items + per - 1) / per)); };
+    switch (what) {
+    case 0:  // state scores
+        if (a.n_genes > 0)
+            hipLaunchKernelGGL(gl_state<LP>, blocks(a.n_genes, G), dim3(kGT), 0, stream, a.gene_ptr, a.attr_id, a.wtab, a.L,
+                               a.n_genes, a.state, a.E, a.smax);
+        break;
+    case 1: {
+        const size_t lds = (size_t(G) * a.W * (LP + 1) + kGT) * sizeof(double);
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gl_windowed<LP>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            if (e != hipSuccess) return e;
+        }
+        if (a.S > 0) hipLaunchKernelGGL(gl_windowed<LP>, blocks(a.S, G), dim3(kGT), lds, stream, a);
+        break;
+    }
+    case 2:
+        if (a.n_contigs > 0) hipLaunchKernelGGL(gl_marginals_seq<LP>, blocks(a.n_contigs, G), dim3(kGT), 0, stream, a);
+        break;
+    case 3:
+        if (a.n_contigs > 0) hipLaunchKernelGGL(gl_viterbi_seq<LP>, blocks(a.n_contigs, G), dim3(kGT), 0, stream, a);
+        break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_any(int what, const GenArgs &a, hipStream_t stream) {
+    if (a.L <= 0 || a.L > kGenMaxL) return hipErrorNotSupported;
+    if (a.L <= 2) return launch_lp<2>(what, a, stream);
+    if (a.L <= 4) return launch_lp<4>(what, a, stream);
+    if (a.L <= 8) return launch_lp<8>(what, a, stream);
+    if (a.L <= 16) return launch_lp<16>(what, a, stream);
+    return launch_lp<32>(what, a, stream);
+}
+
+}  // namespace
+
+hipError_t launch_gen_state(const GenArgs &a, hipStream_t stream) { return launch_any(0, a, stream); }
+hipError_t launch_gen_windowed(const GenArgs &a, hipStream_t stream) {
+    if (a.W > kGenMaxW) return hipErrorNotSupported;
+    return launch_any(1, a, stream);
+}
+hipError_t launch_gen_marginals(const GenArgs &a, hipStream_t stream) { return launch_any(2, a, stream); }
+hipError_t launch_gen_viterbi(const GenArgs &a, hipStream_t stream) { return launch_any(3, a, stream); }
+
+}  // namespace gecco

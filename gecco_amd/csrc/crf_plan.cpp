@@ -38,6 +38,7 @@ Model::~Model() {
             (void)hipFree(t->wtab2[0]);
             (void)hipFree(t->wtab2[1]);
             (void)hipFree(t->exp_trans);
+            (void)hipFree(t->trans);
             (void)hipSetDevice(prev);
         }
         delete t;
@@ -60,6 +61,7 @@ int get_device_tables(const Model &m, int device, const DeviceTables **out) {
     std::vector<double> et(L * L);
     for (size_t i = 0; i < L * L; ++i) et[i] = std::exp(m.trans[i]);
     if ((rc = upload(&t->exp_trans, et.data(), L * L, "upload transitions"))) return rc;
+    if ((rc = upload(&t->trans, m.trans.data(), L * L, "upload transitions"))) return rc;
     if (m.L == 2) {
         std::vector<double2> w2(A ? A : 1);
         for (int label = 0; label < 2; ++label) {
@@ -86,6 +88,7 @@ Plan::~Plan() {
             (void)hipFree(d_seq_flags);
             (void)hipFree(d_seq_ws);
             (void)hipFree(d_win_scratch);
+            (void)hipFree(d_gen_ws);
             (void)hipSetDevice(prev);
         }
     }
@@ -182,17 +185,21 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     p.S = int32_t(S);
     p.c_slot.push_back(p.S);
 
-    if (m.L != 2) {
-        set_error("only 2-label models are supported (GECCO's labels are '0' and '1')");
+    if (m.L < 1 || m.L > kGenMaxL) {
+        set_error("models with more than 32 labels are not supported");
         return GECCO_CRF_EUNSUPPORTED;
     }
-    p.fast_ok = (W <= kWinMaxW && rescale_mask_for(m, W, &p.rescale_mask));
+    {
+        const char *env = std::getenv("GECCO_CRF_FORCE_GENERAL");
+        p.general = m.L != 2 || (env && env[0] == '1');
+    }
+    p.fast_ok = (!p.general && W <= kWinMaxW && rescale_mask_for(m, W, &p.rescale_mask));
     {
         const char *env = std::getenv("GECCO_CRF_FORCE_GENERIC");
         p.force_generic = env && env[0] == '1';
     }
     if (p.force_generic) p.fast_ok = false;
-    p.kernel_name = windowed_kernel_name(W, m.L, p.fast_ok);
+    p.kernel_name = p.general ? "gl_windowed" : windowed_kernel_name(W, m.L, p.fast_ok);
     p.tile_out = windowed_tile_out(W, m.L);
     p.ntiles = p.S > 0 ? (p.S + p.tile_out - 1) / p.tile_out : 0;
     // window-start flags per slot (_meta.py:131: starts at 0, step, 2*step, ... <= n' - W)
@@ -239,6 +246,70 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     return GECCO_CRF_OK;
 }
 
+// ---- any number of labels (crf_general.hip) ------------------------------------------------
+namespace {
+inline size_t align256g(size_t x) { return (x + 255) & ~size_t(255); }
+
+int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, GenArgs &a) {
+    const Model &m = *p.model;
+    const size_t n = size_t(p.n_genes), L = size_t(m.L);
+    const size_t b_vec = align256g(n * L * 8 + 8), b_one = align256g(n * 8 + 8), b_back = align256g(n * L + 8);
+    if (!p.d_gen_ws) {
+        int rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_gen_ws), 3 * b_vec + 2 * b_one + b_back),
+                           "hipMalloc general-L workspace");
+        if (rc) return rc;
+    }
+    char *w = p.d_gen_ws;
+    a = GenArgs{};
+    a.gene_ptr = d_gene_ptr;
+    a.attr_id = d_attr_id;
+    a.wtab = p.tables->wtab;
+    a.exp_trans = p.tables->exp_trans;
+    a.trans = p.tables->trans;
+    a.contig_ptr = p.d_contig_ptr;
+    a.L = m.L;
+    a.n_genes = p.n_genes;
+    a.n_contigs = p.n_contigs;
+    a.state = reinterpret_cast<double *>(w);
+    a.E = reinterpret_cast<double *>(w + b_vec);
+    a.alpha = reinterpret_cast<double *>(w + 2 * b_vec);
+    a.smax = reinterpret_cast<double *>(w + 3 * b_vec);
+    a.scale = reinterpret_cast<double *>(w + 3 * b_vec + b_one);
+    a.back = reinterpret_cast<uint8_t *>(w + 3 * b_vec + 2 * b_one);
+    a.c_slot = p.d_c_slot;
+    a.c_gene = p.d_c_gene;
+    a.c_n = p.d_c_n;
+    a.start_bits = p.d_start_bits;
+    a.K = p.K;
+    a.S = p.S;
+    a.W = p.W;
+    return GECCO_CRF_OK;
+}
+
+int run_windowed_general(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                         hipStream_t stream) {
+    if (p.W > kGenMaxW) {
+        set_error("window too long for the any-L kernel (alpha of a whole window is LDS-resident: W <= 48)");
+        return GECCO_CRF_EUNSUPPORTED;
+    }
+    GenArgs a;
+    int rc = fill_gen_args(p, d_gene_ptr, d_attr_id, a);
+    if (rc) return rc;
+    a.p_out = d_p_out;
+    a.label = label;
+    // atomic-max accumulation starts from 0.0 (numpy.zeros, crf/__init__.py:251)
+    if ((rc = check_hip(hipMemsetAsync(d_p_out, 0, size_t(p.n_genes) * 8, stream), "memset p"))) return rc;
+    if (!p.skipped.empty())
+        if ((rc = check_hip(launch_fill_nan(d_p_out, p.d_skipped, int(p.skipped.size()), stream), "fill_nan launch")))
+            return rc;
+    double *keep_state = a.state;
+    a.state = nullptr;  // marginals only need exp(state - max)
+    if ((rc = check_hip(launch_gen_state(a, stream), "state score launch"))) return rc;
+    a.state = keep_state;
+    return check_hip(launch_gen_windowed(a, stream), "windowed launch");
+}
+}  // namespace
+
 int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                       hipStream_t stream) {
     if (p.device < 0) {
@@ -257,6 +328,7 @@ int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_
     int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
     if (rc) return rc;
     const Model &m = *p.model;
+    if (p.general) return run_windowed_general(p, d_gene_ptr, d_attr_id, label, d_p_out, stream);
     WinArgs a{};
     a.gene_ptr = d_gene_ptr;
     a.attr_id = d_attr_id;
@@ -371,12 +443,9 @@ int fill_seq_args(Plan &p, SeqArgs &a) {
         set_error("host-only plan: no HIP device bound (there is no CPU fallback)");
         return GECCO_CRF_ENODEV;
     }
-    if (p.model->L != 2) {
-        set_error("whole-contig kernels support 2-label models only");
-        return GECCO_CRF_EUNSUPPORTED;
-    }
     int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
     if (rc) return rc;
+    if (p.general) return GECCO_CRF_OK;  // the any-L path has its own workspace
     if ((rc = ensure_seq(p))) return rc;
     const Model &m = *p.model;
     const SeqLayout l = seq_layout(size_t(p.n_genes));
@@ -420,6 +489,15 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
         set_error("null device buffer");
         return GECCO_CRF_EINVAL;
     }
+    if (p.general) {
+        GenArgs g;
+        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g))) return rc;
+        g.marg = d_marg;
+        g.lognorm = d_lognorm;
+        g.state = nullptr;
+        if ((rc = check_hip(launch_gen_state(g, stream), "state score launch"))) return rc;
+        return check_hip(launch_gen_marginals(g, stream), "marginals launch");
+    }
     a.marg = d_marg;
     a.lognorm = d_lognorm;
     // wtab2[1] holds (w[a][0], w[a][1]) = (other, label) pairs for label 1
@@ -438,6 +516,16 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
     if (p.n_genes > 0 && (!d_gene_ptr || !d_y)) {
         set_error("null device buffer");
         return GECCO_CRF_EINVAL;
+    }
+    if (p.general) {
+        GenArgs g;
+        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g))) return rc;
+        g.y = d_y;
+        g.score = d_score;
+        g.E = nullptr;
+        g.smax = nullptr;
+        if ((rc = check_hip(launch_gen_state(g, stream), "state score launch"))) return rc;
+        return check_hip(launch_gen_viterbi(g, stream), "viterbi launch");
     }
     a.y = d_y;
     a.score = d_score;

@@ -19,6 +19,7 @@ struct DeviceTables {
     double *wtab = nullptr;       // [A*L]
     double2 *wtab2[2] = {nullptr, nullptr};  // L == 2: [A] (other, label) for label = 0 / 1
     double *exp_trans = nullptr;  // [L*L]
+    double *trans = nullptr;      // [L*L] raw weights (general-L Viterbi)
 };
 
 struct Plan {
@@ -37,6 +38,8 @@ struct Plan {
     uint32_t rescale_mask = 0;
     bool fast_ok = false;       // the register-resident kernel takes this shape
     bool force_generic = false; // GECCO_CRF_FORCE_GENERIC=1 (tests): always use the generic kernel
+    bool general = false;       // any-L kernels (crf_general.hip): L != 2, or GECCO_CRF_FORCE_GENERAL=1 (tests)
+    char *d_gen_ws = nullptr;   // their per-gene workspace, allocated on first use
     double *d_win_scratch = nullptr;
     std::string kernel_name;
     // device copies

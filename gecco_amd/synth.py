@@ -68,7 +68,7 @@ def contig_lengths(rng: np.random.Generator, n_contigs: int, total_genes: int = 
 
 
 def workload(name: str, seed: int = SEED):
-    """Named configurations of BASELINE.json (C2, C3, C5) -> dict(w, trans, contig_ptr, gene_ptr, attr_id)."""
+    """Named configurations of BASELINE.json (C2, C3, C5; Cinf = 2e8 genes) -> dict(w, trans, contig_ptr, gene_ptr, attr_id)."""
     rng = np.random.default_rng(seed)
     A = 35000
     w, trans = synth_model(A, rng)
@@ -79,7 +79,15 @@ def workload(name: str, seed: int = SEED):
         lengths = contig_lengths(rng, 10000, total_genes=2_000_000)
     elif name == "C5":
         lengths = np.full(100, 50000, dtype=np.int64)
+    elif name == "Cinf":
+        lengths = contig_lengths(rng, 10000, total_genes=2_000_000)
     else:
         raise ValueError(name)
     cptr, gptr, attr = synth_contigs(rng, lengths, A, planted=0.01, hot_attrs=hot)
+    if name == "Cinf":  # SURVEY.md 8d "C-infinity": 2e8 genes = 100 concatenated copies of the C3 batch
+        reps = 100
+        n, nnz = int(cptr[-1]), int(gptr[-1])
+        cptr = np.concatenate([[0]] + [cptr[1:].astype(np.int64) + r * n for r in range(reps)]).astype(np.int32)
+        gptr = np.concatenate([[0]] + [gptr[1:].astype(np.int64) + r * nnz for r in range(reps)]).astype(np.int32)
+        attr = np.tile(attr, reps)
     return dict(name=name, w=w, trans=trans, contig_ptr=cptr, gene_ptr=gptr, attr_id=attr, A=A)

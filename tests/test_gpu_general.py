@@ -1,0 +1,152 @@
+"""GPU parity of the any-number-of-labels kernels (crf_general.hip):
+windowed marginals, whole-contig marginals and Viterbi for CRFsuite models with L != 2
+labels, and the same kernels forced onto 2-label models as an on-device cross-check of the
+specialised ones.  Checker: the CPU oracle ([EXT] CRFsuite semantics) + brute-force
+enumeration of label paths.  Tolerance: 1e-12 on marginals (north star: 1e-6), labels exact."""
+import numpy as np
+import pytest
+
+from tests.helpers import golden_csr, synth_contigs, synth_model
+
+pytestmark = pytest.mark.gpu
+
+LABEL_COUNTS = [1, 3, 4, 5, 8, 13, 16, 17, 32]
+LENGTHS = [1, 2, 3, 4, 7, 19, 20, 21, 40, 63, 64, 65, 200, 1500]
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from gecco_amd import _native
+
+    assert _native.device_count() >= 1
+    return _native
+
+
+def _case(L, seed, A=300, extra=30):
+    rng = np.random.default_rng(seed)
+    w, trans = synth_model(A, rng, L=L)
+    cptr, gptr, attr = synth_contigs(rng, LENGTHS + list(rng.integers(1, 120, size=extra)), A)
+    return w, trans, cptr, gptr, attr
+
+
+@pytest.mark.parametrize("L", LABEL_COUNTS)
+def test_windowed_any_label_count(nat, L):
+    from oracle import crf_oracle as orc
+
+    w, trans, cptr, gptr, attr = _case(L, 100 + L)
+    model = nat.Model.from_tables(w, trans)
+    assert model.num_labels == L
+    for W, step, pad, label in [(20, 1, True, L - 1), (5, 1, True, 0), (20, 3, True, L // 2), (20, 1, False, 0), (48, 7, True, 0)]:
+        got = model.windowed_marginals(cptr, gptr, attr, W, step, label, pad)
+        exp = orc.windowed_marginals(w, trans, cptr, gptr, attr, W, step, label, pad)
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.abs(got[ok] - exp[ok]).max() <= 1e-12, (L, W, step, pad, label)
+
+
+@pytest.mark.parametrize("L", LABEL_COUNTS)
+def test_full_marginals_any_label_count(nat, L):
+    from oracle import crf_oracle as orc
+
+    w, trans, cptr, gptr, attr = _case(L, 200 + L)
+    model = nat.Model.from_tables(w, trans)
+    marg, ln = model.marginals_full(cptr, gptr, attr)
+    emarg, eln = orc.full_marginals(w, trans, cptr, gptr, attr)
+    assert marg.shape == emarg.shape == (int(cptr[-1]), L)
+    assert np.abs(marg - emarg).max() <= 1e-12
+    np.testing.assert_allclose(marg.sum(axis=1), 1.0, atol=1e-13)
+    assert np.abs(ln - eln).max() <= 1e-10 * max(1.0, np.abs(eln).max())
+
+
+@pytest.mark.parametrize("L", LABEL_COUNTS)
+def test_viterbi_any_label_count(nat, L):
+    from oracle import crf_oracle as orc
+
+    w, trans, cptr, gptr, attr = _case(L, 300 + L)
+    model = nat.Model.from_tables(w, trans)
+    y, sc = model.viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y.astype(np.int32), ey)
+    assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
+
+
+@pytest.mark.parametrize("L", [3, 5])
+def test_viterbi_ties_first_argmax(nat, L):
+    """Small-integer weights make exact ties common: the strict `<` update / first arg max of
+    [EXT] crf1dc_viterbi must be reproduced label for label."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(17 + L)
+    A = 40
+    w = rng.integers(-2, 3, size=(A, L)).astype(np.float64)
+    trans = rng.integers(-1, 2, size=(L, L)).astype(np.float64)
+    cptr, gptr, attr = synth_contigs(rng, [1, 2, 5, 33, 64, 65, 300, 999], A)
+    y, sc = nat.Model.from_tables(w, trans).viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y.astype(np.int32), ey)
+    assert np.array_equal(sc, esc)
+
+
+def test_three_labels_against_path_enumeration(nat):
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(5)
+    L, A, T = 3, 12, 7
+    w = rng.normal(0, 1.5, size=(A, L))
+    trans = rng.normal(0, 1.0, size=(L, L))
+    cptr, gptr, attr = synth_contigs(rng, [T], A)
+    state = orc.state_scores(w, gptr, attr)
+    model = nat.Model.from_tables(w, trans)
+    marg, ln = model.marginals_full(cptr, gptr, attr)
+    bm, bln = orc.brute_marginals(state, trans)
+    assert np.abs(marg - bm).max() <= 1e-12 and abs(ln[0] - bln) <= 1e-10
+    y, sc = model.viterbi(cptr, gptr, attr)
+    by, bsc = orc.brute_viterbi(state, trans)
+    assert np.array_equal(y.astype(np.int32), by) and abs(sc[0] - bsc) <= 1e-10
+    # a window as long as the contig is the whole-contig marginal
+    for label in range(L):
+        p = model.windowed_marginals(cptr, gptr, attr, T, 1, label, True)
+        assert np.abs(p - bm[:, label]).max() <= 1e-12
+
+
+def test_two_label_model_through_general_kernels(nat, oracle_model, monkeypatch):
+    """GECCO_CRF_FORCE_GENERAL=1: the shipped model on the any-L kernels must reproduce the golden
+    table and agree with the specialised kernels."""
+    import os
+
+    from oracle import lcrf
+    from tests.helpers import GOLDEN
+
+    real = nat.Model.from_lcrf(lcrf.load_pickle(os.path.join(GOLDEN, "model.pkl"))["blob"])
+    ids, cptr, gptr, attr, expected, ann = golden_csr(oracle_model["attr_index"])
+    rng = np.random.default_rng(9)
+    rc, rg, ra = synth_contigs(rng, LENGTHS + list(rng.integers(1, 300, size=40)), oracle_model["state"].shape[0])
+    fast = real.windowed_marginals(rc, rg, ra, 20, 1, 1, True)
+    fast_full, fast_ln = real.marginals_full(rc, rg, ra)
+    fast_y, fast_sc = real.viterbi(rc, rg, ra)
+    monkeypatch.setenv("GECCO_CRF_FORCE_GENERAL", "1")
+    p = real.windowed_marginals(cptr, gptr, attr, 20, 1, 1, True)
+    assert np.abs(p - expected).max() <= 1e-12
+    assert np.abs(real.windowed_marginals(rc, rg, ra, 20, 1, 1, True) - fast).max() <= 1e-12
+    full, ln = real.marginals_full(rc, rg, ra)
+    assert np.abs(full - fast_full).max() <= 1e-12 and np.abs(ln - fast_ln).max() <= 1e-9 * np.abs(ln).max()
+    y, sc = real.viterbi(rc, rg, ra)
+    assert np.array_equal(y, fast_y) and np.abs(sc - fast_sc).max() <= 1e-9 * np.abs(sc).max()
+
+
+def test_window_too_long_is_reported(nat):
+    rng = np.random.default_rng(3)
+    w, trans = synth_model(20, rng, L=3)
+    cptr, gptr, attr = synth_contigs(rng, [100], 20)
+    with pytest.raises(nat.NativeError) as ei:
+        nat.Model.from_tables(w, trans).windowed_marginals(cptr, gptr, attr, 49, 1, 0, True)
+    assert ei.value.code == nat.EUNSUPPORTED
+
+
+def test_too_many_labels_is_reported(nat):
+    rng = np.random.default_rng(4)
+    w, trans = synth_model(20, rng, L=33)
+    cptr, gptr, attr = synth_contigs(rng, [30], 20)
+    with pytest.raises(nat.NativeError) as ei:
+        nat.Model.from_tables(w, trans).windowed_marginals(cptr, gptr, attr, 20, 1, 0, True)
+    assert ei.value.code == nat.EUNSUPPORTED
