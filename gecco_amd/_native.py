@@ -52,6 +52,10 @@ SIGNATURES = {
         [ctypes.c_int32, _c_f64p, _c_u8p, _c_i32p, ctypes.c_int32, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
          ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p],
     ),
+    "gecco_crf_domain_composition": (
+        ctypes.c_int,
+        [ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p, _c_f64p, ctypes.c_int32, ctypes.c_int32, _c_f64p],
+    ),
     "gecco_crf_plan_create": (
         ctypes.c_int, [_vp, ctypes.c_int32, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_vp)]
     ),
@@ -244,6 +248,23 @@ class Model:
             )
         )
         return y[:n], sc[:nc]
+
+
+def domain_composition(seg, dom_ptr, dom_col, dom_weight, n_cols, normalize=True, device=0) -> np.ndarray:
+    """Dense (n_seg, n_cols) weighted domain compositions of the clusters in `seg` (gecco_crf_domain_composition)."""
+    lib = load_library()
+    seg = np.ascontiguousarray(seg, dtype=np.int32).reshape(-1, 4)
+    dom_ptr, dom_col = _i32(dom_ptr), _i32(dom_col)
+    dom_weight = np.ascontiguousarray(dom_weight, dtype=np.float64)
+    if dom_col.size == 0:
+        dom_col, dom_weight = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.float64)
+    out = np.zeros((len(seg), int(n_cols)), dtype=np.float64)
+    seg_buf = seg if len(seg) else np.zeros((1, 4), dtype=np.int32)
+    out_buf = out if out.size else np.zeros(1, dtype=np.float64)
+    _check(lib.gecco_crf_domain_composition(
+        device, _ptr(seg_buf, _c_i32p), len(seg), _ptr(dom_ptr, _c_i32p), len(dom_ptr) - 1, _ptr(dom_col, _c_i32p),
+        _ptr(dom_weight, _c_f64p), int(n_cols), int(bool(normalize)), _ptr(out_buf, _c_f64p)))
+    return out
 
 
 def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, trim=True, device=0) -> np.ndarray:

@@ -374,3 +374,46 @@ GECCO_API int gecco_crf_segment(int32_t device, const double *p, const uint8_t *
         return rc;
     return GECCO_CRF_OK;
 }
+
+GECCO_API int gecco_crf_domain_composition(int32_t device, const int32_t *seg, int32_t n_seg, const int32_t *dom_ptr,
+                                           int32_t n_genes, const int32_t *dom_col, const double *dom_weight,
+                                           int32_t n_cols, int32_t normalize, double *comp_out) {
+    if (n_seg < 0 || n_genes < 0 || n_cols < 0 || (n_seg > 0 && (!seg || !dom_ptr || (n_cols > 0 && !comp_out)))) {
+        set_error("gecco_crf_domain_composition: bad arguments");
+        return GECCO_CRF_EINVAL;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (n_seg == 0 || n_cols == 0) return GECCO_CRF_OK;
+    const size_t rows = size_t(dom_ptr[n_genes]);
+    if (rows && (!dom_col || !dom_weight)) {
+        set_error("gecco_crf_domain_composition: null domain arrays");
+        return GECCO_CRF_EINVAL;
+    }
+    for (int32_t k = 0; k < n_seg; ++k) {
+        const int32_t a = seg[4 * k + 2], b = seg[4 * k + 3];
+        if (a < 0 || b < a || b > n_genes) {
+            set_error("gecco_crf_domain_composition: segment outside the gene range");
+            return GECCO_CRF_EINVAL;
+        }
+    }
+    DeviceGuard guard;
+    if ((rc = check_hip(hipSetDevice(device), "hipSetDevice"))) return rc;
+    DevBuf<int32_t> d_seg, d_ptr, d_col;
+    DevBuf<double> d_w, d_tmp, d_out;
+    const size_t out_n = size_t(n_seg) * size_t(n_cols);
+    if ((rc = d_seg.alloc(size_t(n_seg) * 4, "hipMalloc segments"))) return rc;
+    if ((rc = d_ptr.alloc(size_t(n_genes) + 1, "hipMalloc dom_ptr"))) return rc;
+    if ((rc = d_col.alloc(rows, "hipMalloc dom_col"))) return rc;
+    if ((rc = d_w.alloc(rows, "hipMalloc dom_weight"))) return rc;
+    if ((rc = d_tmp.alloc(rows, "hipMalloc scratch"))) return rc;
+    if ((rc = d_out.alloc(out_n, "hipMalloc compositions"))) return rc;
+    if ((rc = check_hip(hipMemcpy(d_seg.p, seg, size_t(n_seg) * 16, hipMemcpyHostToDevice), "H2D segments"))) return rc;
+    if ((rc = check_hip(hipMemcpy(d_ptr.p, dom_ptr, (size_t(n_genes) + 1) * 4, hipMemcpyHostToDevice), "H2D dom_ptr"))) return rc;
+    if (rows && (rc = check_hip(hipMemcpy(d_col.p, dom_col, rows * 4, hipMemcpyHostToDevice), "H2D dom_col"))) return rc;
+    if (rows && (rc = check_hip(hipMemcpy(d_w.p, dom_weight, rows * 8, hipMemcpyHostToDevice), "H2D dom_weight"))) return rc;
+    if ((rc = check_hip(launch_composition(d_seg.p, n_seg, d_ptr.p, d_col.p, d_w.p, d_tmp.p, n_cols, normalize ? 1 : 0,
+                                           d_out.p, nullptr), "composition launch")))
+        return rc;
+    return check_hip(hipMemcpy(comp_out, d_out.p, out_n * 8, hipMemcpyDeviceToHost), "D2H compositions");
+}

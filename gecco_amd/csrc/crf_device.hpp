@@ -108,6 +108,11 @@ hipError_t launch_gen_windowed(const GenArgs &a, hipStream_t stream);   // p_out
 hipError_t launch_gen_marginals(const GenArgs &a, hipStream_t stream);
 hipError_t launch_gen_viterbi(const GenArgs &a, hipStream_t stream);
 
+// weighted domain composition of called clusters (crf_composition.hip); d_tmp: one double per domain row
+hipError_t launch_composition(const int32_t *d_seg, int n_seg, const int32_t *d_dom_ptr, const int32_t *d_dom_col,
+                              const double *d_dom_w, double *d_tmp, int n_cols, int normalize, double *d_out,
+                              hipStream_t stream);
+
 const char *windowed_kernel_name(int W, int L, bool fast);
 // tile_out = output slots per workgroup for the kernel that (W, L) dispatches to.
 int windowed_tile_out(int W, int L);

@@ -20,14 +20,16 @@ from typing import List, Optional
 
 import numpy as np
 
-from . import _native, packing, tables
+from . import _native, composition, packing, tables
 from .crf import ClusterCRF
 
 
 def predict_tables(genes_t: tables.GeneTable, feats_t: tables.FeatureTable, crf: ClusterCRF, *, pad: bool = True,
                    threshold: float = 0.8, n_cds: int = 3, edge_distance: int = 0, trim: bool = True,
-                   device: Optional[int] = None):
-    """Returns (GeneTable, FeatureTable, ClusterTable) with probabilities / clusters filled in."""
+                   device: Optional[int] = None, composition_domains: Optional[List[str]] = None):
+    """Returns (GeneTable, FeatureTable, ClusterTable) with probabilities / clusters filled in; with
+    `composition_domains` (the type classifier's domain list) also the (n_clusters, n_domains)
+    weighted domain composition matrix ``TypeClassifier.predict_types`` feeds its forest with."""
     if crf.feature_type != "protein":
         raise ValueError("the columnar path supports protein-level features (the shipped model's mode)")
     dev = crf.devices[0] if device is None else device
@@ -90,7 +92,13 @@ def predict_tables(genes_t: tables.GeneTable, feats_t: tables.FeatureTable, crf:
         ccols["type"].append("Unknown")
         ccols["proteins"].append(";".join(sorted(members)))
         ccols["domains"].append(";".join(sorted(d for pid in members for d in doms_of.get(pid, ()))))
-    return genes_out, feats_out, tables.ClusterTable(ccols)
+    clusters_out = tables.ClusterTable(ccols)
+    if composition_domains is None:
+        return genes_out, feats_out, clusters_out
+    # input matrix of the type classifier (types/__init__.py:118), one row per called cluster
+    comps = composition.table_compositions(seg, order, feats_t.protein_id, feats_t.domain, feats_t.pvalue,
+                                           feats_t.domain_start, composition_domains, device=dev)
+    return genes_out, feats_out, clusters_out, comps
 
 
 def main(argv: Optional[List[str]] = None) -> int:
@@ -104,13 +112,21 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--cds", type=int, default=3)
     ap.add_argument("-E", "--edge-distance", type=int, default=0)
     ap.add_argument("--no-trim", action="store_true")
+    ap.add_argument("--composition-domains", default=None,
+                    help="file with one domain accession per line (the type classifier's domains.tsv): also write "
+                         "<base>.compositions.npy, the classifier's input matrix")
     args = ap.parse_args(argv)
     crf = ClusterCRF.trained(args.model)
     genes_t = tables.GeneTable.load(args.genes)
     feats_t = tables.FeatureTable.load(args.features)
-    genes_out, feats_out, clusters = predict_tables(
+    comp_domains = None
+    if args.composition_domains:
+        with open(args.composition_domains) as fh:
+            comp_domains = [line.strip() for line in fh if line.strip()]
+    res = predict_tables(
         genes_t, feats_t, crf, pad=not args.no_pad, threshold=args.threshold, n_cds=args.cds,
-        edge_distance=args.edge_distance, trim=not args.no_trim)
+        edge_distance=args.edge_distance, trim=not args.no_trim, composition_domains=comp_domains)
+    genes_out, feats_out, clusters = res[:3]
     os.makedirs(args.output_dir, exist_ok=True)
     base = os.path.splitext(os.path.basename(args.genes))[0]
     base = base[:-len(".genes")] if base.endswith(".genes") else base
@@ -118,6 +134,8 @@ def main(argv: Optional[List[str]] = None) -> int:
         genes_out.dump(os.path.join(args.output_dir, f"{base}.genes.tsv"))
     feats_out.dump(os.path.join(args.output_dir, f"{base}.features.tsv"))
     clusters.dump(os.path.join(args.output_dir, f"{base}.clusters.tsv"))
+    if comp_domains is not None:
+        np.save(os.path.join(args.output_dir, f"{base}.compositions.npy"), res[3])
     print(f"{len(genes_t)} genes, {len(clusters)} clusters -> {args.output_dir}", file=sys.stderr)
     return 0
 

@@ -106,6 +106,20 @@ int gecco_crf_segment(int32_t device, const double *p, const uint8_t *annotated,
                       double threshold, int32_t n_cds, int32_t edge_distance, int32_t trim,
                       int32_t *seg_out, int32_t max_seg, int32_t *n_seg);
 
+/* Weighted domain composition of called clusters (gecco/model.py:458-503
+ * `Cluster.domain_composition(all_possible, normalize)`, assembled per cluster for the type
+ * classifier at gecco/types/__init__.py:118).  seg rows as written by gecco_crf_segment
+ * (only first_gene / last_gene_exclusive are read); dom_ptr[n_genes+1] = CSR of the domain
+ * rows of every gene in the order of `gene.protein.domains`; dom_col[row] = index of the
+ * domain's name in all_possible or -1; dom_weight[row] = 1 - pvalue (or -log10, the caller's
+ * choice as in the reference).  comp_out[n_seg][n_cols], every entry numpy.sum of the matching
+ * weights and every row divided by `row.sum() or 1` when normalize != 0: bit-identical to
+ * numpy's pairwise summation. */
+int gecco_crf_domain_composition(int32_t device, const int32_t *seg, int32_t n_seg,
+                                 const int32_t *dom_ptr, int32_t n_genes,
+                                 const int32_t *dom_col, const double *dom_weight,
+                                 int32_t n_cols, int32_t normalize, double *comp_out);
+
 /* ---- resident / asynchronous API ----------------------------------------------------
  * A plan owns the device copies of the model tables and of the contig layout of one
  * batch; bulk arrays stay in caller-owned DEVICE memory and launches go to the caller's

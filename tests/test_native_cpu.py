@@ -106,6 +106,21 @@ def test_host_only_plan_layout(blob):
     assert ei.value.code == nat.ENODEV
 
 
+def test_host_only_plan_dispatch_by_label_count(blob, monkeypatch):
+    rng = np.random.default_rng(1)
+    m3 = nat.Model.from_tables(rng.normal(size=(9, 3)), rng.normal(size=(3, 3)))
+    assert nat.Plan(m3, [0, 50], 20, device=-1).kernel_name == "gl_windowed"
+    m33 = nat.Model.from_tables(rng.normal(size=(9, 33)), rng.normal(size=(33, 33)))
+    with pytest.raises(nat.NativeError) as ei:
+        nat.Plan(m33, [0, 50], 20, device=-1)
+    assert ei.value.code == nat.EUNSUPPORTED
+    m2 = nat.Model.from_lcrf(blob)
+    monkeypatch.setenv("GECCO_CRF_FORCE_GENERAL", "1")
+    assert nat.Plan(m2, [0, 50], 20, device=-1).kernel_name == "gl_windowed"
+    monkeypatch.delenv("GECCO_CRF_FORCE_GENERAL")
+    assert "crf_windowed_l2" in nat.Plan(m2, [0, 50], 20, device=-1).kernel_name
+
+
 @pytest.mark.skipif(nat.device_count() > 0, reason="only meaningful on a box without a GPU")
 def test_no_cpu_fallback(blob):
     m = nat.Model.from_lcrf(blob)
