@@ -85,9 +85,10 @@ def main() -> None:
         have_viterbi = False
 
     def step():
-        plan.run_windowed(d_gp.data_ptr(), d_at.data_ptr(), d_p.data_ptr(), LABEL, stream)
-        if have_viterbi:
-            plan.run_viterbi(d_gp.data_ptr(), d_at.data_ptr(), d_y.data_ptr(), 0, stream)
+        if have_viterbi:  # one pass over the CSR: state scores are accumulated once for both outputs
+            plan.run_decode(d_gp.data_ptr(), d_at.data_ptr(), d_p.data_ptr(), d_y.data_ptr(), LABEL, 0, stream)
+        else:
+            plan.run_windowed(d_gp.data_ptr(), d_at.data_ptr(), d_p.data_ptr(), LABEL, stream)
 
     def barrier():
         if dist is not None:

@@ -65,6 +65,7 @@ SIGNATURES = {
     "gecco_crf_plan_num_tiles": (ctypes.c_int32, [_vp]),
     "gecco_crf_plan_kernel_name": (ctypes.c_char_p, [_vp]),
     "gecco_crf_plan_run_windowed": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp]),
+    "gecco_crf_plan_run_decode": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     "gecco_crf_plan_run_marginals_full": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gecco_crf_plan_run_viterbi": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gecco_crf_plan_time_windowed": (
@@ -325,6 +326,11 @@ class Plan:
 
     def run_windowed(self, d_gene_ptr: int, d_attr_id: int, d_p_out: int, label=1, stream: int = 0):
         _check(self._lib.gecco_crf_plan_run_windowed(self._h, d_gene_ptr, d_attr_id, int(label), d_p_out, stream or None))
+
+    def run_decode(self, d_gene_ptr: int, d_attr_id: int, d_p_out: int, d_y: int, label: int = 1, d_score: int = 0, stream: int = 0):
+        """Windowed marginals + Viterbi labels in one pass over the CSR (shared state scores)."""
+        _check(self._lib.gecco_crf_plan_run_decode(self._h, d_gene_ptr, d_attr_id or None, int(label), d_p_out, d_y,
+                                                   d_score or None, stream or None))
 
     def run_marginals_full(self, d_gene_ptr: int, d_attr_id: int, d_marg: int, d_lognorm: int = 0, stream: int = 0):
         _check(self._lib.gecco_crf_plan_run_marginals_full(self._h, d_gene_ptr, d_attr_id, d_marg, d_lognorm or None, stream or None))

@@ -202,6 +202,12 @@ GECCO_API int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_g
     return rc;
 }
 
+GECCO_API int gecco_crf_plan_run_decode(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                        int32_t label, double *d_p_out, int8_t *d_y, double *d_score, void *stream) {
+    if (!p) return GECCO_CRF_EINVAL;
+    DeviceGuard guard;
+    return plan_run_decode(p->p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, static_cast<hipStream_t>(stream));
+}
 GECCO_API int gecco_crf_plan_run_marginals_full(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                                                 double *d_marg, double *d_lognorm, void *stream) {
     if (!p) return GECCO_CRF_EINVAL;

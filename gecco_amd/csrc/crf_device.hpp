@@ -20,7 +20,9 @@ struct WinArgs {
     const int4 *tile_desc;     // [ntiles]     (gene-slot shift, first contig, last contig, flags: 1 = regular)
     const uint64_t *start_bits;// [S/64+1]     bit q: a window may start at slot q
     double *p_out;             // [n_genes]
+    double2 *state_out;        // [n_genes] or null: raw state scores (s[0], s[1]) as a by-product (fast L == 2 kernel)
     int32_t K, S, ntiles, W, step, L, label;
+    int32_t n_genes, A;        // CSR extent and weight-table rows (buffer descriptors)
     uint32_t rescale_mask;     // bit k: renormalise the DP vectors after step k
     // transitions in the transformed basis (rows/cols ordered (other, label)):
     //   mu01 = m01*m10/m00^2, mu11 = m11/m00, kappa = m10/m00, rho = mu11/mu01  with m = exp(trans)

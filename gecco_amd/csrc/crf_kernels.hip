@@ -118,40 +118,33 @@ __device__ __forceinline__ void state_scores_l2(const int32_t *__restrict__ attr
     }
 }
 
-// Same for the two slots a lane may own (its own and, for the first W-1 lanes, a tail slot):
-// the first chunk of both genes is in flight together.
-__device__ __forceinline__ void state_scores_l2_pair(const int32_t *__restrict__ attr_id,
-                                                     const double2 *__restrict__ wtab2, int lo0, int hi0,
-                                                     int lo1, int hi1, bool any1, double &s00, double &s01,
-                                                     double &s10, double &s11) {
-    int a0[kGatherUnroll], a1[kGatherUnroll];
+// Branch-free variant for the windowed kernel, on buffer descriptors: an out-of-range raw buffer
+// load returns 0 instead of faulting, so (a) the kGatherUnroll attribute ids of a gene are loaded
+// unconditionally (the ones past the gene's run belong to the next genes or lie past the end of
+// the array and are simply not used), and (b) an unused slot gathers from offset 0xFFFFFFF0, which
+// is past the weight table and yields the pair (+0.0, +0.0): the sum stays bit-exact and a gene
+// costs 3 VALU ops per attribute slot (shift, compare, select) + 2 adds, no exec-mask branches.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void state_scores_buf(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, uint32_t off,
+                                                 uint32_t cnt, double &s0, double &s1) {
+    for (uint32_t base = 0; base < cnt; base += kGatherUnroll) {  // one trip unless a gene has > 8 domains
+        int a[kGatherUnroll];
 #pragma unroll
-    for (int u = 0; u < kGatherUnroll; ++u) a0[u] = lo0 + u < hi0 ? attr_id[lo0 + u] : -1;
-    if (any1) {
-#pragma unroll
-        for (int u = 0; u < kGatherUnroll; ++u) a1[u] = lo1 + u < hi1 ? attr_id[lo1 + u] : -1;
-    }
-    double2 w0[kGatherUnroll], w1[kGatherUnroll];
-#pragma unroll
-    for (int u = 0; u < kGatherUnroll; ++u) w0[u] = a0[u] >= 0 ? wtab2[a0[u]] : make_double2(0.0, 0.0);
-    if (any1) {
-#pragma unroll
-        for (int u = 0; u < kGatherUnroll; ++u) w1[u] = a1[u] >= 0 ? wtab2[a1[u]] : make_double2(0.0, 0.0);
-    }
-#pragma unroll
-    for (int u = 0; u < kGatherUnroll; ++u) {
-        s00 += w0[u].x;
-        s01 += w0[u].y;
-    }
-    if (any1) {
+        for (int u = 0; u < kGatherUnroll; ++u)
+            a[u] = __builtin_amdgcn_raw_buffer_load_b32(ra, int((off + base + u) << 2), 0, 0);
+        i32x4 w[kGatherUnroll];
 #pragma unroll
         for (int u = 0; u < kGatherUnroll; ++u) {
-            s10 += w1[u].x;
-            s11 += w1[u].y;
+            const uint32_t wo = base + u < cnt ? uint32_t(a[u]) << 4 : 0xFFFFFFF0u;
+            w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, int(wo), 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kGatherUnroll; ++u) {
+            s0 += __hiloint2double(w[u].y, w[u].x);
+            s1 += __hiloint2double(w[u].w, w[u].z);
         }
     }
-    state_scores_l2(attr_id, wtab2, lo0 + kGatherUnroll, hi0, s00, s01);  // rare: > 8 domains
-    if (any1) state_scores_l2(attr_id, wtab2, lo1 + kGatherUnroll, hi1, s10, s11);
 }
 
 // Recurrences in the transformed basis (see crf_plan.cpp for the constants):
@@ -206,6 +199,17 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 5 : 3)) crf_windowed_l2(cons
         if (has1) gene1 = slot_lookup(sm, cnt, q0 + NT + tid, P.S, W, P.step).gene;
     }
 
+    // buffer descriptors: attribute ids relative to the tile's first run (keeps byte offsets in 32
+    // bits for any batch), the weight-pair table whole.  All operands are wave-uniform (SGPRs).
+    const uint32_t nnz = uint32_t(P.gene_ptr[P.n_genes]);
+    const int g_first = (td.w & 1) ? (q0 > 0 ? q0 : 0) + td.x : P.c_gene[td.y];
+    const uint32_t lo_tile = uint32_t(P.gene_ptr[g_first]);
+    const uint64_t abytes = uint64_t(nnz - lo_tile) << 2;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t *>(P.attr_id + lo_tile), 0, abytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(abytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(P.wtab2), 0, uint32_t(P.A) << 4, 0x00020000);
+
     // ---- stage 1: CSR row bounds -> state scores -> slot constants in LDS
     int lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
     if (gene0 >= 0) {
@@ -218,7 +222,12 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 5 : 3)) crf_windowed_l2(cons
     }
     {
         double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
-        state_scores_l2_pair(P.attr_id, P.wtab2, lo0, hi0, lo1, hi1, wave == 0, s00, s01, s10, s11);
+        state_scores_buf(ra, rw, uint32_t(lo0) - lo_tile, uint32_t(hi0 - lo0), s00, s01);
+        if (wave == 0) state_scores_buf(ra, rw, uint32_t(lo1) - lo_tile, uint32_t(hi1 - lo1), s10, s11);
+        // decode = windowed marginals + Viterbi of the same batch: the raw scores of the genes this
+        // tile owns are handed to the whole-contig kernels instead of being gathered a second time
+        if (P.state_out && tid >= W - 1 && gene0 >= 0)
+            reinterpret_cast<f64x2 *>(P.state_out)[gene0] = P.label ? f64x2{s00, s01} : f64x2{s01, s00};
         {
             const double d = s01 - s00;
             const double e = exp(-fabs(d));

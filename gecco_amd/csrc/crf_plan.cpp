@@ -310,8 +310,16 @@ int run_windowed_general(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_at
 }
 }  // namespace
 
+static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                             double2 *d_state_out, hipStream_t stream);
+
 int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                       hipStream_t stream) {
+    return run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, stream);
+}
+
+static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                             double2 *d_state_out, hipStream_t stream) {
     if (p.device < 0) {
         set_error("host-only plan: no HIP device bound (there is no CPU fallback)");
         return GECCO_CRF_ENODEV;
@@ -341,6 +349,7 @@ int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_
     a.tile_desc = p.d_tile_desc;
     a.start_bits = p.d_start_bits;
     a.p_out = d_p_out;
+    a.state_out = d_state_out;
     a.K = p.K;
     a.S = p.S;
     a.ntiles = p.ntiles;
@@ -348,6 +357,8 @@ int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_
     a.step = p.step;
     a.L = m.L;
     a.label = label;
+    a.n_genes = p.n_genes;
+    a.A = m.A;
     a.rescale_mask = p.rescale_mask;
     {
         // exp() of differences only: every constant is a ratio of transition weights
@@ -532,6 +543,34 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
     if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables->wtab2[1], p.n_genes,
                                          const_cast<double2 *>(a.state), stream), "state score launch")))
         return rc;
+    return check_hip(launch_seq_viterbi(a, p.d_contig_ptr, stream), "viterbi launch");
+}
+
+
+int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                    int8_t *d_y, double *d_score, hipStream_t stream) {
+    // the fused hand-over needs the register-resident 2-label kernel and every gene in slot space
+    const bool share = !p.general && p.fast_ok && p.skipped.empty() && p.device >= 0;
+    if (!share) {
+        int rc = plan_run_windowed(p, d_gene_ptr, d_attr_id, label, d_p_out, stream);
+        if (rc) return rc;
+        return plan_run_viterbi(p, d_gene_ptr, d_attr_id, d_y, d_score, stream);
+    }
+    if (label < 0 || label >= p.model->L) {
+        set_error("label out of range");
+        return GECCO_CRF_EINVAL;
+    }
+    SeqArgs a;
+    int rc = fill_seq_args(p, a);
+    if (rc) return rc;
+    if (p.n_contigs == 0 || p.n_genes == 0) return GECCO_CRF_OK;
+    if (!d_gene_ptr || !d_p_out || !d_y) {
+        set_error("null device buffer");
+        return GECCO_CRF_EINVAL;
+    }
+    if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, const_cast<double2 *>(a.state), stream))) return rc;
+    a.y = d_y;
+    a.score = d_score;
     return check_hip(launch_seq_viterbi(a, p.d_contig_ptr, stream), "viterbi launch");
 }
 

@@ -59,6 +59,9 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
                int32_t pad, Plan &p);
 int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                       hipStream_t stream);
+// windowed marginals + whole-contig Viterbi of the same batch in one pass over the CSR
+int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                    int8_t *d_y, double *d_score, hipStream_t stream);
 int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, double *d_marg,
                             double *d_lognorm, hipStream_t stream);
 int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int8_t *d_y, double *d_score,

@@ -140,6 +140,12 @@ int gecco_crf_plan_run_marginals_full(gecco_crf_plan *p, const int32_t *d_gene_p
                                       double *d_marg, double *d_lognorm, void *stream);
 int gecco_crf_plan_run_viterbi(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                                int8_t *d_y, double *d_score, void *stream);
+/* Windowed marginals (gecco/crf/__init__.py:244-258) and whole-contig Viterbi ([EXT]
+ * CRF.predict_single) of the same batch in one pass over the CSR: the state scores
+ * ([EXT] crf1dt_state_score) are accumulated once and shared.  Same outputs, bit for bit, as
+ * gecco_crf_plan_run_windowed followed by gecco_crf_plan_run_viterbi; d_score may be NULL. */
+int gecco_crf_plan_run_decode(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                              int32_t label, double *d_p_out, int8_t *d_y, double *d_score, void *stream);
 /* Average milliseconds per launch of `iters` back-to-back windowed launches, measured with
  * HIP events on `stream` (after `warmup` untimed launches). */
 int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,

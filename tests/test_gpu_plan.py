@@ -1,0 +1,114 @@
+"""GPU: the resident / asynchronous half of the C ABI (gecco_crf_plan_*): caller-owned device
+buffers (torch is only the allocator here), caller's stream, one plan reused across launches.
+Results must equal the one-shot host entry points and the CPU oracle."""
+import numpy as np
+import pytest
+
+from tests.helpers import synth_contigs
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from gecco_amd import _native
+
+    assert _native.device_count() >= 1
+    return _native
+
+
+@pytest.fixture(scope="module")
+def real(nat):
+    import os
+
+    from oracle import lcrf
+    from tests.helpers import GOLDEN
+
+    return nat.Model.from_lcrf(lcrf.load_pickle(os.path.join(GOLDEN, "model.pkl"))["blob"])
+
+
+def _batch(oracle_model, seed, lengths=None):
+    rng = np.random.default_rng(seed)
+    lengths = lengths if lengths is not None else [1, 5, 19, 20, 21, 64, 300, 1000] + list(rng.integers(1, 400, size=60))
+    return synth_contigs(rng, lengths, oracle_model["state"].shape[0])
+
+
+def _dev(*arrays):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in arrays]
+
+
+@pytest.mark.parametrize("label", [1, 0])
+@pytest.mark.parametrize("pad", [True, False])
+def test_decode_equals_separate_launches(nat, real, oracle_model, label, pad):
+    from oracle import crf_oracle as orc
+
+    cptr, gptr, attr = _batch(oracle_model, 40 + label)
+    n = int(cptr[-1])
+    d_gp, d_at = _dev(gptr, attr)
+    plan = nat.Plan(real, cptr, 20, 1, pad, device=0)
+    p1 = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    y1 = torch.zeros(n, dtype=torch.int8, device="cuda:0")
+    s1 = torch.zeros(len(cptr) - 1, dtype=torch.float64, device="cuda:0")
+    p2, y2, s2 = torch.zeros_like(p1), torch.zeros_like(y1), torch.zeros_like(s1)
+    stream = torch.cuda.Stream(device="cuda:0")
+    with torch.cuda.stream(stream):
+        plan.run_windowed(d_gp.data_ptr(), d_at.data_ptr(), p1.data_ptr(), label, stream.cuda_stream)
+        plan.run_viterbi(d_gp.data_ptr(), d_at.data_ptr(), y1.data_ptr(), s1.data_ptr(), stream.cuda_stream)
+        for _ in range(2):  # a plan is reusable
+            plan.run_decode(d_gp.data_ptr(), d_at.data_ptr(), p2.data_ptr(), y2.data_ptr(), label, s2.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    a, b = p1.cpu().numpy(), p2.cpu().numpy()
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    assert torch.equal(y1, y2) and torch.equal(s1, s2)
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, label, pad)
+    ok = ~np.isnan(exp)
+    assert np.array_equal(np.isnan(b), ~ok) and np.abs(b[ok] - exp[ok]).max() <= 1e-12
+    ey, esc = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    assert np.array_equal(y2.cpu().numpy().astype(np.int32), ey)
+    assert np.abs(s2.cpu().numpy() - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
+
+
+def test_resident_calls_equal_one_shot(nat, real, oracle_model):
+    cptr, gptr, attr = _batch(oracle_model, 7)
+    n = int(cptr[-1])
+    d_gp, d_at = _dev(gptr, attr)
+    plan = nat.Plan(real, cptr, 20, 1, True, device=0)
+    p = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    marg = torch.zeros(n, 2, dtype=torch.float64, device="cuda:0")
+    ln = torch.zeros(len(cptr) - 1, dtype=torch.float64, device="cuda:0")
+    plan.run_windowed(d_gp.data_ptr(), d_at.data_ptr(), p.data_ptr(), 1)
+    plan.run_marginals_full(d_gp.data_ptr(), d_at.data_ptr(), marg.data_ptr(), ln.data_ptr())
+    ms = plan.time_windowed(d_gp.data_ptr(), d_at.data_ptr(), p.data_ptr(), 1, warmup=1, iters=3)
+    torch.cuda.synchronize()
+    assert ms > 0
+    assert np.array_equal(p.cpu().numpy(), real.windowed_marginals(cptr, gptr, attr, 20))
+    m1, l1 = real.marginals_full(cptr, gptr, attr)
+    assert np.array_equal(marg.cpu().numpy(), m1) and np.array_equal(ln.cpu().numpy(), l1)
+
+
+def test_batch_whose_attribute_array_ends_inside_a_gather(nat, real, oracle_model):
+    """The windowed kernel loads 8 attribute ids per gene unconditionally through a bounds-checked
+    buffer descriptor: the last genes' loads run past the end of attr_id and must read as absent."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(12)
+    A = oracle_model["state"].shape[0]
+    gptr = np.arange(0, 41, dtype=np.int32)  # 40 genes, one domain each, nothing after the last id
+    attr = rng.integers(0, A, size=40).astype(np.int32)
+    cptr = np.array([0, 40], dtype=np.int32)
+    d_gp = torch.from_numpy(gptr).to("cuda:0")
+    d_at = torch.from_numpy(attr).to("cuda:0")  # exact-size allocation
+    p = torch.zeros(40, dtype=torch.float64, device="cuda:0")
+    nat.Plan(real, cptr, 20, 1, True, device=0).run_windowed(d_gp.data_ptr(), d_at.data_ptr(), p.data_ptr(), 1)
+    torch.cuda.synchronize()
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20)
+    assert np.abs(p.cpu().numpy() - exp).max() <= 1e-12
+    # genes with more than 8 domains take a second trip of the gather loop
+    gptr2 = np.array([0, 11, 11, 30] + list(range(31, 58)), dtype=np.int32)
+    attr2 = rng.integers(0, A, size=int(gptr2[-1])).astype(np.int32)
+    cptr2 = np.array([0, len(gptr2) - 1], dtype=np.int32)
+    got = real.windowed_marginals(cptr2, gptr2, attr2, 20)
+    exp2 = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr2, gptr2, attr2, 20)
+    assert np.abs(got - exp2).max() <= 1e-12
