@@ -158,6 +158,46 @@ __global__ void __launch_bounds__(kTS) scan_block_totals(E *agg, int n) {
     }
 }
 
+// Look-back over per-workgroup totals instead of a separate scan launch: the exclusive prefix of
+// workgroup b is total[j] (x) ... (x) total[b-1] from the nearest workgroup j whose span contains a
+// contig start (`rs`), because everything before a contig start is forgotten.  With contigs of a
+// few hundred genes and 2048-gene workgroups that is one 64-wide coalesced read of neighbouring
+// totals and one wave scan; a 50 000-gene contig walks back 25 totals, still one read.  Every wave
+// does it for itself (no barrier).
+__device__ __forceinline__ VE wave_bcast63(const VE &v) {
+    auto b = [](double x) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+    };
+    return VE{b(v.a00), b(v.a01), b(v.a10), b(v.a11), b(v.rs)};
+}
+__device__ __forceinline__ VE lookback_prefix(const VE *__restrict__ totals, int b) {
+    const int lane = threadIdx.x & 63;
+    VE acc = VOp::identity();
+    for (int hi = b; hi > 0; hi -= 64) {
+        const int idx = hi - 1 - lane;  // lanes hold the totals back to front
+        const VE e = idx >= 0 ? totals[idx] : VOp::identity();
+        const VE r = wave_bcast63(wave_scan_inclusive<VOp, true>(e));
+        acc = VOp::combine(r, acc);
+        if (r.rs != 0.0) break;
+    }
+    return acc;
+}
+// Same for the back-to-front label maps: the suffix of workgroup b is map[b+1] o map[b+2] o ...
+// up to the first constant map (a workgroup that contains a contig end, or in which the two
+// Viterbi paths have merged): whatever lies to its right cannot matter.
+__device__ __forceinline__ uint32_t lookahead_suffix(const uint32_t *__restrict__ maps, int b, int nb) {
+    const int lane = threadIdx.x & 63;
+    uint32_t acc = MapOp::identity();
+    for (int lo = b + 1; lo < nb; lo += 64) {
+        const int idx = lo + lane;
+        const uint32_t e = idx < nb ? maps[idx] : MapOp::identity();
+        const uint32_t r = uint32_t(__builtin_amdgcn_readlane(int(wave_scan_inclusive<MapOp, false>(e)), 63));
+        acc = MapOp::combine(acc, r);
+        if (acc == 0u || acc == 3u) break;
+    }
+    return acc;
+}
+
 // ---------------------------------------------------------------- row S: state scores
 __global__ void __launch_bounds__(kT) seq_state_scores(const int32_t *__restrict__ gene_ptr,
                                                        const int32_t *__restrict__ attr_id,
@@ -270,7 +310,7 @@ __global__ void __launch_bounds__(kT) v_replay(const SeqArgs A) {
     __shared__ LaneStage stg;
     const int slot = threadIdx.x;
     const LaneGenes L = load_lane(A, slot, stg);
-    const VE M = VOp::combine(A.vBlock[blockIdx.x], A.vLane[blockIdx.x * kT + slot]);
+    const VE M = VOp::combine(lookback_prefix(A.vBlock, blockIdx.x), A.vLane[blockIdx.x * kT + slot]);
     double d0 = M.a00, d1 = M.a01;  // rows are identical once a contig has started (M.rs)
     uint32_t maps = 0;                                         // 2 bits per gene
     uint32_t lane_map = MapOp::identity();
@@ -319,10 +359,11 @@ __global__ void __launch_bounds__(kT) v_labels(const SeqArgs A) {
     const int slot = threadIdx.x;
     const int g0 = (blockIdx.x * kT + slot) * kGPL;
     const int cnt = min(kGPL, A.n_genes - g0);
+    const uint32_t block_suf = lookahead_suffix(A.vBlockMap, blockIdx.x, gridDim.x);
     if (cnt <= 0) return;
     // suffix map of everything to the right of this lane, applied to a dummy label (the last gene
     // of the batch ends a contig, so the composition is constant)
-    const uint32_t suf = MapOp::combine(A.vLaneMap[blockIdx.x * kT + slot], A.vBlockMap[blockIdx.x]);
+    const uint32_t suf = MapOp::combine(A.vLaneMap[blockIdx.x * kT + slot], block_suf);
     uint32_t lab = suf & 1u;
     const uint32_t maps = A.vMaps[blockIdx.x * kT + slot];
     uint64_t packed = 0;
@@ -507,9 +548,7 @@ hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hip
     if (a.n_genes > 0) {
         const int nb = (a.n_genes + kBlockGenes - 1) / kBlockGenes;
         hipLaunchKernelGGL(v_fold, dim3(nb), dim3(kT), 0, stream, a);
-        hipLaunchKernelGGL((scan_block_totals<VOp, false, VE>), dim3(1), dim3(kTS), 0, stream, reinterpret_cast<VE *>(a.vBlock), nb);
         hipLaunchKernelGGL(v_replay, dim3(nb), dim3(kT), 0, stream, a);
-        hipLaunchKernelGGL((scan_block_totals<MapOp, true, uint32_t>), dim3(1), dim3(kTS), 0, stream, a.vBlockMap, nb);
         hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, a);
     }
     if (a.score) hipLaunchKernelGGL(v_scores, grid_for(a.n_contigs, kT), dim3(kT), 0, stream, a, d_contig_ptr);

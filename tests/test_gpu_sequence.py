@@ -81,6 +81,30 @@ def test_viterbi_exact_ties_integer_weights(nat, seed):
     assert np.array_equal(sc, esc)
 
 
+@pytest.mark.parametrize("integer_weights", [False, True])
+def test_viterbi_very_long_contigs_walk_back_many_workgroups(nat, real, oracle_model, integer_weights):
+    """Contigs spanning > 64 workgroups of 2048 genes: the look-back over workgroup totals (prefix
+    scores) and the look-ahead over workgroup label maps both take more than one 64-wide step."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(77)
+    if integer_weights:  # label-neutral genes dominate: the two paths stay apart over long stretches
+        A = 8
+        w = np.zeros((A, 2))
+        w[0] = (1.0, 0.0)
+        w[1] = (0.0, 1.0)
+        trans = np.array([[1.0, -3.0], [-3.0, 1.0]])
+        model = nat.Model.from_tables(w, trans)
+    else:
+        A = oracle_model["state"].shape[0]
+        w, trans, model = oracle_model["state"], oracle_model["trans"], real
+    cptr, gptr, attr = synth_contigs(rng, [300000, 3, 140000, 2049], A)
+    y, sc = model.viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y, ey.astype(np.int8))
+    assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
+
+
 def test_synthetic_model_c2_shape(nat):
     from oracle import crf_oracle as orc
 
