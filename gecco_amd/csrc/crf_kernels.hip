@@ -118,6 +118,23 @@ __device__ __forceinline__ void state_scores_l2(const int32_t *__restrict__ attr
     }
 }
 
+// exp(-t) for t >= 0: n = rint(t log2 e), r = n ln2 - t in two pieces (|r| <= ln2/2), degree-13
+// Taylor polynomial (truncation 2e-18), v_ldexp_f64 for 2^-n (flushes to 0 by itself for huge t).
+// The coefficients 1/13! .. 1/2! travel as kernel arguments so that they sit in SGPRs: as literals
+// every one of them costs two v_mov per use, as many VALU slots as the polynomial itself.
+__device__ __forceinline__ double exp_neg(double t, const double (&kExpC)[12]) {
+    const double n = rint(t * 1.4426950408889634);
+    double r = fma(n, 0.6931471805599453094, -t);   // ln2 hi
+    r = fma(n, 2.3190468138462996e-17, r);           // ln2 lo
+    // exp(-t) = 2^-n exp(r),  r = n ln2 - t
+    double p = kExpC[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) p = fma(p, r, kExpC[i]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, -int(n));
+}
+
 // Branch-free variant for the windowed kernel, on buffer descriptors: an out-of-range raw buffer
 // load returns 0 instead of faulting, so (a) the kGatherUnroll attribute ids of a gene are loaded
 // unconditionally (the ones past the gene's run belong to the next genes or lie past the end of
@@ -230,13 +247,13 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 5 : 3)) crf_windowed_l2(cons
             reinterpret_cast<f64x2 *>(P.state_out)[gene0] = P.label ? f64x2{s00, s01} : f64x2{s01, s00};
         {
             const double d = s01 - s00;
-            const double e = exp(-fabs(d));
+            const double e = exp_neg(fabs(d), P.expc);
             const double e1 = d > 0.0 ? 1.0 : e;
             sm.ef[tid] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
         }
         if (has1) {
             const double d = s11 - s10;
-            const double e = exp(-fabs(d));
+            const double e = exp_neg(fabs(d), P.expc);
             const double e1 = d > 0.0 ? 1.0 : e;
             sm.ef[NT + tid] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
         }
@@ -246,72 +263,135 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 5 : 3)) crf_windowed_l2(cons
     const int my_gene = gene0;
     const uint32_t rmask = P.rescale_mask;
 
-    // ---- stage 2a: forward recursion, all W alpha pairs stay in registers
-    double A0[WMAX], A1[WMAX];
     const double rho = P.rho;
-    double a0, a1;
-    {
-        const f64x2 ef = sm.ef[tid];
-        a0 = ef.x;
-        a1 = ef.y * P.kappa_over_mu01;  // kappa * e1
-    }
-    A0[0] = a0;
-    A1[0] = a1;
-#pragma unroll
-    for (int k = 1; k < WMAX; ++k) {
-        if (EXACT || k < W) {
-            const f64x2 ef = sm.ef[tid + k];
-            const double t = a0 + a1;
-            const double n1 = fma(a1, rho, a0) * ef.y;
-            a0 = t * ef.x;
-            a1 = n1;
-            if (RESCALE && ((rmask >> k) & 1u)) rescale_pair(a0, a1);
-            A0[k] = a0;
-            A1[k] = a1;
+    if constexpr (!RESCALE) {
+        // ---- stage 2a: forward recursion.  Without rescaling the un-normalised vectors satisfy
+        //   alpha_k[0] beta_k[0] + alpha_k[1] beta_k[1] = Z   at EVERY position k of the window
+        // (all per-position scale factors and the basis change cancel), so the marginal of the
+        // queried label at position k is x_k / Z with x_k = alpha_k[label] beta_k[label] and one
+        // reciprocal per window: only the label component of alpha has to be kept (W doubles).
+        double A1[WMAX];
+        double a0, a1;
+        {
+            const f64x2 ef = sm.ef[tid];
+            a0 = ef.x;
+            a1 = ef.y * P.kappa_over_mu01;  // kappa * e1
         }
-    }
-
-    // the backward pass re-reads the slot constants from LDS; without this the compiler
-    // keeps all of them live across both passes (+40 VGPRs, one wave per SIMD less)
-    asm volatile("" ::: "memory");
-
-    // ---- stage 2b + 3: backward recursion, candidates, diagonal max via DPP shifts
-    double b0 = 1.0, b1 = P.inv_kappa;
-    // running best candidate; (0, 0) = "no window yet" so that DPP zero-fill is the identity
-    double Rx = 0.0, Ry = 0.0;
+        A1[0] = a1;
 #pragma unroll
-    for (int k = WMAX - 1; k >= 0; --k) {
-        if (EXACT || k < W) {
-            const double x = A1[k] * b1;
-            const double y = A0[k] * b0;
-            if (k < W - 1) {
-                if (lane == 63 && wave < NT / 64 - 1) sm.carry[wave][k] = f64x2{Rx, Ry};
-                Rx = wave_shr1_zero(Rx);
-                Ry = wave_shr1_zero(Ry);
-            }
-            // x/y >= Rx/Ry by cross-multiplication; always true against the (0,0) identity
-            const bool take = my_start && (x * Ry >= Rx * y);
-            Rx = take ? x : Rx;
-            Ry = take ? y : Ry;
-            if (k > 0) {
+        for (int k = 1; k < WMAX; ++k) {
+            if (EXACT || k < W) {
                 const f64x2 ef = sm.ef[tid + k];
-                const double c = ef.x * b0, u = ef.y * b1;
-                b0 = c + u;
-                b1 = fma(u, rho, c);
-                if (RESCALE && ((rmask >> k) & 1u)) rescale_pair(b0, b1);
+                const double t = a0 + a1;
+                a1 = fma(a1, rho, a0) * ef.y;
+                a0 = t * ef.x;
+                A1[k] = a1;
             }
         }
-    }
-    __syncthreads();
-    if (wave > 0 && lane < W - 1) {
-        const f64x2 c = sm.carry[wave - 1][lane];
-        if (c.x * Ry > Rx * c.y || (Rx == 0.0 && Ry == 0.0)) {
-            Rx = c.x;
-            Ry = c.y;
+        asm volatile("" ::: "memory");  // re-read the slot constants in the backward pass (VGPRs)
+
+        // ---- stage 2b + 3: backward recursion; candidate k of lane s is P(slot s+k) in window s.
+        // The maximum over windows is a diagonal reduction: the running best moves one lane up per
+        // step (DPP wave_shr:1, zero fill = "no window yet" = numpy.zeros) and meets the candidate.
+        // 1/Z goes into the initial beta (the backward recursion is linear), so a candidate is one
+        // multiplication; lanes that may not start a window get beta = 0, i.e. candidates 0 = the
+        // identity of the maximum.  Reciprocal: v_rcp_f64 + one Newton step (< 1 ulp from exact).
+        double b0, b1;
+        {
+            const double z = fma(a1, P.inv_kappa, a0);
+            double r = __builtin_amdgcn_rcp(z);
+            r = fma(fma(-z, r, 1.0), r, r);
+            b0 = my_start ? r : 0.0;
+            b1 = b0 * P.inv_kappa;
         }
+        double R = 0.0;
+        double *carry = reinterpret_cast<double *>(&sm.carry[0][0]);
+#pragma unroll
+        for (int k = WMAX - 1; k >= 0; --k) {
+            if (EXACT || k < W) {
+                const double cand = A1[k] * b1;
+                if (k < W - 1) {
+                    if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
+                    R = wave_shr1_zero(R);
+                }
+                R = fmax(R, cand);
+                if (k > 0) {
+                    const f64x2 ef = sm.ef[tid + k];
+                    const double c = ef.x * b0, u = ef.y * b1;
+                    b0 = c + u;
+                    b1 = fma(u, rho, c);
+                }
+            }
+        }
+        __syncthreads();
+        if (wave > 0 && lane < W - 1) R = fmax(R, carry[(wave - 1) * WMAX + lane]);
+        R = fmin(R, 1.0);  // x_k and Z are rounded independently: x_k / Z may land one ulp above 1
+        // genes no window covers (step > 1) keep 0.0 like numpy.zeros (crf/__init__.py:251)
+        if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = R;
+    } else {
+        // ---- rescaling variant (transition weights far apart): power-of-two renormalisation at the
+        // flagged steps changes Z from position to position, so candidates stay un-normalised pairs
+        // (x, y) = (alpha[label] beta[label], alpha[other] beta[other]) compared by cross-multiplication
+        // (x1*y2 > x2*y1); the only division is the final x/(x+y) per gene.
+        double A0[WMAX], A1[WMAX];
+        double a0, a1;
+        {
+            const f64x2 ef = sm.ef[tid];
+            a0 = ef.x;
+            a1 = ef.y * P.kappa_over_mu01;  // kappa * e1
+        }
+        A0[0] = a0;
+        A1[0] = a1;
+#pragma unroll
+        for (int k = 1; k < WMAX; ++k) {
+            if (EXACT || k < W) {
+                const f64x2 ef = sm.ef[tid + k];
+                const double t = a0 + a1;
+                const double n1 = fma(a1, rho, a0) * ef.y;
+                a0 = t * ef.x;
+                a1 = n1;
+                if ((rmask >> k) & 1u) rescale_pair(a0, a1);
+                A0[k] = a0;
+                A1[k] = a1;
+            }
+        }
+        asm volatile("" ::: "memory");
+        double b0 = 1.0, b1 = P.inv_kappa;
+        // running best candidate; (0, 0) = "no window yet" so that DPP zero-fill is the identity
+        double Rx = 0.0, Ry = 0.0;
+#pragma unroll
+        for (int k = WMAX - 1; k >= 0; --k) {
+            if (EXACT || k < W) {
+                const double x = A1[k] * b1;
+                const double y = A0[k] * b0;
+                if (k < W - 1) {
+                    if (lane == 63 && wave < NT / 64 - 1) sm.carry[wave][k] = f64x2{Rx, Ry};
+                    Rx = wave_shr1_zero(Rx);
+                    Ry = wave_shr1_zero(Ry);
+                }
+                // x/y >= Rx/Ry by cross-multiplication; always true against the (0,0) identity
+                const bool take = my_start && (x * Ry >= Rx * y);
+                Rx = take ? x : Rx;
+                Ry = take ? y : Ry;
+                if (k > 0) {
+                    const f64x2 ef = sm.ef[tid + k];
+                    const double c = ef.x * b0, u = ef.y * b1;
+                    b0 = c + u;
+                    b1 = fma(u, rho, c);
+                    if ((rmask >> k) & 1u) rescale_pair(b0, b1);
+                }
+            }
+        }
+        __syncthreads();
+        if (wave > 0 && lane < W - 1) {
+            const f64x2 c = sm.carry[wave - 1][lane];
+            if (c.x * Ry > Rx * c.y || (Rx == 0.0 && Ry == 0.0)) {
+                Rx = c.x;
+                Ry = c.y;
+            }
+        }
+        if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = (Rx + Ry > 0.0) ? Rx / (Rx + Ry) : 0.0;
     }
-    // genes no window covers (step > 1) keep 0.0 like numpy.zeros (crf/__init__.py:251)
-    if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = (Rx + Ry > 0.0) ? Rx / (Rx + Ry) : 0.0;
 }
 
 // ---- generic window kernel (2 labels, ANY window size, ANY transition spread) -------------

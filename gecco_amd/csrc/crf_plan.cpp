@@ -379,6 +379,13 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
         a.g10 = G(label, o);
         a.g11 = G(label, label);
     }
+    {
+        double f = 1.0;  // k!
+        for (int k = 2; k <= 13; ++k) {
+            f *= double(k);
+            a.expc[13 - k] = 1.0 / f;
+        }
+    }
     a.generic = p.fast_ok ? 0 : 1;
     if (a.generic) {
         if (!p.d_win_scratch &&
