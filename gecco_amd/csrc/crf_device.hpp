@@ -23,6 +23,7 @@ struct WinArgs {
     double2 *state_out;        // [n_genes] or null: raw state scores (s[0], s[1]) as a by-product (fast L == 2 kernel)
     int32_t K, S, ntiles, W, step, L, label;
     int32_t n_genes, A;        // CSR extent and weight-table rows (buffer descriptors)
+    int32_t tiles_per_wg;      // DP phases per workgroup of the fast kernel (plan geometry)
     uint32_t rescale_mask;     // bit k: renormalise the DP vectors after step k
     // transitions in the transformed basis (rows/cols ordered (other, label)):
     //   mu01 = m01*m10/m00^2, mu11 = m11/m00, kappa = m10/m00, rho = mu11/mu01  with m = exp(trans)
@@ -37,6 +38,7 @@ struct WinArgs {
 // Geometry of the fast L==2 kernel.
 constexpr int kWinThreads = 256;  // lanes (= window starts) per workgroup: 4 waves, 5 workgroups per CU at <= 96 VGPRs
 constexpr int kWinMaxW = 32;      // largest window the register-resident kernel handles
+constexpr int kWinTilesPerWg = 2; // default DP phases per workgroup (GECCO_CRF_TILES_PER_WG=1..3 overrides; A/B runs)
 
 // ---- whole-contig kernels (crf_sequence.hip) ------------------------------------------------
 constexpr int kSeqGenesPerLane = 8;  // genes folded sequentially by one lane of the flat scans
@@ -118,7 +120,7 @@ hipError_t launch_composition(const int32_t *d_seg, int n_seg, const int32_t *d_
 
 const char *windowed_kernel_name(int W, int L, bool fast);
 // tile_out = output slots per workgroup for the kernel that (W, L) dispatches to.
-int windowed_tile_out(int W, int L);
+int windowed_tile_out(int W, int L, int tiles_per_wg);
 hipError_t launch_windowed(const WinArgs &a, hipStream_t stream);
 hipError_t launch_fill_nan(double *p, const int2 *ranges, int n_ranges, hipStream_t stream);
 

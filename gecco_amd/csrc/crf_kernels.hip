@@ -64,13 +64,21 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kGatherUnroll = 8;  // attribute loads in flight per slot before the first use
 
-template <int WMAX, int NT>
+// A workgroup of NT lanes owns TT consecutive "tiles": TT*(NT-(W-1)) output slots, for which it
+// needs the slot constants of those slots plus W-1 on either side.  Stage 1 runs ONCE for all of
+// them (every lane owns JMAX slots and has their dependent load chains in flight together: the
+// chain of four memory round trips is what a workgroup spends most of its life on), then TT DP
+// phases of NT window starts each.
+template <int WMAX, int NT, int TT>
 struct WinSmem {
-    f64x2 ef[NT + WMAX - 1];        // per slot: (e0, f = mu01*e1)   with e = exp(s - max s), "other" first
+    static constexpr int JMAX = TT == 1 ? 2 : TT;             // slots a lane may own
+    static constexpr int CAP = TT == 1 ? NT + WMAX - 1 : TT * NT;  // slot capacity of the workgroup
+    f64x2 ef[CAP];                  // per slot: (e0, f = mu01*e1)   with e = exp(s - max s), "other" first
+    uint32_t ginfo[CAP];            // per slot: bit 31 = a window may start here; low bits = gene + 1 (0: none)
     f64x2 carry[NT / 64][WMAX];     // running best leaving lane 63 of each wave, per step
-    int32_t cslot[NT + WMAX + 1];   // slot offsets of the contigs this tile overlaps
-    int32_t cgene[NT + WMAX];
-    int32_t cn[NT + WMAX];
+    int32_t cslot[CAP + 2];         // slot offsets of the contigs this workgroup overlaps (irregular tiles)
+    int32_t cgene[CAP + 1];
+    int32_t cn[CAP + 1];
 };
 
 struct SlotInfo {
@@ -175,31 +183,39 @@ __device__ __forceinline__ void state_scores_buf(__amdgpu_buffer_rsrc_t ra, __am
 //   backward: c = e0 * b0;  b0' = c + f * b1;  b1' = c + g * b1
 //   candidate for slot s+k: x = a1 * b1 (label), y = a0 * b0 (other); all scale factors cancel
 //   in x / (x + y).
-template <int WMAX, bool EXACT, bool RESCALE, int NT>
+template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT>
 __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 5 : 3)) crf_windowed_l2(const WinArgs P) {
-    using Smem = WinSmem<WMAX, NT>;
+    using Smem = WinSmem<WMAX, NT, TT>;
+    constexpr int JMAX = Smem::JMAX;
     __shared__ Smem sm;
     const int W = EXACT ? WMAX : P.W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_remap(blockIdx.x, P.ntiles);
-    const int q0 = tile * (NT - (W - 1)) - (W - 1);  // slot owned by lane 0
+    const int OUT = NT - (W - 1);             // output slots of one DP phase
+    const int ns = TT * OUT + 2 * (W - 1);    // slots this workgroup needs constants for
+    const int q0 = tile * (TT * OUT) - (W - 1);  // slot owned by lane 0
 
-    // ---- slot -> gene.  A "regular" tile (no padded or skipped contig in reach: the normal
+    // ---- slot -> gene.  A "regular" workgroup (no padded or skipped contig in reach: the normal
     // case) maps slots to genes by a constant shift and takes its window-start flags from a
     // host-built bit array, so the CSR loads can leave immediately; otherwise the contig
-    // table of the tile goes through LDS and every lane searches it.
+    // table of its reach goes through LDS and every lane searches it.
     const int4 td = P.tile_desc[tile];  // (gene - slot shift, first contig, last contig, flags)
-    const bool has1 = tid < W - 1;      // first W-1 lanes also own tail slot NT + tid
-    int gene0 = -1, gene1 = -1;
-    bool my_start = false;
+    int gene[JMAX];
+    bool start[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        gene[j] = -1;
+        start[j] = false;
+    }
     if (td.w & 1) {
-        const int q = q0 + tid;
-        if (q >= 0 && q < P.S) {
-            gene0 = q + td.x;
-            my_start = (P.start_bits[q >> 6] >> (q & 63)) & 1ull;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int sl = tid + j * NT, q = q0 + sl;
+            if (sl < ns && q >= 0 && q < P.S) {
+                gene[j] = q + td.x;
+                start[j] = (P.start_bits[q >> 6] >> (q & 63)) & 1ull;
+            }
         }
-        const int q1 = q0 + NT + tid;
-        if (has1 && q1 < P.S) gene1 = q1 + td.x;
     } else {
         const int cnt = td.z - td.y + 1;
         for (int j = tid; j <= cnt; j += NT) {
@@ -210,14 +226,19 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 5 : 3)) crf_windowed_l2(cons
             }
         }
         __syncthreads();
-        const SlotInfo si0 = slot_lookup(sm, cnt, q0 + tid, P.S, W, P.step);
-        gene0 = si0.gene;
-        my_start = si0.start_ok;
-        if (has1) gene1 = slot_lookup(sm, cnt, q0 + NT + tid, P.S, W, P.step).gene;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int sl = tid + j * NT;
+            if (sl < ns) {
+                const SlotInfo si = slot_lookup(sm, cnt, q0 + sl, P.S, W, P.step);
+                gene[j] = si.gene;
+                start[j] = si.start_ok;
+            }
+        }
     }
 
-    // buffer descriptors: attribute ids relative to the tile's first run (keeps byte offsets in 32
-    // bits for any batch), the weight-pair table whole.  All operands are wave-uniform (SGPRs).
+    // buffer descriptors: attribute ids relative to the workgroup's first run (keeps byte offsets in
+    // 32 bits for any batch), the weight-pair table whole.  All operands are wave-uniform (SGPRs).
     const uint32_t nnz = uint32_t(P.gene_ptr[P.n_genes]);
     const int g_first = (td.w & 1) ? (q0 > 0 ? q0 : 0) + td.x : P.c_gene[td.y];
     const uint32_t lo_tile = uint32_t(P.gene_ptr[g_first]);
@@ -227,170 +248,199 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 5 : 3)) crf_windowed_l2(cons
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(P.wtab2), 0, uint32_t(P.A) << 4, 0x00020000);
 
-    // ---- stage 1: CSR row bounds -> state scores -> slot constants in LDS
-    int lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
-    if (gene0 >= 0) {
-        lo0 = P.gene_ptr[gene0];
-        hi0 = P.gene_ptr[gene0 + 1];
-    }
-    if (gene1 >= 0) {
-        lo1 = P.gene_ptr[gene1];
-        hi1 = P.gene_ptr[gene1 + 1];
-    }
-    {
-        double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
-        state_scores_buf(ra, rw, uint32_t(lo0) - lo_tile, uint32_t(hi0 - lo0), s00, s01);
-        if (wave == 0) state_scores_buf(ra, rw, uint32_t(lo1) - lo_tile, uint32_t(hi1 - lo1), s10, s11);
-        // decode = windowed marginals + Viterbi of the same batch: the raw scores of the genes this
-        // tile owns are handed to the whole-contig kernels instead of being gathered a second time
-        if (P.state_out && tid >= W - 1 && gene0 >= 0)
-            reinterpret_cast<f64x2 *>(P.state_out)[gene0] = P.label ? f64x2{s00, s01} : f64x2{s01, s00};
-        {
-            const double d = s01 - s00;
-            const double e = exp_neg(fabs(d), P.expc);
-            const double e1 = d > 0.0 ? 1.0 : e;
-            sm.ef[tid] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
+    // ---- stage 1: CSR row bounds -> attribute ids -> weight pairs -> slot constants in LDS.
+    // The row bounds and then the first kGatherUnroll attribute ids of ALL of the lane's slots are
+    // requested before anything is waited for.
+    uint32_t off[JMAX], cnt[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        int lo = 0, hi = 0;
+        if (gene[j] >= 0) {
+            lo = P.gene_ptr[gene[j]];
+            hi = P.gene_ptr[gene[j] + 1];
         }
-        if (has1) {
-            const double d = s11 - s10;
-            const double e = exp_neg(fabs(d), P.expc);
-            const double e1 = d > 0.0 ? 1.0 : e;
-            sm.ef[NT + tid] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
+        off[j] = uint32_t(lo) - lo_tile;
+        cnt[j] = uint32_t(hi - lo);
+    }
+    int ids[JMAX][kGatherUnroll];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j)
+        if (TT > 1 || j == 0 || wave == 0) {
+#pragma unroll
+            for (int u = 0; u < kGatherUnroll; ++u)
+                ids[j][u] = __builtin_amdgcn_raw_buffer_load_b32(ra, int((off[j] + u) << 2), 0, 0);
+        }
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        if (TT > 1 || j == 0 || wave == 0) {
+            const int sl = tid + j * NT;
+            double s0 = 0.0, s1 = 0.0;
+            i32x4 w[kGatherUnroll];
+#pragma unroll
+            for (int u = 0; u < kGatherUnroll; ++u) {
+                const uint32_t wo = uint32_t(u) < cnt[j] ? uint32_t(ids[j][u]) << 4 : 0xFFFFFFF0u;
+                w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, int(wo), 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < kGatherUnroll; ++u) {
+                s0 += __hiloint2double(w[u].y, w[u].x);
+                s1 += __hiloint2double(w[u].w, w[u].z);
+            }
+            if (cnt[j] > uint32_t(kGatherUnroll))  // rare: a gene with more than 8 domains
+                state_scores_buf(ra, rw, off[j] + kGatherUnroll, cnt[j] - kGatherUnroll, s0, s1);
+            // decode = windowed marginals + Viterbi of the same batch: the raw scores of the genes this
+            // workgroup owns are handed to the whole-contig kernels instead of being gathered again
+            if (P.state_out && sl >= W - 1 && sl < TT * OUT + (W - 1) && gene[j] >= 0)
+                reinterpret_cast<f64x2 *>(P.state_out)[gene[j]] = P.label ? f64x2{s0, s1} : f64x2{s1, s0};
+            if (sl < ns) {
+                const double d = s1 - s0;
+                const double e = exp_neg(fabs(d), P.expc);
+                const double e1 = d > 0.0 ? 1.0 : e;
+                sm.ef[sl] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
+                sm.ginfo[sl] = (start[j] ? 0x80000000u : 0u) | uint32_t(gene[j] + 1);
+            }
         }
     }
     __syncthreads();
 
-    const int my_gene = gene0;
     const uint32_t rmask = P.rescale_mask;
-
     const double rho = P.rho;
-    if constexpr (!RESCALE) {
-        // ---- stage 2a: forward recursion.  Without rescaling the un-normalised vectors satisfy
-        //   alpha_k[0] beta_k[0] + alpha_k[1] beta_k[1] = Z   at EVERY position k of the window
-        // (all per-position scale factors and the basis change cancel), so the marginal of the
-        // queried label at position k is x_k / Z with x_k = alpha_k[label] beta_k[label] and one
-        // reciprocal per window: only the label component of alpha has to be kept (W doubles).
-        double A1[WMAX];
-        double a0, a1;
-        {
-            const f64x2 ef = sm.ef[tid];
-            a0 = ef.x;
-            a1 = ef.y * P.kappa_over_mu01;  // kappa * e1
-        }
-        A1[0] = a1;
-#pragma unroll
-        for (int k = 1; k < WMAX; ++k) {
-            if (EXACT || k < W) {
-                const f64x2 ef = sm.ef[tid + k];
-                const double t = a0 + a1;
-                a1 = fma(a1, rho, a0) * ef.y;
-                a0 = t * ef.x;
-                A1[k] = a1;
+#pragma unroll 1
+    for (int ph = 0; ph < TT; ++ph) {
+        const int sbase = ph * OUT + tid;  // slot of this lane's window start (and of its output)
+        const uint32_t gi = sm.ginfo[sbase];
+        const bool my_start = gi >> 31;
+        const int my_gene = int(gi & 0x7fffffffu) - 1;
+        const f64x2 *ef = sm.ef + sbase;
+        if constexpr (!RESCALE) {
+            // ---- stage 2a: forward recursion.  Without rescaling the un-normalised vectors satisfy
+            //   alpha_k[0] beta_k[0] + alpha_k[1] beta_k[1] = Z   at EVERY position k of the window
+            // (all per-position scale factors and the basis change cancel), so the marginal of the
+            // queried label at position k is x_k / Z with x_k = alpha_k[label] beta_k[label] and one
+            // reciprocal per window: only the label component of alpha has to be kept (W doubles).
+            double A1[WMAX];
+            double a0, a1;
+            {
+                const f64x2 c = ef[0];
+                a0 = c.x;
+                a1 = c.y * P.kappa_over_mu01;  // kappa * e1
             }
-        }
-        asm volatile("" ::: "memory");  // re-read the slot constants in the backward pass (VGPRs)
+            A1[0] = a1;
+#pragma unroll
+            for (int k = 1; k < WMAX; ++k) {
+                if (EXACT || k < W) {
+                    const f64x2 c = ef[k];
+                    const double t = a0 + a1;
+                    a1 = fma(a1, rho, a0) * c.y;
+                    a0 = t * c.x;
+                    A1[k] = a1;
+                }
+            }
+            asm volatile("" ::: "memory");  // re-read the slot constants in the backward pass (VGPRs)
 
-        // ---- stage 2b + 3: backward recursion; candidate k of lane s is P(slot s+k) in window s.
-        // The maximum over windows is a diagonal reduction: the running best moves one lane up per
-        // step (DPP wave_shr:1, zero fill = "no window yet" = numpy.zeros) and meets the candidate.
-        // 1/Z goes into the initial beta (the backward recursion is linear), so a candidate is one
-        // multiplication; lanes that may not start a window get beta = 0, i.e. candidates 0 = the
-        // identity of the maximum.  Reciprocal: v_rcp_f64 + one Newton step (< 1 ulp from exact).
-        double b0, b1;
-        {
-            const double z = fma(a1, P.inv_kappa, a0);
-            double r = __builtin_amdgcn_rcp(z);
-            r = fma(fma(-z, r, 1.0), r, r);
-            b0 = my_start ? r : 0.0;
-            b1 = b0 * P.inv_kappa;
-        }
-        double R = 0.0;
-        double *carry = reinterpret_cast<double *>(&sm.carry[0][0]);
+            // ---- stage 2b + 3: backward recursion; candidate k of lane s is P(slot s+k) in window s.
+            // The maximum over windows is a diagonal reduction: the running best moves one lane up per
+            // step (DPP wave_shr:1, zero fill = "no window yet" = numpy.zeros) and meets the candidate.
+            // 1/Z goes into the initial beta (the backward recursion is linear), so a candidate is one
+            // multiplication; lanes that may not start a window get beta = 0, i.e. candidates 0 = the
+            // identity of the maximum.  Reciprocal: v_rcp_f64 + one Newton step (< 1 ulp from exact).
+            double b0, b1;
+            {
+                const double z = fma(a1, P.inv_kappa, a0);
+                double r = __builtin_amdgcn_rcp(z);
+                r = fma(fma(-z, r, 1.0), r, r);
+                b0 = my_start ? r : 0.0;
+                b1 = b0 * P.inv_kappa;
+            }
+            double R = 0.0;
+            double *carry = reinterpret_cast<double *>(&sm.carry[0][0]);
 #pragma unroll
-        for (int k = WMAX - 1; k >= 0; --k) {
-            if (EXACT || k < W) {
-                const double cand = A1[k] * b1;
-                if (k < W - 1) {
-                    if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
-                    R = wave_shr1_zero(R);
-                }
-                R = fmax(R, cand);
-                if (k > 0) {
-                    const f64x2 ef = sm.ef[tid + k];
-                    const double c = ef.x * b0, u = ef.y * b1;
-                    b0 = c + u;
-                    b1 = fma(u, rho, c);
+            for (int k = WMAX - 1; k >= 0; --k) {
+                if (EXACT || k < W) {
+                    const double cand = A1[k] * b1;
+                    if (k < W - 1) {
+                        if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
+                        R = wave_shr1_zero(R);
+                    }
+                    R = fmax(R, cand);
+                    if (k > 0) {
+                        const f64x2 c = ef[k];
+                        const double cc = c.x * b0, u = c.y * b1;
+                        b0 = cc + u;
+                        b1 = fma(u, rho, cc);
+                    }
                 }
             }
-        }
-        __syncthreads();
-        if (wave > 0 && lane < W - 1) R = fmax(R, carry[(wave - 1) * WMAX + lane]);
-        R = fmin(R, 1.0);  // x_k and Z are rounded independently: x_k / Z may land one ulp above 1
-        // genes no window covers (step > 1) keep 0.0 like numpy.zeros (crf/__init__.py:251)
-        if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = R;
-    } else {
-        // ---- rescaling variant (transition weights far apart): power-of-two renormalisation at the
-        // flagged steps changes Z from position to position, so candidates stay un-normalised pairs
-        // (x, y) = (alpha[label] beta[label], alpha[other] beta[other]) compared by cross-multiplication
-        // (x1*y2 > x2*y1); the only division is the final x/(x+y) per gene.
-        double A0[WMAX], A1[WMAX];
-        double a0, a1;
-        {
-            const f64x2 ef = sm.ef[tid];
-            a0 = ef.x;
-            a1 = ef.y * P.kappa_over_mu01;  // kappa * e1
-        }
-        A0[0] = a0;
-        A1[0] = a1;
+            __syncthreads();
+            if (wave > 0 && lane < W - 1) R = fmax(R, carry[(wave - 1) * WMAX + lane]);
+            R = fmin(R, 1.0);  // x_k and Z are rounded independently: x_k / Z may land one ulp above 1
+            // genes no window covers (step > 1) keep 0.0 like numpy.zeros (crf/__init__.py:251)
+            if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = R;
+        } else {
+            // ---- rescaling variant (transition weights far apart): power-of-two renormalisation at the
+            // flagged steps changes Z from position to position, so candidates stay un-normalised pairs
+            // (x, y) = (alpha[label] beta[label], alpha[other] beta[other]) compared by cross-multiplication
+            // (x1*y2 > x2*y1); the only division is the final x/(x+y) per gene.
+            double A0[WMAX], A1[WMAX];
+            double a0, a1;
+            {
+                const f64x2 c = ef[0];
+                a0 = c.x;
+                a1 = c.y * P.kappa_over_mu01;  // kappa * e1
+            }
+            A0[0] = a0;
+            A1[0] = a1;
 #pragma unroll
-        for (int k = 1; k < WMAX; ++k) {
-            if (EXACT || k < W) {
-                const f64x2 ef = sm.ef[tid + k];
-                const double t = a0 + a1;
-                const double n1 = fma(a1, rho, a0) * ef.y;
-                a0 = t * ef.x;
-                a1 = n1;
-                if ((rmask >> k) & 1u) rescale_pair(a0, a1);
-                A0[k] = a0;
-                A1[k] = a1;
+            for (int k = 1; k < WMAX; ++k) {
+                if (EXACT || k < W) {
+                    const f64x2 c = ef[k];
+                    const double t = a0 + a1;
+                    const double n1 = fma(a1, rho, a0) * c.y;
+                    a0 = t * c.x;
+                    a1 = n1;
+                    if ((rmask >> k) & 1u) rescale_pair(a0, a1);
+                    A0[k] = a0;
+                    A1[k] = a1;
+                }
             }
-        }
-        asm volatile("" ::: "memory");
-        double b0 = 1.0, b1 = P.inv_kappa;
-        // running best candidate; (0, 0) = "no window yet" so that DPP zero-fill is the identity
-        double Rx = 0.0, Ry = 0.0;
+            asm volatile("" ::: "memory");
+            double b0 = 1.0, b1 = P.inv_kappa;
+            // running best candidate; (0, 0) = "no window yet" so that DPP zero-fill is the identity
+            double Rx = 0.0, Ry = 0.0;
 #pragma unroll
-        for (int k = WMAX - 1; k >= 0; --k) {
-            if (EXACT || k < W) {
-                const double x = A1[k] * b1;
-                const double y = A0[k] * b0;
-                if (k < W - 1) {
-                    if (lane == 63 && wave < NT / 64 - 1) sm.carry[wave][k] = f64x2{Rx, Ry};
-                    Rx = wave_shr1_zero(Rx);
-                    Ry = wave_shr1_zero(Ry);
-                }
-                // x/y >= Rx/Ry by cross-multiplication; always true against the (0,0) identity
-                const bool take = my_start && (x * Ry >= Rx * y);
-                Rx = take ? x : Rx;
-                Ry = take ? y : Ry;
-                if (k > 0) {
-                    const f64x2 ef = sm.ef[tid + k];
-                    const double c = ef.x * b0, u = ef.y * b1;
-                    b0 = c + u;
-                    b1 = fma(u, rho, c);
-                    if ((rmask >> k) & 1u) rescale_pair(b0, b1);
+            for (int k = WMAX - 1; k >= 0; --k) {
+                if (EXACT || k < W) {
+                    const double x = A1[k] * b1;
+                    const double y = A0[k] * b0;
+                    if (k < W - 1) {
+                        if (lane == 63 && wave < NT / 64 - 1) sm.carry[wave][k] = f64x2{Rx, Ry};
+                        Rx = wave_shr1_zero(Rx);
+                        Ry = wave_shr1_zero(Ry);
+                    }
+                    // x/y >= Rx/Ry by cross-multiplication; always true against the (0,0) identity
+                    const bool take = my_start && (x * Ry >= Rx * y);
+                    Rx = take ? x : Rx;
+                    Ry = take ? y : Ry;
+                    if (k > 0) {
+                        const f64x2 c = ef[k];
+                        const double cc = c.x * b0, u = c.y * b1;
+                        b0 = cc + u;
+                        b1 = fma(u, rho, cc);
+                        if ((rmask >> k) & 1u) rescale_pair(b0, b1);
+                    }
                 }
             }
-        }
-        __syncthreads();
-        if (wave > 0 && lane < W - 1) {
-            const f64x2 c = sm.carry[wave - 1][lane];
-            if (c.x * Ry > Rx * c.y || (Rx == 0.0 && Ry == 0.0)) {
-                Rx = c.x;
-                Ry = c.y;
+            __syncthreads();
+            if (wave > 0 && lane < W - 1) {
+                const f64x2 c = sm.carry[wave - 1][lane];
+                if (c.x * Ry > Rx * c.y || (Rx == 0.0 && Ry == 0.0)) {
+                    Rx = c.x;
+                    Ry = c.y;
+                }
             }
+            if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = (Rx + Ry > 0.0) ? Rx / (Rx + Ry) : 0.0;
         }
-        if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = (Rx + Ry > 0.0) ? Rx / (Rx + Ry) : 0.0;
+        if (TT > 1) __syncthreads();  // the carry slots are reused by the next phase
     }
 }
 
@@ -482,28 +532,39 @@ const char *windowed_kernel_name(int W, int L, bool fast) {
     return "unsupported";
 }
 
-int windowed_tile_out(int W, int L) {
-    if (L == 2 && W <= kWinMaxW) return kWinThreads - (W - 1);
+int windowed_tile_out(int W, int L, int tt) {
+    if (L == 2 && W <= kWinMaxW) return tt * (kWinThreads - (W - 1));
     return kWinThreads;
+}
+
+template <int TT>
+static hipError_t launch_windowed_tt(const WinArgs &a, hipStream_t stream) {
+    const dim3 grid(a.ntiles), block(kWinThreads);
+    if (a.W == 20 && a.rescale_mask == 0) {
+        hipLaunchKernelGGL((crf_windowed_l2<20, true, false, kWinThreads, TT>), grid, block, 0, stream, a);
+    } else if (a.W == 20) {
+        hipLaunchKernelGGL((crf_windowed_l2<20, true, true, kWinThreads, TT>), grid, block, 0, stream, a);
+    } else if (a.rescale_mask == 0) {
+        hipLaunchKernelGGL((crf_windowed_l2<kWinMaxW, false, false, kWinThreads, TT>), grid, block, 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((crf_windowed_l2<kWinMaxW, false, true, kWinThreads, TT>), grid, block, 0, stream, a);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_windowed(const WinArgs &a, hipStream_t stream) {
     if (a.ntiles <= 0) return hipSuccess;
-    const dim3 grid(a.ntiles), block(kWinThreads);
     if (a.L == 2 && a.generic) {
         hipLaunchKernelGGL(crf_windowed_generic_l2, dim3((a.S + 255) / 256), dim3(256), 0, stream, a);
-    } else if (a.L == 2 && a.W == 20 && a.rescale_mask == 0) {
-        hipLaunchKernelGGL((crf_windowed_l2<20, true, false, kWinThreads>), grid, block, 0, stream, a);
-    } else if (a.L == 2 && a.W == 20) {
-        hipLaunchKernelGGL((crf_windowed_l2<20, true, true, kWinThreads>), grid, block, 0, stream, a);
-    } else if (a.L == 2 && a.W <= kWinMaxW && a.rescale_mask == 0) {
-        hipLaunchKernelGGL((crf_windowed_l2<kWinMaxW, false, false, kWinThreads>), grid, block, 0, stream, a);
-    } else if (a.L == 2 && a.W <= kWinMaxW) {
-        hipLaunchKernelGGL((crf_windowed_l2<kWinMaxW, false, true, kWinThreads>), grid, block, 0, stream, a);
-    } else {
-        return hipErrorNotSupported;
+        return hipGetLastError();
     }
-    return hipGetLastError();
+    if (a.L != 2 || a.W > kWinMaxW) return hipErrorNotSupported;
+    switch (a.tiles_per_wg) {
+    case 1: return launch_windowed_tt<1>(a, stream);
+    case 2: return launch_windowed_tt<2>(a, stream);
+    case 3: return launch_windowed_tt<3>(a, stream);
+    default: return hipErrorNotSupported;
+    }
 }
 
 hipError_t launch_fill_nan(double *p, const int2 *ranges, int n_ranges, hipStream_t stream) {

@@ -200,7 +200,11 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     }
     if (p.force_generic) p.fast_ok = false;
     p.kernel_name = p.general ? "gl_windowed" : windowed_kernel_name(W, m.L, p.fast_ok);
-    p.tile_out = windowed_tile_out(W, m.L);
+    {
+        const char *env = std::getenv("GECCO_CRF_TILES_PER_WG");
+        p.tiles_per_wg = (env && env[0] >= '1' && env[0] <= '3' && !env[1]) ? env[0] - '0' : kWinTilesPerWg;
+    }
+    p.tile_out = windowed_tile_out(W, m.L, p.tiles_per_wg);
     p.ntiles = p.S > 0 ? (p.S + p.tile_out - 1) / p.tile_out : 0;
     // window-start flags per slot (_meta.py:131: starts at 0, step, 2*step, ... <= n' - W)
     p.start_bits.assign(size_t(p.S) / 64 + 2, 0);
@@ -222,7 +226,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     for (int32_t b = 0; b < p.ntiles; ++b) {
         const int64_t q0 = int64_t(b) * p.tile_out - (W - 1);
         const int64_t q_lo = std::max<int64_t>(q0, 0);
-        const int64_t q_hi = std::min<int64_t>(q0 + kWinThreads + W - 2, p.S - 1);
+        const int64_t q_hi = std::min<int64_t>(q0 + p.tile_out + 2 * (W - 1) - 1, p.S - 1);
         const int first = int(std::upper_bound(p.c_slot.begin(), p.c_slot.begin() + p.K, int32_t(q_lo)) - p.c_slot.begin()) - 1;
         const int last = int(std::upper_bound(p.c_slot.begin(), p.c_slot.begin() + p.K, int32_t(q_hi)) - p.c_slot.begin()) - 1;
         // regular: no padded contig in reach and no skipped contig between the contigs in reach
@@ -359,6 +363,7 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     a.label = label;
     a.n_genes = p.n_genes;
     a.A = m.A;
+    a.tiles_per_wg = p.tiles_per_wg;
     a.rescale_mask = p.rescale_mask;
     {
         // exp() of differences only: every constant is a ratio of transition weights

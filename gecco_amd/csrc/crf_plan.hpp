@@ -29,7 +29,7 @@ struct Plan {
     int32_t n_contigs = 0, n_genes = 0;
     int64_t n_windows = 0;
     // slot-space layout (host)
-    int32_t K = 0, S = 0, ntiles = 0, tile_out = 0;
+    int32_t K = 0, S = 0, ntiles = 0, tile_out = 0, tiles_per_wg = 1;
     std::vector<int32_t> c_slot, c_gene, c_n;
     std::vector<int4> tile_desc;
     std::vector<uint64_t> start_bits;

@@ -94,9 +94,10 @@ def test_host_only_plan_layout(blob):
     # contigs of 50, 10 (padded to 20) and 240 genes: windows = 31 + 1 + 221 (crf/__init__.py:239)
     p = nat.Plan(m, [0, 50, 60, 300], 20, 1, True, device=-1)
     assert (p.num_genes, p.num_windows) == (300, 253)
-    # 310 slots (the 10-gene contig is padded to 20); 256-lane workgroups emit 256-(W-1) slots each
-    assert p.num_tiles == 2 and "crf_windowed" in p.kernel_name
-    assert nat.Plan(m, [0, 5000], 20, 1, True, device=-1).num_tiles == -(-5000 // (256 - 19))
+    # 310 slots (the 10-gene contig is padded to 20); a 256-lane workgroup runs two DP phases of
+    # 256-(W-1) output slots each
+    assert p.num_tiles == 1 and "crf_windowed" in p.kernel_name
+    assert nat.Plan(m, [0, 5000], 20, 1, True, device=-1).num_tiles == -(-5000 // (2 * (256 - 19)))
     p = nat.Plan(m, [0, 50, 60, 300], 20, 1, False, device=-1)
     assert p.num_windows == 252
     p = nat.Plan(m, [0], 20, device=-1)
