@@ -235,20 +235,22 @@ class Model:
         )
         return marg[:n], ln[:nc]
 
-    def viterbi(self, contig_ptr, gene_ptr, attr_id, device=0):
+    def viterbi(self, contig_ptr, gene_ptr, attr_id, device=0, want_score=True):
+        """Best label path per contig; with `want_score=False` returns (labels, None) and 2-label
+        models take the cheaper score-difference form of the recursion."""
         contig_ptr, gene_ptr, attr_id = _i32(contig_ptr), _i32(gene_ptr), _i32(attr_id)
         n, nc = int(contig_ptr[-1]), len(contig_ptr) - 1
         y = np.zeros(max(n, 1), dtype=np.int8)
-        sc = np.zeros(max(nc, 1), dtype=np.float64)
+        sc = np.zeros(max(nc, 1), dtype=np.float64) if want_score else None
         if attr_id.size == 0:
             attr_id = np.zeros(1, dtype=np.int32)
         _check(
             self._lib.gecco_crf_viterbi(
                 self._h, device, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p), _ptr(attr_id, _c_i32p),
-                _ptr(y, _c_i8p), _ptr(sc, _c_f64p),
+                _ptr(y, _c_i8p), _ptr(sc, _c_f64p) if want_score else None,
             )
         )
-        return y[:n], sc[:nc]
+        return y[:n], (sc[:nc] if want_score else None)
 
 
 def domain_composition(seg, dom_ptr, dom_col, dom_weight, n_cols, normalize=True, device=0) -> np.ndarray:

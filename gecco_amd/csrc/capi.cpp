@@ -332,8 +332,8 @@ GECCO_API int gecco_crf_viterbi(const gecco_crf_model *m, int32_t device, const 
     DevBuf<int8_t> d_y;
     DevBuf<double> d_sc;
     if ((rc = d_y.alloc(n, "hipMalloc labels"))) return rc;
-    if ((rc = d_sc.alloc(size_t(n_contigs), "hipMalloc scores"))) return rc;
-    if ((rc = plan_run_viterbi(os.h.p, os.d_gp.p, os.d_at.p, d_y.p, d_sc.p, nullptr))) return rc;
+    if (score && (rc = d_sc.alloc(size_t(n_contigs), "hipMalloc scores"))) return rc;
+    if ((rc = plan_run_viterbi(os.h.p, os.d_gp.p, os.d_at.p, d_y.p, score ? d_sc.p : nullptr, nullptr))) return rc;
     if (n && y_out && (rc = check_hip(hipMemcpy(y_out, d_y.p, n, hipMemcpyDeviceToHost), "D2H labels"))) return rc;
     if (score && (rc = check_hip(hipMemcpy(score, d_sc.p, size_t(n_contigs) * 8, hipMemcpyDeviceToHost), "D2H scores")))
         return rc;

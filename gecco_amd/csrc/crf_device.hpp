@@ -21,6 +21,7 @@ struct WinArgs {
     const uint64_t *start_bits;// [S/64+1]     bit q: a window may start at slot q
     double *p_out;             // [n_genes]
     double2 *state_out;        // [n_genes] or null: raw state scores (s[0], s[1]) as a by-product (fast L == 2 kernel)
+    double *dstate_out;        // [n_genes] or null: s[1] - s[0] as a by-product
     int32_t K, S, ntiles, W, step, L, label;
     int32_t n_genes, A;        // CSR extent and weight-table rows (buffer descriptors)
     int32_t tiles_per_wg;      // DP phases per workgroup of the fast kernel (plan geometry)
@@ -52,13 +53,19 @@ struct FE {  // sum-product 2x2 scan element + power-of-two exponent + sum of em
     double a00, a01, a10, a11, ex, ms, rs;
 };
 
+struct CE {  // Viterbi of a 2-label model on score differences: Delta -> min(max(Delta + a, L), H)
+    double a, L, H;
+};
+
 struct SeqArgs {
     const double2 *state;    // [n_genes]  (s[label 0], s[label 1])
+    const double *dstate;    // [n_genes]  s[1] - s[0]: all the difference-form Viterbi needs (8 B/gene)
     const uint8_t *flags;    // [n_genes]  bit0: first gene of a contig, bit1: last gene
     int32_t n_contigs, n_genes;
     double m00, m01, m10, m11;  // exp(trans - mx)
     double t00, t01, t10, t11;  // raw transition weights (Viterbi)
     double mx;                  // max(trans)
+    double v_lo, v_hi, v_k;     // difference-form Viterbi: t01-t11, t00-t10, t11-t00
     // workspaces: one element per lane (n_genes / kSeqGenesPerLane) or per workgroup
     VE *vLane, *vBlock;
     uint32_t *vMaps, *vLaneMap, *vBlockMap;
@@ -76,6 +83,10 @@ hipError_t launch_seq_state(const int32_t *gene_ptr, const int32_t *attr_id, con
                             double2 *state, hipStream_t stream);
 hipError_t launch_seq_marginals(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream);
 hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream);
+// labels only, from a.dstate; needs trans[0][1] - trans[1][1] <= trans[0][0] - trans[1][0]
+hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream);
+hipError_t launch_seq_state_delta(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_genes,
+                                  double *dstate, hipStream_t stream);
 
 // row R on packed arrays (crf_segment.hip); d_work: 2*n_contigs int32 + n_contigs bytes
 hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const int32_t *d_cptr, int n_contigs, double threshold,

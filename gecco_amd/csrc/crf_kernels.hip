@@ -290,8 +290,10 @@ __global__ void __launch_bounds__(NT, (WMAX <= 20 ? 5 : 3)) crf_windowed_l2(cons
                 state_scores_buf(ra, rw, off[j] + kGatherUnroll, cnt[j] - kGatherUnroll, s0, s1);
             // decode = windowed marginals + Viterbi of the same batch: the raw scores of the genes this
             // workgroup owns are handed to the whole-contig kernels instead of being gathered again
-            if (P.state_out && sl >= W - 1 && sl < TT * OUT + (W - 1) && gene[j] >= 0)
-                reinterpret_cast<f64x2 *>(P.state_out)[gene[j]] = P.label ? f64x2{s0, s1} : f64x2{s1, s0};
+            if (sl >= W - 1 && sl < TT * OUT + (W - 1) && gene[j] >= 0) {
+                if (P.state_out) reinterpret_cast<f64x2 *>(P.state_out)[gene[j]] = P.label ? f64x2{s0, s1} : f64x2{s1, s0};
+                if (P.dstate_out) P.dstate_out[gene[j]] = P.label ? s1 - s0 : s0 - s1;
+            }
             if (sl < ns) {
                 const double d = s1 - s0;
                 const double e = exp_neg(fabs(d), P.expc);

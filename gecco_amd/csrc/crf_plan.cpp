@@ -315,15 +315,15 @@ int run_windowed_general(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_at
 }  // namespace
 
 static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
-                             double2 *d_state_out, hipStream_t stream);
+                             double2 *d_state_out, double *d_dstate_out, hipStream_t stream);
 
 int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                       hipStream_t stream) {
-    return run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, stream);
+    return run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, nullptr, stream);
 }
 
 static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
-                             double2 *d_state_out, hipStream_t stream) {
+                             double2 *d_state_out, double *d_dstate_out, hipStream_t stream) {
     if (p.device < 0) {
         set_error("host-only plan: no HIP device bound (there is no CPU fallback)");
         return GECCO_CRF_ENODEV;
@@ -354,6 +354,7 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     a.start_bits = p.d_start_bits;
     a.p_out = d_p_out;
     a.state_out = d_state_out;
+    a.dstate_out = d_dstate_out;
     a.K = p.K;
     a.S = p.S;
     a.ntiles = p.ntiles;
@@ -498,9 +499,21 @@ int fill_seq_args(Plan &p, SeqArgs &a) {
     a.m01 = std::exp(a.t01 - a.mx);
     a.m10 = std::exp(a.t10 - a.mx);
     a.m11 = std::exp(a.t11 - a.mx);
+    a.dstate = reinterpret_cast<const double *>(a.state);  // same workspace, one of the two forms per call
+    a.v_lo = a.t01 - a.t11;
+    a.v_hi = a.t00 - a.t10;
+    a.v_k = a.t11 - a.t00;
     return GECCO_CRF_OK;
 }
 }  // namespace
+
+// Labels without path scores from a 2-label model whose transitions satisfy lo <= hi take the
+// difference form (8 B/gene, 24-B scan elements); GECCO_CRF_VITERBI=matrix forces the general form.
+static bool viterbi_delta_ok(const SeqArgs &a, const double *d_score) {
+    const char *env = std::getenv("GECCO_CRF_VITERBI");
+    if (env && env[0] == 'm') return false;
+    return !d_score && a.v_lo <= a.v_hi && std::isfinite(a.v_lo) && std::isfinite(a.v_hi);
+}
 
 int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, double *d_marg,
                             double *d_lognorm, hipStream_t stream) {
@@ -552,6 +565,12 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
     }
     a.y = d_y;
     a.score = d_score;
+    if (viterbi_delta_ok(a, d_score)) {
+        if ((rc = check_hip(launch_seq_state_delta(d_gene_ptr, d_attr_id, p.tables->wtab2[1], p.n_genes,
+                                                   const_cast<double *>(a.dstate), stream), "state score launch")))
+            return rc;
+        return check_hip(launch_seq_viterbi_delta(a, stream), "viterbi launch");
+    }
     if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables->wtab2[1], p.n_genes,
                                          const_cast<double2 *>(a.state), stream), "state score launch")))
         return rc;
@@ -580,9 +599,15 @@ int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id
         set_error("null device buffer");
         return GECCO_CRF_EINVAL;
     }
-    if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, const_cast<double2 *>(a.state), stream))) return rc;
     a.y = d_y;
     a.score = d_score;
+    if (viterbi_delta_ok(a, d_score)) {
+        if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, const_cast<double *>(a.dstate), stream)))
+            return rc;
+        return check_hip(launch_seq_viterbi_delta(a, stream), "viterbi launch");
+    }
+    if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, const_cast<double2 *>(a.state), nullptr, stream)))
+        return rc;
     return check_hip(launch_seq_viterbi(a, p.d_contig_ptr, stream), "viterbi launch");
 }
 

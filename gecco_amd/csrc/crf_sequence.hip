@@ -69,6 +69,21 @@ struct MapOp {  // maps {0,1}->{0,1} packed in 2 bits: bit x = image of x
     }
 };
 
+// Difference form of the 2-label Viterbi recursion.  With Delta = delta[1] - delta[0] and d = s[1] - s[0],
+//   Delta_t = clamp(Delta_{t-1}, lo, hi) + (t11 - t00) + d_t,   lo = t01 - t11,  hi = t00 - t10  (lo <= hi),
+// the back-pointers of gene t are (Delta_{t-1} > hi, Delta_{t-1} > lo) and the end label is Delta_T > 0
+// (strict, = CRFsuite's first arg max).  x -> min(max(x + a, L), H) is closed under composition, a
+// contig's first gene is the constant map L = H = d_0, so the whole batch is again ONE scan -- with
+// 24-byte elements, a 7-op combine, no reset flag, and 8 instead of 16 bytes of input per gene.
+// Differences of accumulated scores stay O(1), so this form is if anything closer to exact
+// arithmetic than the delta recursion itself; with integer-valued weights both are exact.
+struct COp {
+    static __device__ __forceinline__ CE identity() { return CE{0.0, -__builtin_huge_val(), __builtin_huge_val()}; }
+    static __device__ __forceinline__ CE combine(const CE &a, const CE &b) {  // a applied first
+        return CE{a.a + b.a, fmin(fmax(a.L + b.a, b.L), b.H), fmin(fmax(a.H + b.a, b.L), b.H)};
+    }
+};
+
 // ---------------------------------------------------------------- DPP plumbing
 template <int CTRL, int RM>
 __device__ __forceinline__ double dpp_f64(double old, double src) {
@@ -86,6 +101,10 @@ __device__ __forceinline__ FE dpp_elem(const FE &old, const FE &s) {
     return FE{dpp_f64<CTRL, RM>(old.a00, s.a00), dpp_f64<CTRL, RM>(old.a01, s.a01), dpp_f64<CTRL, RM>(old.a10, s.a10),
               dpp_f64<CTRL, RM>(old.a11, s.a11), dpp_f64<CTRL, RM>(old.ex, s.ex),   dpp_f64<CTRL, RM>(old.ms, s.ms),
               dpp_f64<CTRL, RM>(old.rs, s.rs)};
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ CE dpp_elem(const CE &old, const CE &s) {
+    return CE{dpp_f64<CTRL, RM>(old.a, s.a), dpp_f64<CTRL, RM>(old.L, s.L), dpp_f64<CTRL, RM>(old.H, s.H)};
 }
 template <int CTRL, int RM>
 __device__ __forceinline__ uint32_t dpp_elem(const uint32_t &old, const uint32_t &s) {
@@ -198,6 +217,23 @@ __device__ __forceinline__ uint32_t lookahead_suffix(const uint32_t *__restrict_
     return acc;
 }
 
+__device__ __forceinline__ CE lookback_prefix(const CE *__restrict__ totals, int b) {
+    const int lane = threadIdx.x & 63;
+    auto bc = [](double x) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+    };
+    CE acc = COp::identity();
+    for (int hi = b; hi > 0; hi -= 64) {
+        const int idx = hi - 1 - lane;  // lanes hold the totals back to front
+        const CE e = idx >= 0 ? totals[idx] : COp::identity();
+        const CE s = wave_scan_inclusive<COp, true>(e);
+        const CE r{bc(s.a), bc(s.L), bc(s.H)};
+        acc = COp::combine(r, acc);
+        if (acc.L == acc.H) break;  // a constant map: nothing further back can matter
+    }
+    return acc;
+}
+
 // ---------------------------------------------------------------- row S: state scores
 __global__ void __launch_bounds__(kT) seq_state_scores(const int32_t *__restrict__ gene_ptr,
                                                        const int32_t *__restrict__ attr_id,
@@ -221,6 +257,30 @@ __global__ void __launch_bounds__(kT) seq_state_scores(const int32_t *__restrict
         }
     }
     state[g] = make_double2(s0, s1);
+}
+
+__global__ void __launch_bounds__(kT) seq_state_delta(const int32_t *__restrict__ gene_ptr,
+                                                       const int32_t *__restrict__ attr_id,
+                                                       const double2 *__restrict__ wtab01, int n_genes,
+                                                       double *__restrict__ dstate) {
+    const int g = blockIdx.x * kT + threadIdx.x;
+    if (g >= n_genes) return;
+    const int lo = gene_ptr[g], hi = gene_ptr[g + 1];
+    double s0 = 0.0, s1 = 0.0;
+    for (int base = lo; base < hi; base += 4) {
+        int a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = base + u < hi ? attr_id[base + u] : -1;
+        double2 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = a[u] >= 0 ? wtab01[a[u]] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s0 += w[u].x;
+            s1 += w[u].y;
+        }
+    }
+    dstate[g] = s1 - s0;
 }
 
 // ---------------------------------------------------------------- lane-local loads
@@ -379,6 +439,109 @@ __global__ void __launch_bounds__(kT) v_labels(const SeqArgs A) {
     } else {
         for (int k = 0; k < cnt; ++k) A.y[g0 + k] = int8_t((packed >> (8 * k)) & 0xff);
     }
+}
+
+// ---- difference form: fold / replay on 8-byte inputs ------------------------------------------
+struct LaneStageD {
+    double st[kT * (kGPL + 1)];
+    uint8_t fl[kT * kGPL];
+};
+struct LaneGenesD {
+    double d[kGPL];
+    uint32_t first, last;
+    int g0, cnt;
+};
+__device__ __forceinline__ LaneGenesD load_lane_d(const SeqArgs &A, int slot, LaneStageD &stg) {
+    const int base = blockIdx.x * kT * kGPL;
+#pragma unroll
+    for (int j = 0; j < kGPL; ++j) {  // coalesced 8-B loads, transposed through padded LDS rows
+        const int idx = j * kT + slot, g = base + idx;
+        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = g < A.n_genes ? A.dstate[g] : 0.0;
+    }
+    {
+        const int g0 = base + slot * kGPL;
+        uint64_t w = 0;
+        if (g0 + kGPL <= A.n_genes) {
+            w = *reinterpret_cast<const uint64_t *>(A.flags + g0);
+        } else {
+            for (int k = 0; k < kGPL; ++k)
+                if (g0 + k < A.n_genes) w |= uint64_t(A.flags[g0 + k]) << (8 * k);
+        }
+        *reinterpret_cast<uint64_t *>(stg.fl + slot * kGPL) = w;
+    }
+    __syncthreads();
+    LaneGenesD L;
+    L.g0 = base + slot * kGPL;
+    L.cnt = min(kGPL, A.n_genes - L.g0);
+    L.first = L.last = 0;
+    const uint64_t w = *reinterpret_cast<const uint64_t *>(stg.fl + slot * kGPL);
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        L.d[k] = stg.st[slot * (kGPL + 1) + k];
+        const uint32_t f = uint32_t(w >> (8 * k)) & 0xffu;
+        L.first |= (f & 1u) << k;
+        L.last |= ((f >> 1) & 1u) << k;
+    }
+    __syncthreads();
+    return L;
+}
+
+__global__ void __launch_bounds__(kT) vd_fold(const SeqArgs A) {
+    __shared__ CE lds[kT / 64];
+    __shared__ LaneStageD stg;
+    const LaneGenesD L = load_lane_d(A, threadIdx.x, stg);
+    CE P = COp::identity();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        if (k < L.cnt) {
+            const double c = A.v_k + L.d[k];
+            const CE e = ((L.first >> k) & 1u) ? CE{0.0, L.d[k], L.d[k]} : CE{c, A.v_lo + c, A.v_hi + c};
+            P = COp::combine(P, e);
+        }
+    }
+    CE total;
+    const CE excl = block_scan_exclusive<COp, false>(P, lds, &total);
+    reinterpret_cast<CE *>(A.vLane)[blockIdx.x * kT + threadIdx.x] = excl;
+    if (threadIdx.x == 0) reinterpret_cast<CE *>(A.vBlock)[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
+    __shared__ uint32_t lds[kT / 64];
+    __shared__ LaneStageD stg;
+    const int slot = threadIdx.x;
+    const LaneGenesD L = load_lane_d(A, slot, stg);
+    const CE M = COp::combine(lookback_prefix(reinterpret_cast<const CE *>(A.vBlock), blockIdx.x),
+                              reinterpret_cast<const CE *>(A.vLane)[blockIdx.x * kT + slot]);
+    double D = M.L;  // the map entering a lane is constant once a contig has started
+    uint32_t maps = 0, lane_map = MapOp::identity();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        if (k < L.cnt) {
+            D = ((L.first >> k) & 1u) ? L.d[k] : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + L.d[k]);
+            uint32_t m;
+            if ((L.last >> k) & 1u) {
+                m = D > 0.0 ? 3u : 0u;  // end label: first arg max
+            } else {
+                m = (D > A.v_hi ? 1u : 0u) | (D > A.v_lo ? 2u : 0u);  // back-pointers the next gene will take
+            }
+            maps |= m << (2 * k);
+        }
+    }
+#pragma unroll
+    for (int k = kGPL - 1; k >= 0; --k)
+        if (k < L.cnt) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
+    A.vMaps[blockIdx.x * kT + slot] = maps;
+    __shared__ uint32_t xch[kT];
+    xch[kT - 1 - slot] = lane_map;
+    __syncthreads();
+    const uint32_t mine = xch[slot];
+    uint32_t total;
+    const uint32_t excl = block_scan_exclusive<MapOp, true>(mine, lds, &total);
+    __syncthreads();
+    xch[kT - 1 - slot] = excl;
+    __syncthreads();
+    A.vLaneMap[blockIdx.x * kT + slot] = xch[slot];
+    if (slot == 0) A.vBlockMap[blockIdx.x] = total;
 }
 
 __global__ void __launch_bounds__(kT) v_scores(const SeqArgs A, const int32_t *__restrict__ contig_ptr) {
@@ -552,6 +715,22 @@ hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hip
         hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, a);
     }
     if (a.score) hipLaunchKernelGGL(v_scores, grid_for(a.n_contigs, kT), dim3(kT), 0, stream, a, d_contig_ptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream) {
+    if (a.n_contigs <= 0 || a.n_genes <= 0) return hipSuccess;
+    const int nb = (a.n_genes + kBlockGenes - 1) / kBlockGenes;
+    hipLaunchKernelGGL(vd_fold, dim3(nb), dim3(kT), 0, stream, a);
+    hipLaunchKernelGGL(vd_replay, dim3(nb), dim3(kT), 0, stream, a);
+    hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_seq_state_delta(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_genes,
+                                  double *dstate, hipStream_t stream) {
+    if (n_genes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(seq_state_delta, grid_for(n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_genes, dstate);
     return hipGetLastError();
 }
 

@@ -68,6 +68,13 @@ def test_decode_equals_separate_launches(nat, real, oracle_model, label, pad):
     ey, esc = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
     assert np.array_equal(y2.cpu().numpy().astype(np.int32), ey)
     assert np.abs(s2.cpu().numpy() - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
+    # without path scores the decoders share 8 B/gene (score differences) instead of 16
+    p3, y3 = torch.zeros_like(p1), torch.zeros_like(y1)
+    plan.run_decode(d_gp.data_ptr(), d_at.data_ptr(), p3.data_ptr(), y3.data_ptr(), label, 0, 0)
+    torch.cuda.synchronize()
+    c = p3.cpu().numpy()
+    assert np.array_equal(np.isnan(c), np.isnan(b)) and np.array_equal(c[~np.isnan(c)], b[~np.isnan(b)])
+    assert torch.equal(y3, y2)
 
 
 def test_resident_calls_equal_one_shot(nat, real, oracle_model):

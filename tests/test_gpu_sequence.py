@@ -105,6 +105,56 @@ def test_viterbi_very_long_contigs_walk_back_many_workgroups(nat, real, oracle_m
     assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_viterbi_difference_form(nat, real, oracle_model, seed, monkeypatch):
+    """Labels without path scores take the score-difference form of the recursion (8 B/gene): same
+    labels as the oracle and as the matrix form, on the shipped model, on integer weights (exact
+    ties) and on very long contigs."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(200 + seed)
+    if seed == 0:
+        w, trans, model = oracle_model["state"], oracle_model["trans"], real
+        lengths = LENGTHS + list(rng.integers(1, 300, size=50))
+    elif seed == 1:
+        w = rng.integers(-1, 2, size=(6, 2)).astype(float)
+        trans = np.array([[1.0, -1.0], [-1.0, 1.0]])
+        model = nat.Model.from_tables(w, trans)
+        lengths = [1, 5, 64, 65, 130, 700, 3000, 2048, 2049]
+    elif seed == 2:
+        w = np.zeros((8, 2))
+        w[0], w[1] = (1.0, 0.0), (0.0, 1.0)
+        trans = np.array([[1.0, -3.0], [-3.0, 1.0]])
+        model = nat.Model.from_tables(w, trans)
+        lengths = [300000, 3, 140000, 2049]
+    else:
+        w, _ = synth_model(500, rng)
+        trans = np.array([[0.3, -0.2], [0.1, 0.25]])  # lo = -0.45 <= hi = 0.2, barely sticky
+        model = nat.Model.from_tables(w, trans)
+        lengths = list(rng.integers(1, 3000, size=40))
+    cptr, gptr, attr = synth_contigs(rng, lengths, w.shape[0])
+    y, sc = model.viterbi(cptr, gptr, attr, want_score=False)
+    assert sc is None
+    ey, _ = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y, ey.astype(np.int8))
+    monkeypatch.setenv("GECCO_CRF_VITERBI", "matrix")
+    ym, _ = model.viterbi(cptr, gptr, attr, want_score=False)
+    assert np.array_equal(y, ym)
+
+
+def test_viterbi_antisticky_model_falls_back_to_matrix_form(nat):
+    """t01 - t11 > t00 - t10: the difference recursion is not a clamp; the general form must be used."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(31)
+    w, _ = synth_model(300, rng)
+    trans = np.array([[-1.0, 2.0], [1.5, -0.5]])
+    cptr, gptr, attr = synth_contigs(rng, [1, 2, 70, 500, 4100], 300)
+    y, _ = nat.Model.from_tables(w, trans).viterbi(cptr, gptr, attr, want_score=False)
+    ey, _ = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y, ey.astype(np.int8))
+
+
 def test_synthetic_model_c2_shape(nat):
     from oracle import crf_oracle as orc
 
