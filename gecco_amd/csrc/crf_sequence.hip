@@ -5,18 +5,20 @@
 //   V  [EXT] CRF.predict_single = crf1dc_viterbi, first-argmax tie-breaking.
 // Two-label models.  Contigs range from a handful of genes to 50 000 (BASELINE.json
 // configs[4]: scan-length-bound), so nothing here is "one lane per contig": all genes of all
-// contigs form ONE flat sequence and both recursions are associative scans of 2x2 matrices
-// over it -- max-plus for V, sum-product with exact power-of-two rescaling for F.  A contig's
-// first gene contributes a matrix with identical rows (it ignores whatever came before), so
-// contig boundaries need no segmented-scan logic at all; the backward direction does the same
-// with the contig's last gene.
+// contigs form ONE flat sequence and both recursions are associative scans over it -- max-plus
+// 2x2 matrices (or, without path scores, clamp maps on score differences: see COp) for V,
+// sum-product 2x2 matrices with exact power-of-two rescaling for F.  The scans are segmented: an
+// element that contains a contig's first gene forgets whatever came before it (`rs` flag of the
+// matrix elements; a constant map in the difference form), so every contig sees exactly its own
+// sequential values; the backward direction does the same with the contig's last gene.
 //
-// Three scan levels: a lane folds kGPL consecutive genes (registers, sequential, coalesced
-// 128-B reads), a wave scans its 64 lane products with DPP row_shr/row_bcast (no LDS), the
-// four wave totals and then the per-workgroup totals are combined through LDS / a
-// single-workgroup kernel.  Every gene is then replayed from the exact vector entering its
-// lane, using CRFsuite's operation order inside the lane.  Scores entering a lane come from
-// matrix products, i.e. they equal the strictly sequential values whenever the additions are
+// Scan levels: a lane folds kGPL consecutive genes (registers, sequential; coalesced loads
+// transposed through padded LDS), a wave scans its 64 lane products with DPP row_shr/row_bcast
+// (no LDS), the four wave totals meet in LDS.  Per-workgroup totals: V looks back over the
+// neighbouring workgroups' totals inside the replay kernel (see lookback_prefix), F still runs a
+// single-workgroup scan kernel.  Every gene is then replayed from the exact value entering its
+// lane, using CRFsuite's operation order inside the lane.  Values entering a lane come from
+// composed elements, i.e. they equal the strictly sequential values whenever the additions are
 // exact (integer-valued weights: ties and first-argmax included) and to rounding otherwise.
 #include "crf_device.hpp"
 
