@@ -8,26 +8,25 @@
 //
 // Design (two-label models, window <= 32: `crf_windowed_l2`):
 //   * slot space: genes of all scored contigs end to end, short contigs centre-padded to W
-//     slots (:216-227).  A 256-lane workgroup owns 256 consecutive slots as window starts;
-//     its first W-1 lanes are a recomputed halo, so workgroups never exchange data.
-//   * stage 1 (HBM -> LDS, coalesced CSR reads + L2-resident weight gather): per slot the
-//     state scores s[y] = sum_a w[a][y] ([EXT] crf1dt_state_score): the tile's attribute
-//     range is read flat and coalesced, weight pairs are gathered and staged in LDS, then
-//     every slot sums its run in CSR order.  Scores are reduced to e = exp(s - max(s)) and
-//     parked in LDS pre-multiplied with the transition constant (16 B/slot).  A per-position scale factor
-//     cancels in every marginal, so e (and exp(trans - max)) replace CRFsuite's raw exps;
-//     this bounds the DP vectors in (0, 2^k] and removes CRFsuite's per-step 1/sum
-//     division.  Renormalisation by an exact power of two happens only at the steps the
-//     host flags in `rescale_mask` (never for GECCO's model: see crf_plan.cpp).
-//   * stage 2 (registers): lane s runs the W-step forward recursion for window s keeping all
-//     W alpha pairs in VGPRs (fully unrolled), then the backward recursion; at step k it
-//     holds both alpha_k and beta_k of slot s+k, i.e. the un-normalised pair
-//     (x, y) = (alpha[label]*beta[label], alpha[other]*beta[other]),  P = x / (x + y).
-//   * stage 3 (DPP, no LDS traffic, no atomics): the maximum over windows is a diagonal
-//     reduction -- candidate k of lane s belongs to slot s+k.  A running best (x, y) is
-//     shifted one lane up per step with DPP wave_shr:1 and compared by cross-multiplication
-//     (x1*y2 > x2*y1), so the only division is the final x/(x+y) per gene.  Values leaving
-//     lane 63 are handed to the next wave of the workgroup through a 16-B LDS slot per step.
+//     slots (:216-227).  A 256-lane workgroup owns TT tiles of 256-(W-1) output slots; every
+//     lane is a window start in each of the TT DP phases, and the W-1 slots either side of the
+//     workgroup's range are recomputed, so workgroups never exchange data.
+//   * stage 1 (HBM -> LDS, once per workgroup): per slot the state scores s[y] = sum_a w[a][y]
+//     ([EXT] crf1dt_state_score) through bounds-checked buffer descriptors (no branches, sums in
+//     CSR order), reduced to e = exp(s - max(s)) and parked in LDS pre-multiplied with the
+//     transition constant (16 B/slot).  A per-position scale factor cancels in every marginal, so
+//     e (and transition ratios) replace CRFsuite's raw exps; this bounds the DP vectors and removes
+//     CRFsuite's per-step 1/sum division.  Renormalisation by an exact power of two happens only
+//     at the steps the host flags in `rescale_mask` (never for GECCO's model: see crf_plan.cpp).
+//   * stage 2 (registers): lane s runs the W-step forward recursion for window s keeping the
+//     label component of every alpha in VGPRs (fully unrolled), then the backward recursion; at
+//     step k it holds alpha_k[label] and beta_k[label] of slot s+k.  Un-normalised vectors satisfy
+//     alpha_k . beta_k = Z at every k, so P = alpha_k[label] beta_k[label] / Z with one reciprocal
+//     per window, folded into the initial beta.
+//   * stage 3 (DPP, no atomics): the maximum over windows is a diagonal reduction -- candidate k
+//     of lane s belongs to slot s+k.  The running best is shifted one lane up per step with DPP
+//     wave_shr:1 and meets the candidate in a v_max_f64.  Values leaving lane 63 are handed to the
+//     next wave of the workgroup through an 8-B LDS slot per step.
 //   No MFMA: L = 2 recurrences are 2x2 matrix-vector products on fp64 VALU.
 #include "crf_device.hpp"
 
