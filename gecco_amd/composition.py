@@ -92,3 +92,21 @@ def table_compositions(seg: np.ndarray, order: List[str], feature_protein_id: Se
             dom_w.append(1 - feature_pvalue[r])
         dom_ptr.append(len(dom_col))
     return _native.domain_composition(seg, dom_ptr, dom_col, dom_w, len(all_possible), normalize=normalize, device=device)
+
+
+def packed_compositions(seg: np.ndarray, packed, feature_domain: Sequence[str], feature_pvalue: Sequence[float],
+                        all_possible: Sequence[str], normalize: bool = True, device: int = 0) -> np.ndarray:
+    """`table_compositions` on the row ordering ``packing.pack_columns`` already computed
+    (`packed.row_order` / `packed.row_ptr`: feature rows by gene position and domain start): no
+    per-row Python work."""
+    all_possible = list(all_possible)
+    col_of, dups = _columns(all_possible)
+    if dups:
+        raise ValueError("duplicated names in `all_possible`")
+    dom = np.asarray(feature_domain, dtype=object)[packed.row_order]
+    names, inverse = np.unique(dom.astype(str), return_inverse=True) if len(dom) else (np.zeros(0, dtype=str), np.zeros(0, dtype=np.int64))
+    col_of_name = np.fromiter((col_of.get(str(nm), -1) for nm in names), dtype=np.int32, count=len(names))
+    dom_col = col_of_name[inverse] if len(dom) else np.zeros(0, dtype=np.int32)
+    dom_w = 1 - np.asarray(feature_pvalue, dtype=np.float64)[packed.row_order]
+    return _native.domain_composition(seg, packed.row_ptr.astype(np.int32), dom_col, dom_w, len(all_possible),
+                                      normalize=normalize, device=device)

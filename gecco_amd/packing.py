@@ -63,10 +63,98 @@ def pack_contigs(contigs: Sequence[Sequence[Any]], attr_index: Dict[str, int], f
     )
 
 
+@dataclass
+class PackedColumns:
+    """Result of `pack_columns`; unpacks like the 6-tuple (contig_ids, order, contig_ptr, gene_ptr,
+    attr_id, annotated).  The extra fields let table writers stay columnar."""
+    contig_ids: List[str]
+    order: Any              # protein ids in scoring order (contig id, start)
+    contig_ptr: np.ndarray  # int32 [n_contigs+1]
+    gene_ptr: np.ndarray    # int32 [n_genes+1]
+    attr_id: np.ndarray     # int32 [nnz]
+    annotated: np.ndarray   # uint8 [n_genes]: the gene has at least one feature row
+    row_gene: np.ndarray = None   # int64 [n_rows]: position in `order` of every feature row's gene
+    row_order: np.ndarray = None  # int64 [n_rows]: feature rows sorted by (gene position, domain_start), stable
+    row_ptr: np.ndarray = None    # int64 [n_genes+1]: offsets of every gene's rows in `row_order`
+
+    def __iter__(self):
+        return iter((self.contig_ids, self.order, self.contig_ptr, self.gene_ptr, self.attr_id, self.annotated))
+
+
 def pack_columns(sequence_id: Sequence[str], protein_id: Sequence[str], start: Sequence[int], domain: Sequence[str],
                  domain_start: Sequence[int], attr_index: Dict[str, int], gene_sequence_id: Sequence[str] = None,
-                 gene_protein_id: Sequence[str] = None, gene_start: Sequence[int] = None):
+                 gene_protein_id: Sequence[str] = None, gene_start: Sequence[int] = None) -> PackedColumns:
     """Columnar packer: FeatureTable columns (one row per domain hit,
+    ``gecco/model.py:629-642``) plus, optionally, GeneTable columns (one row per gene, so that
+    genes without any domain are kept) -> CSR batch without materialising Gene objects.
+
+    Order matches ``ClusterCRF.predict_probabilities``: genes by (sequence_id, start) with ties in
+    first-appearance order (``sorted`` is stable, crf/__init__.py:204-206), a gene's domains by
+    domain_start (:200-201), duplicate names collapsed (features.py:31-35), unknown names dropped
+    ([EXT] CRFsuite attribute lookup).  Vectorised (hash factorisation + stable integer sorts):
+    a 2 M-gene metagenome packs in about a second; `pack_columns_py` is the row-by-row statement."""
+    try:
+        import pandas as pd
+    except ImportError:  # pragma: no cover
+        return PackedColumns(*pack_columns_py(sequence_id, protein_id, start, domain, domain_start, attr_index,
+                                              gene_sequence_id, gene_protein_id, gene_start))
+    f_sid = np.asarray(sequence_id, dtype=object)
+    f_pid = np.asarray(protein_id, dtype=object)
+    f_start = np.asarray(start, dtype=np.int64)
+    f_dom = np.asarray(domain, dtype=object)
+    f_ds = np.asarray(domain_start, dtype=np.int64)
+    nf = len(f_pid)
+    if gene_protein_id is not None:
+        g_pid = np.asarray(gene_protein_id, dtype=object)
+        g_sid = np.asarray(gene_sequence_id, dtype=object)
+        g_start = np.asarray(gene_start, dtype=np.int64)
+    else:
+        g_pid, g_sid, g_start = f_pid[:0], f_sid[:0], f_start[:0]
+    ng = len(g_pid)
+    # genes in first-appearance order: gene-table rows, then proteins only the feature table knows
+    codes, uniq = pd.factorize(np.concatenate([g_pid, f_pid]), sort=False)
+    n = len(uniq)
+    sid_u = np.empty(n, dtype=object)
+    start_u = np.zeros(n, dtype=np.int64)
+    if nf:  # feature rows: the first row of a protein defines it ...
+        sid_u[codes[ng:][::-1]] = f_sid[::-1]
+        start_u[codes[ng:][::-1]] = f_start[::-1]
+    if ng:  # ... unless the gene table lists it (a repeated id keeps its last row, like a dict)
+        sid_u[codes[:ng]] = g_sid
+        start_u[codes[:ng]] = g_start
+    sid_code, sid_names = pd.factorize(sid_u, sort=True)  # codes follow str ordering
+    perm = np.lexsort((start_u, sid_code))                # stable
+    rank = np.empty(n, dtype=np.int64)
+    rank[perm] = np.arange(n)
+    order = uniq[perm]
+    sc = sid_code[perm]
+    cuts = np.flatnonzero(np.diff(sc)) + 1 if n else np.zeros(0, dtype=np.int64)
+    contig_ptr = np.concatenate([[0], cuts, [n]]).astype(np.int32) if n else np.zeros(1, dtype=np.int32)
+    contig_ids = [str(x) for x in sid_names[sc[contig_ptr[:-1]]]] if n else []
+    # feature rows by (gene position, domain_start), stable
+    row_gene = rank[codes[ng:]]
+    row_order = np.lexsort((f_ds, row_gene)) if nf else np.zeros(0, dtype=np.int64)
+    rows_per_gene = np.bincount(row_gene, minlength=n) if nf else np.zeros(n, dtype=np.int64)
+    row_ptr = np.concatenate([[0], np.cumsum(rows_per_gene)]).astype(np.int64)
+    dom_code, dom_names = pd.factorize(f_dom, sort=False)
+    attr_of_dom = np.fromiter((attr_index.get(d, -1) for d in dom_names), dtype=np.int64, count=len(dom_names))
+    g_sorted = row_gene[row_order]
+    d_sorted = dom_code[row_order]
+    first = ~pd.Series(g_sorted * max(len(dom_names), 1) + d_sorted).duplicated().to_numpy() if nf else np.zeros(0, dtype=bool)
+    a_sorted = attr_of_dom[d_sorted] if nf else np.zeros(0, dtype=np.int64)
+    keep = first & (a_sorted >= 0)
+    attr = a_sorted[keep].astype(np.int32)
+    per_gene = np.bincount(g_sorted[keep], minlength=n) if nf else np.zeros(n, dtype=np.int64)
+    gene_ptr = np.concatenate([[0], np.cumsum(per_gene)]).astype(np.int32)
+    annotated = (rows_per_gene > 0).astype(np.uint8)
+    return PackedColumns(contig_ids, order, contig_ptr, gene_ptr, attr, annotated, row_gene, row_order, row_ptr)
+
+
+def pack_columns_py(sequence_id: Sequence[str], protein_id: Sequence[str], start: Sequence[int], domain: Sequence[str],
+                 domain_start: Sequence[int], attr_index: Dict[str, int], gene_sequence_id: Sequence[str] = None,
+                 gene_protein_id: Sequence[str] = None, gene_start: Sequence[int] = None):
+    """Row-by-row statement of `pack_columns` (the executable specification its tests compare the
+    vectorised version with).  Columnar packer: FeatureTable columns (one row per domain hit,
     ``gecco/model.py:629-642``) plus, optionally, GeneTable columns (one row per gene, so that
     genes without any domain are kept) -> (contig ids, gene ids per contig order, contig_ptr,
     gene_ptr, attr_id, annotated) without materialising Gene objects.

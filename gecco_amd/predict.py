@@ -34,70 +34,74 @@ def predict_tables(genes_t: tables.GeneTable, feats_t: tables.FeatureTable, crf:
         raise ValueError("the columnar path supports protein-level features (the shipped model's mode)")
     dev = crf.devices[0] if device is None else device
     idx = crf.model._attr_index
-    contig_ids, order, cptr, gptr, attr, annotated = packing.pack_columns(
+    pk = packing.pack_columns(
         feats_t.sequence_id, feats_t.protein_id, feats_t.start, feats_t.domain, feats_t.domain_start, idx,
         genes_t.sequence_id, genes_t.protein_id, genes_t.start)
+    contig_ids, order, cptr, gptr, attr, annotated = pk
     W = crf.window_size
-    for c, cid in enumerate(contig_ids):  # the reference's warnings (crf/__init__.py:216-233)
-        n = int(cptr[c + 1] - cptr[c])
-        if n < W:
-            if pad:
-                unit = "protein" if W - n == 1 else "proteins"
-                warnings.warn(f"Contig {cid!r} does not contain enough proteins ({n}) for sliding window of size {W}, "
-                              f"padding with {W - n} {unit}")
-            else:
-                warnings.warn(f"Contig {cid!r} does not contain enough proteins ({n}) for sliding window of size {W}")
+    lengths = np.diff(cptr)
+    for c in np.flatnonzero(lengths < W):  # the reference's warnings (crf/__init__.py:216-233)
+        cid, n = contig_ids[c], int(lengths[c])
+        if pad:
+            unit = "protein" if W - n == 1 else "proteins"
+            warnings.warn(f"Contig {cid!r} does not contain enough proteins ({n}) for sliding window of size {W}, "
+                          f"padding with {W - n} {unit}")
+        else:
+            warnings.warn(f"Contig {cid!r} does not contain enough proteins ({n}) for sliding window of size {W}")
     p = crf.predict_probabilities_csr(cptr, gptr, attr, pad=pad, device=dev)
     seg = _native.segment(p, annotated, cptr, threshold, n_cds, edge_distance, trim, device=dev)
 
-    # ---- genes table, in the order of ClusterCRF.predict_probabilities (contig id, start)
-    row_of = {pid: i for i, pid in enumerate(genes_t.protein_id)}
-    have_row = all(pid in row_of for pid in order)
-    gcols = {name: [] for name, _, _ in tables.GeneTable.COLUMNS}
-    p_of = {}
-    for k, pid in enumerate(order):
-        pv = float(p[k])
-        p_of[pid] = pv
-        if have_row:
-            i = row_of[pid]
-            gcols["sequence_id"].append(genes_t.sequence_id[i])
-            gcols["protein_id"].append(pid)
-            gcols["start"].append(genes_t.start[i])
-            gcols["end"].append(genes_t.end[i])
-            gcols["strand"].append(genes_t.strand[i])
-        gcols["average_p"].append(pv)
-        gcols["max_p"].append(pv)
-    genes_out = tables.GeneTable(gcols) if have_row else None
+    # ---- genes table, in the order of ClusterCRF.predict_probabilities (contig id, start); every
+    # column is gathered at once (no per-gene Python work)
+    rows = None
+    try:
+        import pandas as pd
+
+        index = pd.Index(np.asarray(genes_t.protein_id, dtype=object))
+        if index.is_unique:
+            rows = index.get_indexer(order).astype(np.int64)
+    except ImportError:  # pragma: no cover
+        pass
+    if rows is None:  # repeated ids: the last row of an id stands for it, like a dict
+        row_of = {pid: i for i, pid in enumerate(genes_t.protein_id)}
+        rows = np.fromiter((row_of.get(pid, -1) for pid in order), dtype=np.int64, count=len(order))
+    have_row = bool((rows >= 0).all())
+    genes_out = None
+    if have_row:
+        gcols = {name: np.asarray(genes_t.columns[name])[rows] for name in ("sequence_id", "protein_id", "start", "end", "strand")}
+        gcols["average_p"] = p
+        gcols["max_p"] = p
+        genes_out = tables.GeneTable(gcols)
 
     # ---- features table: every domain row carries its gene's probability (features.py:92-96)
-    fcols = {name: list(col) for name, col in feats_t.columns.items()}
-    fcols["cluster_probability"] = [p_of.get(pid, math.nan) for pid in feats_t.protein_id]
+    fcols = dict(feats_t.columns)
+    fcols["cluster_probability"] = p[pk.row_gene] if len(pk.row_gene) else np.zeros(0)
     feats_out = tables.FeatureTable(fcols)
 
-    # ---- clusters table (gecco/model.py:731-760)
-    doms_of = {}
-    for pid, dom in zip(feats_t.protein_id, feats_t.domain):
-        doms_of.setdefault(pid, []).append(dom)
+    # ---- clusters table (gecco/model.py:731-760): a handful of rows
+    g_start = np.asarray(genes_t.start)
+    g_end = np.asarray(genes_t.end)
+    f_domain = np.asarray(feats_t.domain, dtype=object)
     ccols = {name: [] for name, _, _ in tables.ClusterTable.COLUMNS}
     for c, number, a, b in seg.tolist():
-        members = order[a:b]
-        rows = [row_of[pid] for pid in members]
-        ps = [p_of[pid] for pid in members if not math.isnan(p_of[pid])]
+        members = [str(x) for x in order[a:b]]
+        r = rows[a:b]
+        ps = [float(v) for v in p[a:b] if not math.isnan(v)]
         ccols["sequence_id"].append(contig_ids[c])
         ccols["cluster_id"].append(f"{contig_ids[c]}_cluster_{number}")
-        ccols["start"].append(min(genes_t.start[i] for i in rows))
-        ccols["end"].append(max(genes_t.end[i] for i in rows))
+        ccols["start"].append(int(g_start[r].min()))
+        ccols["end"].append(int(g_end[r].max()))
         ccols["average_p"].append(statistics.mean(ps) if ps else math.nan)  # exactly rounded, model.py:442-447
         ccols["max_p"].append(max(ps) if ps else math.nan)
         ccols["type"].append("Unknown")
         ccols["proteins"].append(";".join(sorted(members)))
-        ccols["domains"].append(";".join(sorted(d for pid in members for d in doms_of.get(pid, ()))))
+        drows = pk.row_order[pk.row_ptr[a]:pk.row_ptr[b]]
+        ccols["domains"].append(";".join(sorted(str(d) for d in f_domain[drows])))
     clusters_out = tables.ClusterTable(ccols)
     if composition_domains is None:
         return genes_out, feats_out, clusters_out
     # input matrix of the type classifier (types/__init__.py:118), one row per called cluster
-    comps = composition.table_compositions(seg, order, feats_t.protein_id, feats_t.domain, feats_t.pvalue,
-                                           feats_t.domain_start, composition_domains, device=dev)
+    comps = composition.packed_compositions(seg, pk, feats_t.domain, feats_t.pvalue, composition_domains, device=dev)
     return genes_out, feats_out, clusters_out, comps
 
 

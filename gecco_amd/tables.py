@@ -11,7 +11,14 @@ import csv
 import math
 from typing import Any, Dict, Iterable, List, Optional, Sequence, TextIO, Union
 
+import numpy as np
+
 from . import model as _model
+
+try:  # bulk tables (metagenomes: millions of rows) go through pandas' C parser / writer
+    import pandas as _pd
+except ImportError:  # pragma: no cover - pandas is optional
+    _pd = None
 
 _FEATURE_COLUMNS = [
     ("sequence_id", str, None), ("protein_id", str, None), ("start", int, None), ("end", int, None),
@@ -28,8 +35,8 @@ _GENE_COLUMNS = [
 def _fmt(v: Any) -> str:
     if v is None:
         return ""
-    if isinstance(v, float):
-        return "" if math.isnan(v) else repr(v)
+    if isinstance(v, (float, np.floating)):
+        return "" if math.isnan(v) else repr(float(v))
     return str(v)
 
 
@@ -62,12 +69,20 @@ class _Table:
 
     @classmethod
     def load(cls, fh: Union[str, TextIO]):
+        """Columns come back as numpy arrays (object arrays for text) when pandas is available,
+        as lists otherwise; floats are parsed correctly rounded either way."""
+        types = {name: typ for name, typ, _ in cls.COLUMNS}
+        if _pd is not None:
+            dt = {name: (np.float64 if typ is float else np.int64 if typ is int else str) for name, typ in types.items()}
+            df = _pd.read_csv(fh, sep="\t", dtype=dt, keep_default_na=False,
+                              na_values={name: [""] for name, typ in types.items() if typ is float},
+                              float_precision="round_trip", quoting=csv.QUOTE_NONE)
+            return cls({h: df[h].to_numpy(dtype=object) if df[h].dtype == object else df[h].to_numpy() for h in df.columns})
         own = isinstance(fh, str)
         f = open(fh, newline="") if own else fh
         try:
             reader = csv.reader(f, delimiter="\t")
             header = next(reader)
-            types = {name: typ for name, typ, _ in cls.COLUMNS}
             cols: Dict[str, List[Any]] = {h: [] for h in header}
             for row in reader:
                 for h, cell in zip(header, row):
@@ -81,19 +96,26 @@ class _Table:
         keep = []
         for name, _, default in self.COLUMNS:
             col = self.columns[name]
-            if default is not None and len(col) and all(
-                (isinstance(v, float) and math.isnan(v)) if isinstance(default, float) and math.isnan(default) else v == default
-                for v in col
-            ):
-                continue
+            if default is not None and len(col):
+                if isinstance(default, float) and math.isnan(default):
+                    arr = np.asarray(col, dtype=np.float64) if not isinstance(col, np.ndarray) else col
+                    if arr.dtype.kind == "f" and np.isnan(arr).all():
+                        continue
+                elif all(v == default for v in col):
+                    continue
             keep.append(name)
         return keep
 
     def dump(self, fh: Union[str, TextIO]) -> None:
+        names = self._dump_columns()
+        if _pd is not None and len(self) > 64:
+            # floats are written with repr() digits (shortest round trip), NaN as an empty field
+            _pd.DataFrame({n: self.columns[n] for n in names}, columns=names).to_csv(
+                fh, sep="\t", index=False, na_rep="", quoting=csv.QUOTE_NONE, lineterminator="\n")
+            return
         own = isinstance(fh, str)
         f = open(fh, "w", newline="") if own else fh
         try:
-            names = self._dump_columns()
             f.write("\t".join(names) + "\n")
             for i in range(len(self)):
                 f.write("\t".join(_fmt(self.columns[n][i]) for n in names) + "\n")

@@ -126,11 +126,40 @@ def test_columnar_packer_equals_object_packer(trained):
     cids, order, cptr, gptr, attr, ann = packing.pack_columns(
         feats.sequence_id, feats.protein_id, feats.start, feats.domain, feats.domain_start, idx,
         genes_t.sequence_id, genes_t.protein_id, genes_t.start)
-    assert cids == ["BGC0001866.1"] and order == genes_t.protein_id and cptr.tolist() == [0, 23]
+    assert cids == ["BGC0001866.1"] and list(order) == list(genes_t.protein_id) and cptr.tolist() == [0, 23]
     from tests.helpers import golden_csr
 
     _, cptr2, gptr2, attr2, _, ann2 = golden_csr(idx)
     assert gptr.tolist() == gptr2.tolist() and attr.tolist() == attr2.tolist() and ann.tolist() == ann2.tolist()
+
+
+def test_vectorised_column_packer_equals_row_by_row_statement():
+    """`pack_columns` (hash factorisation + stable sorts) against `pack_columns_py` (the row-by-row
+    statement of the reference's ordering rules) on random tables: ties in (contig, start), proteins
+    missing from the gene table, repeated gene rows, repeated and unknown domains, empty tables."""
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        ng, nf = int(rng.integers(0, 40)), int(rng.integers(0, 80))
+        nsid, ndom = int(rng.integers(1, 5)), int(rng.integers(1, 9))
+        sids = [f"c{int(i):03d}" for i in rng.integers(0, nsid, size=ng)]
+        pids = [f"p{i}" for i in range(ng)]
+        starts = rng.integers(0, 50, size=ng).tolist()
+        if trial % 7 == 0 and ng > 3:
+            pids[3] = pids[1]
+        fi = rng.integers(0, ng + 3, size=nf)
+        args = ([sids[i] if i < ng else "zz" for i in fi], [pids[i] if i < ng else f"x{i}" for i in fi],
+                [starts[i] if i < ng else 7 for i in fi], [f"D{int(i)}" for i in rng.integers(0, ndom, size=nf)],
+                rng.integers(0, 6, size=nf).tolist(), {f"D{i}": i * 2 for i in range(0, ndom, 2)})
+        if trial % 3:
+            args += (sids, pids, starts)
+        a, b = packing.pack_columns_py(*args), packing.pack_columns(*args)
+        assert a[0] == b.contig_ids and list(a[1]) == list(b.order), trial
+        assert all(np.array_equal(x, y) for x, y in zip(a[2:], list(b)[2:])), trial
+        # the extra row bookkeeping: rows of gene k, by domain start, stable
+        for k in range(len(b.order)):
+            rows = b.row_order[b.row_ptr[k]:b.row_ptr[k + 1]]
+            exp = sorted([r for r in range(nf) if args[1][r] == b.order[k]], key=lambda r: args[4][r])
+            assert rows.tolist() == exp, trial
 
 
 # ---------------------------------------------------------------- predict_probabilities wrapper

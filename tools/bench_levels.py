@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the windowed-marginals path at three levels:
 kernel only (resident inputs) / one-shot C ABI with host buffers (H2D + kernel + D2H) /
-Python object API (ClusterCRF.predict_probabilities on Gene objects, incl. host packing).
+Python object API (ClusterCRF.predict_probabilities on Gene objects, incl. host packing) /
+columnar tables API (gecco_amd.predict: TSV columns -> CSR -> device -> TSV columns).
 Run on the GPU box; prints one JSON object."""
 import json
 import os
@@ -62,6 +63,43 @@ def main():
         dt = time.perf_counter() - t0
     out["python_object_api"] = {"genes": len(genes), "ms": dt * 1e3, "genes_per_s": len(genes) / dt,
                                 "note": "sort + pack Gene objects + one-shot ABI + new Gene/Domain objects"}
+    # columnar path: the same kind of data as feature / gene tables (2000 contigs x 200 genes)
+    import io
+    import tempfile
+
+    from gecco_amd import predict, tables
+
+    nc, per = 2000, 200
+    ng = nc * per
+    k = rng.integers(0, 4, size=ng)
+    owner = np.repeat(np.arange(ng), k)
+    nf = len(owner)
+    g_sid = np.array([f"contig_{c:05d}" for c in range(nc)], dtype=object)[np.arange(ng) // per]
+    g_pid = np.array([f"g{i:07d}" for i in range(ng)], dtype=object)
+    g_start = (np.arange(ng) % per) * 1000
+    genes_t = tables.GeneTable({"sequence_id": g_sid, "protein_id": g_pid, "start": g_start, "end": g_start + 900,
+                                "strand": np.full(ng, "+", dtype=object)})
+    doms = np.array(attrs, dtype=object)[rng.integers(0, len(attrs), size=nf)]
+    feats_t = tables.FeatureTable({
+        "sequence_id": g_sid[owner], "protein_id": g_pid[owner], "start": g_start[owner], "end": g_start[owner] + 900,
+        "strand": np.full(nf, "+", dtype=object), "domain": doms, "hmm": np.full(nf, "Pfam", dtype=object),
+        "i_evalue": np.full(nf, 1e-10), "pvalue": np.full(nf, 1e-12), "domain_start": rng.integers(1, 300, size=nf),
+        "domain_end": np.full(nf, 300)})
+    predict.predict_tables(genes_t, feats_t, crf)  # warm
+    t0 = time.perf_counter()
+    g_out, f_out, c_out = predict.predict_tables(genes_t, feats_t, crf)
+    dt = time.perf_counter() - t0
+    out["columnar_tables_api"] = {"genes": ng, "domain_rows": nf, "clusters": len(c_out), "ms": dt * 1e3, "genes_per_s": ng / dt,
+                                  "note": "pack_columns + one-shot ABI (marginals, segmentation) + output columns"}
+    with tempfile.TemporaryDirectory() as tmp:
+        gp_, fp_ = os.path.join(tmp, "x.genes.tsv"), os.path.join(tmp, "x.features.tsv")
+        genes_t.dump(gp_)
+        feats_t.dump(fp_)
+        t0 = time.perf_counter()
+        rc = predict.main(["--genes", gp_, "--features", fp_, "--model", golden, "-o", os.path.join(tmp, "out")])
+        dt = time.perf_counter() - t0
+    out["columnar_cli_tsv_to_tsv"] = {"genes": ng, "ms": dt * 1e3, "genes_per_s": ng / dt,
+                                      "note": "python -m gecco_amd.predict: read 2 TSVs, predict, write 3 TSVs (includes model load)"}
     print(json.dumps(out))
 
 
