@@ -202,3 +202,19 @@ def test_generic_kernel_cross_checks_fast_kernel(nat, real_model, oracle_model, 
     monkeypatch.setenv("GECCO_CRF_FORCE_GENERIC", "1")
     slow = real_model.windowed_marginals(cptr, gptr, attr, 20, pad=False)
     _cmp(slow, fast)
+
+
+@pytest.mark.parametrize("tiles", ["1", "3"])
+def test_other_tiles_per_workgroup_geometries(nat, real_model, oracle_model, monkeypatch, tiles):
+    """GECCO_CRF_TILES_PER_WG is an A/B switch of the plan geometry (default 2): every setting must
+    give the same marginals, including padded / skipped contigs that make tiles irregular."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(int(tiles))
+    cptr, gptr, attr = synth_contigs(rng, [3, 700, 19, 20, 21, 255, 256, 257, 1500] + list(rng.integers(1, 600, size=40)),
+                                     oracle_model["state"].shape[0])
+    monkeypatch.setenv("GECCO_CRF_TILES_PER_WG", tiles)
+    for W, step, pad in [(20, 1, True), (20, 1, False), (7, 2, True), (32, 5, True)]:
+        got = real_model.windowed_marginals(cptr, gptr, attr, W, step, 1, pad)
+        exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, W, step, 1, pad)
+        _cmp(got, exp)
