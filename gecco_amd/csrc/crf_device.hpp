@@ -37,7 +37,7 @@ struct WinArgs {
 };
 
 // Geometry of the fast L==2 kernel.
-constexpr int kWinThreads = 256;  // lanes (= window starts) per workgroup: 4 waves, 5 workgroups per CU at <= 96 VGPRs
+constexpr int kWinThreads = 256;  // lanes (= window starts) per workgroup: 4 waves, 8 workgroups per CU at <= 64 VGPRs
 constexpr int kWinMaxW = 32;      // largest window the register-resident kernel handles
 constexpr int kWinTilesPerWg = 2; // default DP phases per workgroup (GECCO_CRF_TILES_PER_WG=1..3 overrides; A/B runs)
 

@@ -183,7 +183,9 @@ __device__ __forceinline__ void state_scores_buf(__amdgpu_buffer_rsrc_t ra, __am
 //   candidate for slot s+k: x = a1 * b1 (label), y = a0 * b0 (other); all scale factors cancel
 //   in x / (x + y).
 template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT>
-__global__ void __launch_bounds__(NT, (WMAX <= 20 ? 5 : 3)) crf_windowed_l2(const WinArgs P) {
+// minimum waves per SIMD the register allocation must allow: the Z-constant DP keeps W doubles of
+// alpha (8 waves at W = 20, 5 at W <= 32), the rescaling variant 2 W (5 / 3)
+__global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <= 20 ? 8 : 5))) crf_windowed_l2(const WinArgs P) {
     using Smem = WinSmem<WMAX, NT, TT>;
     constexpr int JMAX = Smem::JMAX;
     __shared__ Smem sm;
