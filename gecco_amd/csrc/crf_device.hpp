@@ -43,6 +43,7 @@ constexpr int kWinTilesPerWg = 2; // default DP phases per workgroup (GECCO_CRF_
 
 // ---- whole-contig kernels (crf_sequence.hip) ------------------------------------------------
 constexpr int kSeqGenesPerLane = 8;  // genes folded sequentially by one lane of the flat scans
+constexpr int kSeqBlockGenes = 256 * kSeqGenesPerLane;  // genes per workgroup of the flat scans
 
 // `rs` != 0: the span contains the first gene of a contig; everything before that gene is
 // forgotten (segmented scan), so rows are identical and hold the exact values since the reset.
@@ -61,6 +62,8 @@ struct SeqArgs {
     const double2 *state;    // [n_genes]  (s[label 0], s[label 1])
     const double *dstate;    // [n_genes]  s[1] - s[0]: all the difference-form Viterbi needs (8 B/gene)
     const uint8_t *flags;    // [n_genes]  bit0: first gene of a contig, bit1: last gene
+    const int32_t *blk_cs;   // [blocks]   first gene of the contig that the block's first gene belongs to
+    int32_t short_contigs;   // 1: no contig is longer than one scan block (kSeqBlockGenes)
     int32_t n_contigs, n_genes;
     double m00, m01, m10, m11;  // exp(trans - mx)
     double t00, t01, t10, t11;  // raw transition weights (Viterbi)

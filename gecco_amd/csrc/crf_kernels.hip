@@ -185,7 +185,7 @@ __device__ __forceinline__ void state_scores_buf(__amdgpu_buffer_rsrc_t ra, __am
 template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT>
 // minimum waves per SIMD the register allocation must allow: the Z-constant DP keeps W doubles of
 // alpha (8 waves at W = 20, 5 at W <= 32), the rescaling variant 2 W (5 / 3)
-__global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <= 20 ? 8 : 5))) crf_windowed_l2(const WinArgs P) {
+__global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <= 20 && TT <= 2 ? 8 : 5))) crf_windowed_l2(const WinArgs P) {
     using Smem = WinSmem<WMAX, NT, TT>;
     constexpr int JMAX = Smem::JMAX;
     __shared__ Smem sm;

@@ -86,6 +86,7 @@ Plan::~Plan() {
             (void)hipFree(d_start_bits);
             (void)hipFree(d_skipped);
             (void)hipFree(d_seq_flags);
+            (void)hipFree(d_seq_blk_cs);
             (void)hipFree(d_seq_ws);
             (void)hipFree(d_win_scratch);
             (void)hipFree(d_gen_ws);
@@ -454,8 +455,22 @@ int ensure_seq(Plan &p) {
             flags[g1 - 1] |= 2;
         }
     }
+    // per scan block: where the contig of its first gene starts; and whether every contig fits a block
+    const size_t nb = (size_t(p.n_genes) + kSeqBlockGenes - 1) / kSeqBlockGenes;
+    std::vector<int32_t> blk_cs(nb ? nb : 1, 0);
+    p.seq_short = true;
+    {
+        size_t b = 0;
+        for (int32_t c = 0; c < p.n_contigs; ++c) {
+            const int32_t g0 = p.contig_ptr[c], g1 = p.contig_ptr[c + 1];
+            if (g1 - g0 > kSeqBlockGenes) p.seq_short = false;
+            for (; b < nb && int64_t(b) * kSeqBlockGenes < g1; ++b)
+                if (int64_t(b) * kSeqBlockGenes >= g0) blk_cs[b] = g0;
+        }
+    }
     int rc;
     if ((rc = upload(&p.d_seq_flags, flags.data(), flags.size(), "upload contig flags"))) return rc;
+    if ((rc = upload(&p.d_seq_blk_cs, blk_cs.data(), blk_cs.size(), "upload scan block table"))) return rc;
     const SeqLayout l = seq_layout(size_t(p.n_genes));
     if ((rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_seq_ws), l.bytes), "hipMalloc scan workspace"))) return rc;
     p.seq_ready = true;
@@ -488,6 +503,8 @@ int fill_seq_args(Plan &p, SeqArgs &a) {
     a.fLaneSuf = reinterpret_cast<FE *>(w + l.off_flanesuf);
     a.fBlockSuf = reinterpret_cast<FE *>(w + l.off_fblocksuf);
     a.flags = p.d_seq_flags;
+    a.blk_cs = p.d_seq_blk_cs;
+    a.short_contigs = p.seq_short ? 1 : 0;
     a.n_contigs = p.n_contigs;
     a.n_genes = p.n_genes;
     a.mx = *std::max_element(m.trans.begin(), m.trans.end());

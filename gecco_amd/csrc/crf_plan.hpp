@@ -51,6 +51,8 @@ struct Plan {
     // whole-contig scans (rows F, V): chunk tables + workspace, built on first use
     bool seq_ready = false;
     uint8_t *d_seq_flags = nullptr;
+    int32_t *d_seq_blk_cs = nullptr;  // per 2048-gene scan block: first gene of the contig its first gene belongs to
+    bool seq_short = false;           // no contig longer than one scan block: Viterbi looks back by recomputation
     char *d_seq_ws = nullptr;
     ~Plan();
 };

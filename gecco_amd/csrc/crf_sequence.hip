@@ -28,6 +28,7 @@ namespace {
 constexpr int kT = 256;                 // lanes per workgroup
 constexpr int kGPL = kSeqGenesPerLane;  // genes folded by one lane
 constexpr int kBlockGenes = kT * kGPL;
+static_assert(kBlockGenes == kSeqBlockGenes, "host tables assume this block size");
 
 // ---------------------------------------------------------------- scan operators (elements: crf_device.hpp)
 struct VOp {
@@ -546,6 +547,107 @@ __global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
     if (slot == 0) A.vBlockMap[blockIdx.x] = total;
 }
 
+// ---- short contigs: fold + replay in one kernel, looking back by RECOMPUTATION --------------------
+// When no contig is longer than one scan block (metagenome assemblies: the headline workload), the
+// value entering a block depends only on the genes between the start of the contig its first gene
+// belongs to (`blk_cs`, host-built) and the block -- at most one block's worth.  The workgroup
+// loads that stretch together with its own genes and folds it itself: no totals of other
+// workgroups, no second launch, no lane-prefix array in HBM.
+__global__ void __launch_bounds__(kT) vd_fused(const SeqArgs A) {
+    __shared__ CE lds[kT / 64];
+    __shared__ uint32_t ldsm[kT / 64];
+    // 2 x 18 KB of transposition space + ~1 KB: four workgroups per CU, so that the ~10^3 workgroups
+    // of a 2 M-gene batch are resident at once
+    __shared__ struct { double st[kT * (kGPL + 1)]; } stg, stgp;
+    __shared__ uint32_t xch[kT];
+    const int slot = threadIdx.x;
+    const int base = blockIdx.x * kT * kGPL;
+    const int cs = A.blk_cs[blockIdx.x];
+    const bool look = cs < base;  // workgroup-uniform
+    // ---- both stretches are requested before anything is waited for
+#pragma unroll
+    for (int j = 0; j < kGPL; ++j) {
+        const int idx = j * kT + slot;
+        const int g = base + idx, q = cs + idx;
+        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = g < A.n_genes ? A.dstate[g] : 0.0;
+        if (look) stgp.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = q < base ? A.dstate[q] : 0.0;
+    }
+    auto flag_word = [&](int g0, int limit) {
+        uint64_t w = 0;
+        if (g0 + kGPL <= limit) {
+            w = *reinterpret_cast<const uint64_t *>(A.flags + g0);
+        } else {
+            for (int k = 0; k < kGPL; ++k)
+                if (g0 + k < limit) w |= uint64_t(A.flags[g0 + k]) << (8 * k);
+        }
+        return w;
+    };
+    const int g0 = base + slot * kGPL, q0 = cs + slot * kGPL;
+    const uint64_t wf = flag_word(g0, A.n_genes);
+    const uint64_t wq = look ? flag_word(q0, base) : 0;
+    __syncthreads();
+    // ---- the stretch before the block: one ordered reduction to the (constant) map entering the block
+    CE enter = COp::identity();
+    if (look) {
+        const int cntq = min(kGPL, base - q0);
+        CE P = COp::identity();
+#pragma unroll
+        for (int k = 0; k < kGPL; ++k) {
+            if (k < cntq) {
+                const double d = stgp.st[slot * (kGPL + 1) + k];
+                const double c = A.v_k + d;
+                const CE e = ((wq >> (8 * k)) & 1u) ? CE{0.0, d, d} : CE{c, A.v_lo + c, A.v_hi + c};
+                P = COp::combine(P, e);
+            }
+        }
+        (void)block_scan_exclusive<COp, false>(P, lds, &enter);
+    }
+    // ---- own genes: fold, exclusive scan over the workgroup, replay
+    const int cnt = min(kGPL, A.n_genes - g0);
+    double dv[kGPL];
+    uint32_t first = 0, last = 0;
+    CE P = COp::identity();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        dv[k] = stg.st[slot * (kGPL + 1) + k];
+        const uint32_t f = uint32_t(wf >> (8 * k)) & 0xffu;
+        first |= (f & 1u) << k;
+        last |= ((f >> 1) & 1u) << k;
+        if (k < cnt) {
+            const double c = A.v_k + dv[k];
+            const CE e = (f & 1u) ? CE{0.0, dv[k], dv[k]} : CE{c, A.v_lo + c, A.v_hi + c};
+            P = COp::combine(P, e);
+        }
+    }
+    CE total;
+    const CE excl = block_scan_exclusive<COp, false>(P, lds, &total);
+    const CE M = COp::combine(enter, excl);
+    double D = M.L;
+    uint32_t maps = 0, lane_map = MapOp::identity();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        if (k < cnt) {
+            D = ((first >> k) & 1u) ? dv[k] : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dv[k]);
+            const uint32_t m = ((last >> k) & 1u) ? (D > 0.0 ? 3u : 0u) : ((D > A.v_hi ? 1u : 0u) | (D > A.v_lo ? 2u : 0u));
+            maps |= m << (2 * k);
+        }
+    }
+#pragma unroll
+    for (int k = kGPL - 1; k >= 0; --k)
+        if (k < cnt) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
+    A.vMaps[blockIdx.x * kT + slot] = maps;
+    xch[kT - 1 - slot] = lane_map;
+    __syncthreads();
+    const uint32_t mine = xch[slot];
+    uint32_t mtotal;
+    const uint32_t mexcl = block_scan_exclusive<MapOp, true>(mine, ldsm, &mtotal);
+    __syncthreads();
+    xch[kT - 1 - slot] = mexcl;
+    __syncthreads();
+    A.vLaneMap[blockIdx.x * kT + slot] = xch[slot];
+    if (slot == 0) A.vBlockMap[blockIdx.x] = mtotal;
+}
+
 __global__ void __launch_bounds__(kT) v_scores(const SeqArgs A, const int32_t *__restrict__ contig_ptr) {
     const int c = blockIdx.x * kT + threadIdx.x;
     if (c >= A.n_contigs) return;
@@ -723,8 +825,12 @@ hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hip
 hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream) {
     if (a.n_contigs <= 0 || a.n_genes <= 0) return hipSuccess;
     const int nb = (a.n_genes + kBlockGenes - 1) / kBlockGenes;
-    hipLaunchKernelGGL(vd_fold, dim3(nb), dim3(kT), 0, stream, a);
-    hipLaunchKernelGGL(vd_replay, dim3(nb), dim3(kT), 0, stream, a);
+    if (a.short_contigs) {
+        hipLaunchKernelGGL(vd_fused, dim3(nb), dim3(kT), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(vd_fold, dim3(nb), dim3(kT), 0, stream, a);
+        hipLaunchKernelGGL(vd_replay, dim3(nb), dim3(kT), 0, stream, a);
+    }
     hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, a);
     return hipGetLastError();
 }

@@ -142,6 +142,34 @@ def test_viterbi_difference_form(nat, real, oracle_model, seed, monkeypatch):
     assert np.array_equal(y, ym)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_viterbi_short_contigs_single_kernel(nat, real, oracle_model, seed):
+    """No contig longer than one 2048-gene scan block: fold and replay run as one kernel that looks
+    back by recomputing the stretch between the contig start and the block.  Contig boundaries are
+    placed on, just before and just after block boundaries."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(400 + seed)
+    if seed == 0:
+        w, trans, model = oracle_model["state"], oracle_model["trans"], real
+        lengths = [2048, 2048, 1, 2047, 2048, 5, 2043, 2048, 2000, 48, 1, 1, 2046] + list(rng.integers(1, 2049, size=60))
+    elif seed == 1:
+        w = rng.integers(-1, 2, size=(6, 2)).astype(float)
+        trans = np.array([[1.0, -1.0], [-1.0, 1.0]])
+        model = nat.Model.from_tables(w, trans)
+        lengths = [2048, 3, 2045, 2048, 1024, 1024, 1, 2047] + list(rng.integers(1, 2049, size=30))
+    else:
+        w = np.zeros((8, 2))
+        w[0], w[1] = (1.0, 0.0), (0.0, 1.0)
+        trans = np.array([[1.0, -3.0], [-3.0, 1.0]])
+        model = nat.Model.from_tables(w, trans)
+        lengths = list(rng.integers(1500, 2049, size=40))
+    cptr, gptr, attr = synth_contigs(rng, lengths, w.shape[0])
+    y, _ = model.viterbi(cptr, gptr, attr, want_score=False)
+    ey, _ = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y, ey.astype(np.int8))
+
+
 def test_viterbi_antisticky_model_falls_back_to_matrix_form(nat):
     """t01 - t11 > t00 - t10: the difference recursion is not a clamp; the general form must be used."""
     from oracle import crf_oracle as orc
