@@ -68,16 +68,19 @@ constexpr int kGatherUnroll = 8;  // attribute loads in flight per slot before t
 // them (every lane owns JMAX slots and has their dependent load chains in flight together: the
 // chain of four memory round trips is what a workgroup spends most of its life on), then TT DP
 // phases of NT window starts each.
-template <int WMAX, int NT, int TT>
+template <int WMAX, int NT, int TT, bool EXACT>
 struct WinSmem {
     static constexpr int JMAX = TT == 1 ? 2 : TT;             // slots a lane may own
     static constexpr int CAP = TT == 1 ? NT + WMAX - 1 : TT * NT;  // slot capacity of the workgroup
+    // a contig occupies at least W slots (shorter ones are padded or not scored at all)
+    static constexpr int CMAX = EXACT ? CAP / WMAX + 3 : CAP + 2;  // contigs a workgroup can overlap
     f64x2 ef[CAP];                  // per slot: (e0, f = mu01*e1)   with e = exp(s - max s), "other" first
+    double rr[CAP];                 // per slot: f / e0 = mu01 * exp(s[label] - s[other])  (ratio form of the DP)
     uint32_t ginfo[CAP];            // per slot: bit 31 = a window may start here; low bits = gene + 1 (0: none)
     f64x2 carry[NT / 64][WMAX];     // running best leaving lane 63 of each wave, per step
-    int32_t cslot[CAP + 2];         // slot offsets of the contigs this workgroup overlaps (irregular tiles)
-    int32_t cgene[CAP + 1];
-    int32_t cn[CAP + 1];
+    int32_t cslot[CMAX];            // slot offsets of the contigs this workgroup overlaps (irregular tiles)
+    int32_t cgene[CMAX];
+    int32_t cn[CMAX];
 };
 
 struct SlotInfo {
@@ -184,10 +187,13 @@ __device__ __forceinline__ void state_scores_buf(__amdgpu_buffer_rsrc_t ra, __am
 //   in x / (x + y).
 template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT>
 // minimum waves per SIMD the register allocation must allow: the Z-constant DP keeps W doubles of
-// alpha (8 waves at W = 20, 5 at W <= 32), the rescaling variant 2 W (5 / 3)
-__global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <= 20 && TT <= 2 ? 8 : 5))) crf_windowed_l2(const WinArgs P) {
-    using Smem = WinSmem<WMAX, NT, TT>;
+// alpha (8 waves at W = 20, 3-5 at W <= 32), the rescaling variant 2 W (5 / 3)
+__global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <= 20 ? (TT <= 2 ? 8 : 5) : 3))) crf_windowed_l2(const WinArgs P) {
+    using Smem = WinSmem<WMAX, NT, TT, EXACT>;
     constexpr int JMAX = Smem::JMAX;
+    // the ratio form exists for fixed-length windows only (with a run-time W <= 32 the second copy of
+    // the unrolled DP costs more registers than it saves instructions)
+    constexpr bool RATIO = !RESCALE && EXACT;
     __shared__ Smem sm;
     const int W = EXACT ? WMAX : P.W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -263,6 +269,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
         off[j] = uint32_t(lo) - lo_tile;
         cnt[j] = uint32_t(hi - lo);
     }
+    bool big = false;  // some slot leans so far towards the label that the ratio form could overflow
     int ids[JMAX][kGatherUnroll];
 #pragma unroll
     for (int j = 0; j < JMAX; ++j)
@@ -300,11 +307,25 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                 const double e = exp_neg(fabs(d), P.expc);
                 const double e1 = d > 0.0 ? 1.0 : e;
                 sm.ef[sl] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
+                if (RATIO) {
+                    double inv = __builtin_amdgcn_rcp(e);  // exp(+|d|): only used when d is small enough
+                    inv = fma(fma(-e, inv, 1.0), inv, inv);
+                    sm.rr[sl] = P.mu01 * (d > 0.0 ? inv : e);
+                    big |= d > P.ratio_dmax;
+                }
                 sm.ginfo[sl] = (start[j] ? 0x80000000u : 0u) | uint32_t(gene[j] + 1);
             }
         }
     }
-    __syncthreads();
+    // Ratio form of the DP: dividing every position's emission pair by e0 turns the slot constant
+    // into the single number r = f / e0 and removes one multiplication from either recursion
+    //   forward : t = a0 + a1;  a1' = (a0 + rho a1) r;  a0' = t
+    //   backward: u = r b1;  b1' = b0 + rho u;  b0' = b0 + u
+    // (3 + 3 ops, 8 B of LDS per step).  The vectors then grow like exp(sum of positive score
+    // differences), so the workgroup takes this form only if every slot has d <= 600 / W; otherwise
+    // (a run of strongly label-leaning genes: rare) it uses the max-normalised form below.
+    bool ratio_ok = false;
+    if (RATIO) ratio_ok = !__syncthreads_or(big ? 1 : 0); else __syncthreads();
 
     const uint32_t rmask = P.rescale_mask;
     const double rho = P.rho;
@@ -315,7 +336,53 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
         const bool my_start = gi >> 31;
         const int my_gene = int(gi & 0x7fffffffu) - 1;
         const f64x2 *ef = sm.ef + sbase;
-        if constexpr (!RESCALE) {
+        if (RATIO && ratio_ok) {
+            const double *rr = sm.rr + sbase;
+            double A1[WMAX];
+            double a0 = 1.0, a1 = rr[0] * P.kappa_over_mu01;
+            A1[0] = a1;
+#pragma unroll
+            for (int k = 1; k < WMAX; ++k) {
+                if (EXACT || k < W) {
+                    const double r = rr[k];
+                    const double t = a0 + a1;
+                    a1 = fma(a1, rho, a0) * r;
+                    a0 = t;
+                    A1[k] = a1;
+                }
+            }
+            asm volatile("" ::: "memory");
+            double b0, b1;
+            {
+                const double z = fma(a1, P.inv_kappa, a0);
+                double r = __builtin_amdgcn_rcp(z);
+                r = fma(fma(-z, r, 1.0), r, r);
+                b0 = my_start ? r : 0.0;
+                b1 = b0 * P.inv_kappa;
+            }
+            double R = 0.0;
+            double *carry = reinterpret_cast<double *>(&sm.carry[0][0]);
+#pragma unroll
+            for (int k = WMAX - 1; k >= 0; --k) {
+                if (EXACT || k < W) {
+                    const double cand = A1[k] * b1;
+                    if (k < W - 1) {
+                        if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
+                        R = wave_shr1_zero(R);
+                    }
+                    R = fmax(R, cand);
+                    if (k > 0) {
+                        const double u = rr[k] * b1;
+                        b1 = fma(u, rho, b0);
+                        b0 = b0 + u;
+                    }
+                }
+            }
+            __syncthreads();
+            if (wave > 0 && lane < W - 1) R = fmax(R, carry[(wave - 1) * WMAX + lane]);
+            R = fmin(R, 1.0);
+            if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = R;
+        } else if constexpr (!RESCALE) {
             // ---- stage 2a: forward recursion.  Without rescaling the un-normalised vectors satisfy
             //   alpha_k[0] beta_k[0] + alpha_k[1] beta_k[1] = Z   at EVERY position k of the window
             // (all per-position scale factors and the basis change cancel), so the marginal of the

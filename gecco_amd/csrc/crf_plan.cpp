@@ -393,6 +393,10 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
             a.expc[13 - k] = 1.0 / f;
         }
     }
+    {
+        const char *env = std::getenv("GECCO_CRF_RATIO");
+        a.ratio_dmax = (env && env[0] == '0') ? -1e300 : 600.0 / double(p.W);
+    }
     a.generic = p.fast_ok ? 0 : 1;
     if (a.generic) {
         if (!p.d_win_scratch &&
