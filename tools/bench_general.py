@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Throughput of the any-label-count kernels (crf_general.hip) on a C2-shaped
+batch (1 000 contigs, ~2e5 genes, A = 35 000) for L = 3, 8, 32, and of the same kernels forced
+onto the 2-label model next to the specialised ones.  Run on the GPU box; prints one JSON object."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from gecco_amd import _native as nat, synth  # noqa: E402
+
+
+def timed(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    out = {}
+    rng = np.random.default_rng(synth.SEED)
+    A = 35000
+    lengths = synth.contig_lengths(rng, 1000)
+    cptr, gptr, attr = synth.synth_contigs(rng, lengths, A)
+    n = int(cptr[-1])
+    dev = torch.device("cuda:0")
+    d_gp = torch.from_numpy(gptr).to(dev)
+    d_at = torch.from_numpy(attr).to(dev)
+    for L in (2, 3, 8, 32):
+        if L == 2:
+            w, trans = synth.synth_model(A, rng)
+            os.environ["GECCO_CRF_FORCE_GENERAL"] = "1"
+        else:
+            os.environ.pop("GECCO_CRF_FORCE_GENERAL", None)
+            w = np.clip(rng.laplace(0.0, 1.7, size=(A, L)), -6.3, 12.7)
+            trans = rng.normal(0, 1.5, size=(L, L))
+        model = nat.Model.from_tables(w, trans)
+        plan = nat.Plan(model, cptr, 20, 1, True, device=0)
+        p = torch.zeros(n, dtype=torch.float64, device=dev)
+        y = torch.zeros(n, dtype=torch.int8, device=dev)
+        marg = torch.zeros(n, L, dtype=torch.float64, device=dev)
+        res = {"kernel": plan.kernel_name, "genes": n}
+        for name, fn in (("windowed", lambda: plan.run_windowed(d_gp.data_ptr(), d_at.data_ptr(), p.data_ptr(), L - 1)),
+                         ("viterbi", lambda: plan.run_viterbi(d_gp.data_ptr(), d_at.data_ptr(), y.data_ptr())),
+                         ("marginals_full", lambda: plan.run_marginals_full(d_gp.data_ptr(), d_at.data_ptr(), marg.data_ptr()))):
+            dt = timed(fn)
+            res[name] = {"ms": dt * 1e3, "genes_per_s": n / dt}
+        out[f"L={L}" + (" (2-label model forced onto the general kernels)" if L == 2 else "")] = res
+    os.environ.pop("GECCO_CRF_FORCE_GENERAL", None)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
