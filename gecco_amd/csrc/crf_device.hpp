@@ -42,6 +42,32 @@ constexpr int kWinThreads = 256;  // lanes (= window starts) per workgroup: 4 wa
 constexpr int kWinMaxW = 32;      // largest window the register-resident kernel handles
 constexpr int kWinTilesPerWg = 2; // default DP phases per workgroup (GECCO_CRF_TILES_PER_WG=1..3 overrides; A/B runs)
 
+// ---- shared device helpers ----------------------------------------------------------------------
+// exp(-t) for t >= 0: n = rint(t log2 e), r = n ln2 - t in two pieces (|r| <= ln2/2), degree-13
+// Taylor polynomial (truncation 2e-18), v_ldexp_f64 for 2^-n (flushes to 0 by itself for huge t).
+// The coefficients 1/13! .. 1/2! (fill_exp_coefficients) travel as kernel arguments so that they sit in SGPRs: as literals
+// every one of them costs two v_mov per use, as many VALU slots as the polynomial itself.
+__device__ __forceinline__ double exp_neg(double t, const double (&kExpC)[12]) {
+    const double n = rint(t * 1.4426950408889634);
+    double r = fma(n, 0.6931471805599453094, -t);   // ln2 hi
+    r = fma(n, 2.3190468138462996e-17, r);           // ln2 lo
+    // exp(-t) = 2^-n exp(r),  r = n ln2 - t
+    double p = kExpC[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) p = fma(p, r, kExpC[i]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, -int(n));
+}
+
+inline void fill_exp_coefficients(double (&c)[12]) {
+    double f = 1.0;  // k!
+    for (int k = 2; k <= 13; ++k) {
+        f *= double(k);
+        c[13 - k] = 1.0 / f;
+    }
+}
+
 // ---- whole-contig kernels (crf_sequence.hip) ------------------------------------------------
 constexpr int kSeqGenesPerLane = 8;  // genes folded sequentially by one lane of the flat scans
 constexpr int kSeqBlockGenes = 256 * kSeqGenesPerLane;  // genes per workgroup of the flat scans
@@ -70,6 +96,7 @@ struct SeqArgs {
     double t00, t01, t10, t11;  // raw transition weights (Viterbi)
     double mx;                  // max(trans)
     double v_lo, v_hi, v_k;     // difference-form Viterbi: t01-t11, t00-t10, t11-t00
+    double expc[12];            // Taylor coefficients of exp (SGPR-resident), see exp_neg
     // workspaces: one element per lane (n_genes / kSeqGenesPerLane) or per workgroup
     VE *vLane, *vBlock;
     uint32_t *vMaps, *vLaneMap, *vBlockMap;

@@ -128,23 +128,6 @@ __device__ __forceinline__ void state_scores_l2(const int32_t *__restrict__ attr
     }
 }
 
-// exp(-t) for t >= 0: n = rint(t log2 e), r = n ln2 - t in two pieces (|r| <= ln2/2), degree-13
-// Taylor polynomial (truncation 2e-18), v_ldexp_f64 for 2^-n (flushes to 0 by itself for huge t).
-// The coefficients 1/13! .. 1/2! travel as kernel arguments so that they sit in SGPRs: as literals
-// every one of them costs two v_mov per use, as many VALU slots as the polynomial itself.
-__device__ __forceinline__ double exp_neg(double t, const double (&kExpC)[12]) {
-    const double n = rint(t * 1.4426950408889634);
-    double r = fma(n, 0.6931471805599453094, -t);   // ln2 hi
-    r = fma(n, 2.3190468138462996e-17, r);           // ln2 lo
-    // exp(-t) = 2^-n exp(r),  r = n ln2 - t
-    double p = kExpC[0];
-#pragma unroll
-    for (int i = 1; i < 12; ++i) p = fma(p, r, kExpC[i]);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, -int(n));
-}
-
 // Branch-free variant for the windowed kernel, on buffer descriptors: an out-of-range raw buffer
 // load returns 0 instead of faulting, so (a) the kGatherUnroll attribute ids of a gene are loaded
 // unconditionally (the ones past the gene's run belong to the next genes or lie past the end of

@@ -386,13 +386,7 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
         a.g10 = G(label, o);
         a.g11 = G(label, label);
     }
-    {
-        double f = 1.0;  // k!
-        for (int k = 2; k <= 13; ++k) {
-            f *= double(k);
-            a.expc[13 - k] = 1.0 / f;
-        }
-    }
+    fill_exp_coefficients(a.expc);
     {
         const char *env = std::getenv("GECCO_CRF_RATIO");
         a.ratio_dmax = (env && env[0] == '0') ? -1e300 : 600.0 / double(p.W);
@@ -524,6 +518,7 @@ int fill_seq_args(Plan &p, SeqArgs &a) {
     a.v_lo = a.t01 - a.t11;
     a.v_hi = a.t00 - a.t10;
     a.v_k = a.t11 - a.t00;
+    fill_exp_coefficients(a.expc);
     return GECCO_CRF_OK;
 }
 }  // namespace

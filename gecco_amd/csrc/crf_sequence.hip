@@ -14,9 +14,9 @@
 //
 // Scan levels: a lane folds kGPL consecutive genes (registers, sequential; coalesced loads
 // transposed through padded LDS), a wave scans its 64 lane products with DPP row_shr/row_bcast
-// (no LDS), the four wave totals meet in LDS.  Per-workgroup totals: V looks back over the
-// neighbouring workgroups' totals inside the replay kernel (see lookback_prefix), F still runs a
-// single-workgroup scan kernel.  Every gene is then replayed from the exact value entering its
+// (no LDS), the four wave totals meet in LDS.  Per-workgroup totals are never scanned by a launch of
+// their own: the consumer kernels look back / ahead over the neighbouring workgroups' totals (see
+// lookback_prefix, lookahead_suffix).  Every gene is then replayed from the exact value entering its
 // lane, using CRFsuite's operation order inside the lane.  Values entering a lane come from
 // composed elements, i.e. they equal the strictly sequential values whenever the additions are
 // exact (integer-valued weights: ties and first-argmax included) and to rounding otherwise.
@@ -60,6 +60,20 @@ struct FOp {
         c.ex = a.ex + b.ex + double(e);
         c.ms = a.ms + b.ms;
         c.rs = a.rs;
+        return c;
+    }
+};
+// Backward matrices B_t (beta_t = B_t beta_{t+1}): a contig's last gene contributes 1 1^T, so whatever
+// follows it only scales the product; `rs` marks "contains a last gene" and the EARLIER element absorbs.
+struct FOpB {
+    static __device__ __forceinline__ FE identity() { return FOp::identity(); }
+    static __device__ __forceinline__ FE combine(const FE &a, const FE &b) {  // a earlier in the sequence
+        if (a.rs != 0.0) return a;
+        FE bb = b;
+        const double flag = b.rs;
+        bb.rs = 0.0;
+        FE c = FOp::combine(a, bb);
+        c.rs = flag;
         return c;
     }
 };
@@ -156,30 +170,6 @@ __device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /
     return comb<Op, REV>(pre, excl);
 }
 
-// Single-workgroup exclusive scan over per-workgroup totals (in place); 1024 lanes so that the
-// ~10^3 totals of a 2 M-gene batch are one pass.
-constexpr int kTS = 1024;
-template <class Op, bool REV, class E>
-__global__ void __launch_bounds__(kTS) scan_block_totals(E *agg, int n) {
-    __shared__ E lds[kTS / 64];
-    __shared__ E carry_s;
-    if (threadIdx.x == 0) carry_s = Op::identity();
-    __syncthreads();
-    for (int base = 0; base < n; base += kTS) {
-        // REV: element i of the scan is block n-1-i
-        const int i = base + threadIdx.x;
-        const int idx = REV ? n - 1 - i : i;
-        const E mine = i < n ? agg[idx] : Op::identity();
-        E total;
-        const E excl = block_scan_exclusive<Op, REV, E, kTS>(mine, lds, &total);
-        const E carry = carry_s;
-        if (i < n) agg[idx] = comb<Op, REV>(carry, excl);
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = comb<Op, REV>(carry, total);
-        __syncthreads();
-    }
-}
-
 // Look-back over per-workgroup totals instead of a separate scan launch: the exclusive prefix of
 // workgroup b is total[j] (x) ... (x) total[b-1] from the nearest workgroup j whose span contains a
 // contig start (`rs`), because everything before a contig start is forgotten.  With contigs of a
@@ -233,6 +223,39 @@ __device__ __forceinline__ CE lookback_prefix(const CE *__restrict__ totals, int
         const CE r{bc(s.a), bc(s.L), bc(s.H)};
         acc = COp::combine(r, acc);
         if (acc.L == acc.H) break;  // a constant map: nothing further back can matter
+    }
+    return acc;
+}
+
+__device__ __forceinline__ FE wave_bcast63(const FE &v) {
+    auto b = [](double x) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+    };
+    return FE{b(v.a00), b(v.a01), b(v.a10), b(v.a11), b(v.ex), b(v.ms), b(v.rs)};
+}
+__device__ __forceinline__ FE lookback_prefix(const FE *__restrict__ totals, int b) {
+    const int lane = threadIdx.x & 63;
+    FE acc = FOp::identity();
+    for (int hi = b; hi > 0; hi -= 64) {
+        const int idx = hi - 1 - lane;
+        const FE e = idx >= 0 ? totals[idx] : FOp::identity();
+        const FE r = wave_bcast63(wave_scan_inclusive<FOp, true>(e));
+        acc = FOp::combine(r, acc);
+        if (r.rs != 0.0) break;
+    }
+    return acc;
+}
+// suffix of the backward matrices of the workgroups to the right, up to the first one that contains a
+// contig end
+__device__ __forceinline__ FE lookahead_suffix(const FE *__restrict__ totals, int b, int nb) {
+    const int lane = threadIdx.x & 63;
+    FE acc = FOpB::identity();
+    for (int lo = b + 1; lo < nb; lo += 64) {
+        const int idx = lo + lane;
+        const FE e = idx < nb ? totals[idx] : FOpB::identity();
+        const FE r = wave_bcast63(wave_scan_inclusive<FOpB, false>(e));
+        acc = FOpB::combine(acc, r);
+        if (acc.rs != 0.0) break;
     }
     return acc;
 }
@@ -339,6 +362,36 @@ __device__ __forceinline__ LaneGenes load_lane(const SeqArgs &A, int slot, LaneS
     }
     __syncthreads();  // the stage may be reused
     return L;
+}
+
+// Per-lane rows of kGPL consecutive 16-byte entries <-> global memory with coalesced accesses: a lane
+// touching its own kGPL entries directly hits 64 different cache lines per instruction.  Same
+// padded LDS transpose as load_lane; `stg` must not be in use (both end with a barrier).
+__device__ __forceinline__ void store_lane_rows(double2 *__restrict__ gmem, int n_genes, int slot, const double2 (&v)[kGPL],
+                                                LaneStage &stg) {
+    const int base = blockIdx.x * kT * kGPL;
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) stg.st[slot * (kGPL + 1) + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kGPL; ++j) {
+        const int idx = j * kT + slot, g = base + idx;
+        if (g < n_genes) gmem[g] = stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL];
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void load_lane_rows(const double2 *__restrict__ gmem, int n_genes, int slot, double2 (&v)[kGPL],
+                                               LaneStage &stg) {
+    const int base = blockIdx.x * kT * kGPL;
+#pragma unroll
+    for (int j = 0; j < kGPL; ++j) {
+        const int idx = j * kT + slot, g = base + idx;
+        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = g < n_genes ? gmem[g] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) v[k] = stg.st[slot * (kGPL + 1) + k];
+    __syncthreads();
 }
 
 // =====================================================================================
@@ -662,13 +715,16 @@ __global__ void __launch_bounds__(kT) v_scores(const SeqArgs A, const int32_t *_
 // factors cancel in P_t(y) = alpha_t[y] beta_t[y] / (alpha_t . beta_t); exponents and emission
 // maxima are carried along only for log Z.
 // =====================================================================================
-__device__ __forceinline__ double2 emit_norm(double2 s, double &m) {
-    m = fmax(s.x, s.y);
-    return make_double2(exp(s.x - m), exp(s.y - m));
+// exp(s - max s): one of the two is exp(0) = 1 exactly, the other one exp(-|s1 - s0|)
+__device__ __forceinline__ double2 emit_norm(const SeqArgs &A, double2 s, double &m) {
+    const double d = s.y - s.x;
+    const double e = exp_neg(fabs(d), A.expc);
+    m = d > 0.0 ? s.y : s.x;
+    return d > 0.0 ? make_double2(e, 1.0) : make_double2(1.0, e);
 }
 __device__ __forceinline__ FE f_step(const SeqArgs &A, double2 s, bool first) {
     double m;
-    const double2 e = emit_norm(s, m);
+    const double2 e = emit_norm(A, s, m);
     return FE{(first ? 1.0 : A.m00) * e.x, (first ? 1.0 : A.m01) * e.y, (first ? 1.0 : A.m10) * e.x,
               (first ? 1.0 : A.m11) * e.y, 0.0, m, first ? 1.0 : 0.0};
 }
@@ -695,17 +751,19 @@ __global__ void __launch_bounds__(kT) f_replay(const SeqArgs A) {
     __shared__ LaneStage stg;
     const int slot = threadIdx.x;
     const LaneGenes L = load_lane(A, slot, stg);
-    const FE M = FOp::combine(A.fBlock[blockIdx.x], A.fLane[blockIdx.x * kT + slot]);
+    const FE M = FOp::combine(lookback_prefix(A.fBlock, blockIdx.x), A.fLane[blockIdx.x * kT + slot]);
     // alpha entering the lane = a row of M (rows are identical once a contig has started), with the
     // exponent and emission-maximum sums accumulated since that contig's first gene
     double a0 = M.a00, a1 = M.a01, ex = M.ex, ms = M.ms;
     const double2 s_next = (L.cnt == kGPL && L.g0 + kGPL < A.n_genes) ? A.state[L.g0 + kGPL] : make_double2(0.0, 0.0);
     FE Bfold = FOp::identity();
+    double2 al[kGPL];
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
+        al[k] = make_double2(0.0, 0.0);
         if (k < L.cnt) {
             double m;
-            const double2 e = emit_norm(L.s[k], m);
+            const double2 e = emit_norm(A, L.s[k], m);
             double n0, n1;
             if ((L.first >> k) & 1u) {  // alpha_0 = exp(s_0): restart exactly
                 n0 = n1 = 1.0;
@@ -723,7 +781,7 @@ __global__ void __launch_bounds__(kT) f_replay(const SeqArgs A) {
             a1 = ldexp(a1, -ee);
             ex += double(ee);
             ms += m;
-            A.alpha[L.g0 + k] = make_double2(a0, a1);
+            al[k] = make_double2(a0, a1);
             if ((L.last >> k) & 1u) {
                 // log Z' of the contig (max-normalised emissions / transitions) and its emission maxima
                 A.contigTmp[L.g0 + k] = make_double2(ex * 0.6931471805599453 + log(a0 + a1), ms);
@@ -733,18 +791,19 @@ __global__ void __launch_bounds__(kT) f_replay(const SeqArgs A) {
             const double2 sn = k + 1 < kGPL ? L.s[k + 1 < kGPL ? k + 1 : k] : s_next;
             FE B;
             if (last) {
-                B = FE{1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0};
+                B = FE{1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0};  // rs: everything after this gene only scales the product
             } else {
                 B = f_step(A, sn, false);
             }
-            Bfold = FOp::combine(Bfold, B);  // B_{g0} B_{g0+1} ... in sequence order
+            Bfold = FOpB::combine(Bfold, B);  // B_{g0} B_{g0+1} ... in sequence order
         }
     }
+    store_lane_rows(A.alpha, A.n_genes, slot, al, stg);
     xch[kT - 1 - slot] = Bfold;
     __syncthreads();
     const FE mine = xch[slot];
     FE total;
-    const FE excl = block_scan_exclusive<FOp, true>(mine, lds, &total);
+    const FE excl = block_scan_exclusive<FOpB, true>(mine, lds, &total);
     __syncthreads();
     xch[kT - 1 - slot] = excl;
     __syncthreads();
@@ -756,20 +815,22 @@ __global__ void __launch_bounds__(kT) f_marginals(const SeqArgs A) {
     __shared__ LaneStage stg;
     const int slot = threadIdx.x;
     const LaneGenes L = load_lane(A, slot, stg);
-    if (L.cnt <= 0) return;
+    double2 al[kGPL], out[kGPL];
+    load_lane_rows(A.alpha, A.n_genes, slot, al, stg);
     // beta entering from the right of the lane: (suffix of the lanes to the right) 1
-    const FE S = FOp::combine(A.fLaneSuf[blockIdx.x * kT + slot], A.fBlockSuf[blockIdx.x]);
+    const FE S = FOpB::combine(A.fLaneSuf[blockIdx.x * kT + slot], lookahead_suffix(A.fBlockSuf, blockIdx.x, gridDim.x));
     double b0 = S.a00 + S.a01, b1 = S.a10 + S.a11;
     const double2 s_next = (L.cnt == kGPL && L.g0 + kGPL < A.n_genes) ? A.state[L.g0 + kGPL] : make_double2(0.0, 0.0);
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) {
+        out[k] = make_double2(0.0, 0.0);
         if (k < L.cnt) {
             // beta_k = B_k beta_{k+1}
             if ((L.last >> k) & 1u) {
                 b0 = b1 = 1.0;
             } else {
                 double m;
-                const double2 e = emit_norm(k + 1 < kGPL ? L.s[k + 1 < kGPL ? k + 1 : k] : s_next, m);
+                const double2 e = emit_norm(A, k + 1 < kGPL ? L.s[k + 1 < kGPL ? k + 1 : k] : s_next, m);
                 const double c0 = e.x * b0, c1 = e.y * b1;
                 b0 = fma(A.m01, c1, A.m00 * c0);
                 b1 = fma(A.m11, c1, A.m10 * c0);
@@ -778,11 +839,13 @@ __global__ void __launch_bounds__(kT) f_marginals(const SeqArgs A) {
                 b0 = ldexp(b0, -ee);
                 b1 = ldexp(b1, -ee);
             }
-            const double2 al = A.alpha[L.g0 + k];
-            const double x0 = al.x * b0, x1 = al.y * b1, z = x0 + x1;
-            *reinterpret_cast<double2 *>(A.marg + 2 * size_t(L.g0 + k)) = make_double2(x0 / z, x1 / z);
+            const double x0 = al[k].x * b0, x1 = al[k].y * b1, z = x0 + x1;
+            double r = __builtin_amdgcn_rcp(z);  // one reciprocal (+ Newton step) instead of two divisions
+            r = fma(fma(-z, r, 1.0), r, r);
+            out[k] = make_double2(x0 * r, x1 * r);
         }
     }
+    store_lane_rows(reinterpret_cast<double2 *>(A.marg), A.n_genes, slot, out, stg);
 }
 
 // log Z of contig c = log Z' + its emission maxima + (n-1) max(trans)
@@ -847,9 +910,7 @@ hipError_t launch_seq_marginals(const SeqArgs &a, const int32_t *d_contig_ptr, h
     if (a.n_genes > 0) {
         const int nb = (a.n_genes + kBlockGenes - 1) / kBlockGenes;
         hipLaunchKernelGGL(f_fold, dim3(nb), dim3(kT), 0, stream, a);
-        hipLaunchKernelGGL((scan_block_totals<FOp, false, FE>), dim3(1), dim3(kTS), 0, stream, reinterpret_cast<FE *>(a.fBlock), nb);
         hipLaunchKernelGGL(f_replay, dim3(nb), dim3(kT), 0, stream, a);
-        hipLaunchKernelGGL((scan_block_totals<FOp, true, FE>), dim3(1), dim3(kTS), 0, stream, reinterpret_cast<FE *>(a.fBlockSuf), nb);
         hipLaunchKernelGGL(f_marginals, dim3(nb), dim3(kT), 0, stream, a);
     }
     if (a.lognorm) hipLaunchKernelGGL(f_lognorm, grid_for(a.n_contigs, kT), dim3(kT), 0, stream, a, d_contig_ptr);

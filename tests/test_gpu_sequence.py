@@ -81,6 +81,19 @@ def test_viterbi_exact_ties_integer_weights(nat, seed):
     assert np.array_equal(sc, esc)
 
 
+def test_full_marginals_very_long_contigs(real, oracle_model):
+    """Contigs spanning > 64 workgroups: the look-back over forward totals and the look-ahead over
+    backward totals both take more than one 64-wide step; also contig ends on workgroup borders."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(78)
+    cptr, gptr, attr = synth_contigs(rng, [300000, 3, 140000, 2049, 2048, 2048, 1, 4095], oracle_model["state"].shape[0])
+    marg, ln = real.marginals_full(cptr, gptr, attr)
+    emarg, eln = orc.full_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    assert np.abs(marg - emarg).max() <= 1e-12
+    assert np.abs(ln - eln).max() <= 1e-9 * np.abs(eln).max()
+
+
 @pytest.mark.parametrize("integer_weights", [False, True])
 def test_viterbi_very_long_contigs_walk_back_many_workgroups(nat, real, oracle_model, integer_weights):
     """Contigs spanning > 64 workgroups of 2048 genes: the look-back over workgroup totals (prefix
