@@ -102,3 +102,10 @@ def test_golden_cluster_through_columnar_predict(nat, oracle_model):
             for r in sorted(by_gene.get(pid, []), key=lambda r: int(r["domain_start"]))]
     exp = oc.domain_composition([r["domain"] for r in rows], [1 - float(r["pvalue"]) for r in rows], all_possible)
     assert np.array_equal(comps[0], exp)
+
+
+def test_no_clusters_and_no_domains(nat):
+    out = nat.domain_composition(np.zeros((0, 4), dtype=np.int32), [0, 1, 2], [3, 4], [0.5, 0.25], 10)
+    assert out.shape == (0, 10)
+    out = nat.domain_composition(np.array([(0, 1, 0, 3)], dtype=np.int32), [0, 0, 0, 0], [], [], 10)
+    assert out.shape == (1, 10) and not out.any()

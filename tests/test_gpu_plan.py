@@ -119,3 +119,38 @@ def test_batch_whose_attribute_array_ends_inside_a_gather(nat, real, oracle_mode
     got = real.windowed_marginals(cptr2, gptr2, attr2, 20)
     exp2 = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr2, gptr2, attr2, 20)
     assert np.abs(got - exp2).max() <= 1e-12
+
+
+def test_decode_edge_batches(nat, real, oracle_model):
+    """Empty batch, empty contigs in the middle, and a batch in which pad=False skips every contig
+    (marginals are all 'no prediction', Viterbi labels are still decoded)."""
+    from oracle import crf_oracle as orc
+
+    plan = nat.Plan(real, [0], 20, 1, True, device=0)
+    plan.run_decode(0, 0, 0, 0)  # nothing to do, nothing dereferenced
+    plan.run_windowed(0, 0, 0)
+    plan.run_viterbi(0, 0, 0)
+
+    rng = np.random.default_rng(5)
+    A = oracle_model["state"].shape[0]
+    cptr, gptr, attr = synth_contigs(rng, [30, 0, 0, 25, 0, 400], A)
+    d_gp, d_at = _dev(gptr, attr)
+    n = int(cptr[-1])
+    p = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    y = torch.zeros(n, dtype=torch.int8, device="cuda:0")
+    nat.Plan(real, cptr, 20, 1, True, device=0).run_decode(d_gp.data_ptr(), d_at.data_ptr(), p.data_ptr(), y.data_ptr())
+    torch.cuda.synchronize()
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20)
+    ey, _ = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    assert np.abs(p.cpu().numpy() - exp).max() <= 1e-12 and np.array_equal(y.cpu().numpy().astype(np.int32), ey)
+
+    cptr, gptr, attr = synth_contigs(rng, [5, 19, 1, 7], A)
+    d_gp, d_at = _dev(gptr, attr)
+    n = int(cptr[-1])
+    p = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    y = torch.full((n,), 7, dtype=torch.int8, device="cuda:0")
+    nat.Plan(real, cptr, 20, 1, False, device=0).run_decode(d_gp.data_ptr(), d_at.data_ptr(), p.data_ptr(), y.data_ptr())
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(p).all())
+    ey, _ = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    assert np.array_equal(y.cpu().numpy().astype(np.int32), ey)
