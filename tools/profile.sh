@@ -9,8 +9,9 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
 B="python bench.py --no-cpu-baseline $*"
-timeout 180 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B --steps 20 --warmup 3 > $O/kt.log 2>&1
-S="--steps 3 --warmup 1 --kernel-iters 3"
+# kernel trace of the default bench run (device pre-roll + 100 warmup + 1000 timed steps + 200 kernel timings)
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B > $O/kt.log 2>&1
+S="--steps 3 --warmup 1 --kernel-iters 3 --preroll-ms 0"  # few dispatches: the PMC passes serialise and slow every launch
 timeout 180 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc1 -o pmc1 -- $B $S > $O/pmc1.log 2>&1
 timeout 180 rocprofv3 --pmc FETCH_SIZE -d $O/pmc2 -o pmc2 -- $B $S > $O/pmc2.log 2>&1
 timeout 180 rocprofv3 --pmc WRITE_SIZE -d $O/pmc3 -o pmc3 -- $B $S > $O/pmc3.log 2>&1
