@@ -81,7 +81,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("GECCO_CRF_LIBRARY") or LIB_PATH  # the variable is for A/B runs of two builds
     if not os.path.exists(p):
         raise ImportError(
             f"{p} not found: build it with `python -m gecco_amd.build` (hipcc, gfx950). "

@@ -61,6 +61,18 @@ __device__ __forceinline__ double exp_neg(double t, const double (&kExpC)[12]) {
     return ldexp(p, -int(n));
 }
 
+// exp(x) for any sign with the same polynomial: overflows to +inf / flushes to 0 through v_ldexp_f64
+__device__ __forceinline__ double exp_signed(double x, const double (&kExpC)[12]) {
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(-n, 0.6931471805599453094, x);
+    r = fma(-n, 2.3190468138462996e-17, r);
+    double p = kExpC[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) p = fma(p, r, kExpC[i]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, int(n));
+}
 inline void fill_exp_coefficients(double (&c)[12]) {
     double f = 1.0;  // k!
     for (int k = 2; k <= 13; ++k) {

@@ -74,8 +74,8 @@ struct WinSmem {
     static constexpr int CAP = TT == 1 ? NT + WMAX - 1 : TT * NT;  // slot capacity of the workgroup
     // a contig occupies at least W slots (shorter ones are padded or not scored at all)
     static constexpr int CMAX = EXACT ? CAP / WMAX + 3 : CAP + 2;  // contigs a workgroup can overlap
-    f64x2 ef[CAP];                  // per slot: (e0, f = mu01*e1)   with e = exp(s - max s), "other" first
-    double rr[CAP];                 // per slot: f / e0 = mu01 * exp(s[label] - s[other])  (ratio form of the DP)
+    f64x2 ef[CAP];                  // per slot: (e0, f = mu01*e1) with e = exp(s - max s), "other" first; or, in the
+                                    // ratio form, CAP doubles r = f / e0 = mu01 exp(s[label] - s[other]) in its first half
     uint32_t ginfo[CAP];            // per slot: bit 31 = a window may start here; low bits = gene + 1 (0: none)
     f64x2 carry[NT / 64][WMAX];     // running best leaving lane 63 of each wave, per step
     int32_t cslot[CMAX];            // slot offsets of the contigs this workgroup overlaps (irregular tiles)
@@ -256,6 +256,8 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
         cnt[j] = uint32_t(hi - lo);
     }
     bool big = false;  // some slot leans so far towards the label that the ratio form could overflow
+    double dsl[JMAX];  // s[label] - s[other] of the lane's slots
+    double *rr = reinterpret_cast<double *>(sm.ef);  // ratio form: r per slot, in the first half of the (e0, f) array
     int ids[JMAX][kGatherUnroll];
 #pragma unroll
     for (int j = 0; j < JMAX; ++j)
@@ -288,16 +290,17 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                 if (P.state_out) reinterpret_cast<f64x2 *>(P.state_out)[gene[j]] = P.label ? f64x2{s0, s1} : f64x2{s1, s0};
                 if (P.dstate_out) P.dstate_out[gene[j]] = P.label ? s1 - s0 : s0 - s1;
             }
+            dsl[j] = s1 - s0;
             if (sl < ns) {
-                const double d = s1 - s0;
-                const double e = exp_neg(fabs(d), P.expc);
-                const double e1 = d > 0.0 ? 1.0 : e;
-                sm.ef[sl] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
+                const double d = dsl[j];
                 if (RATIO) {
-                    double inv = __builtin_amdgcn_rcp(e);  // exp(+|d|): only used when d is small enough
-                    inv = fma(fma(-e, inv, 1.0), inv, inv);
-                    sm.rr[sl] = P.mu01 * (d > 0.0 ? inv : e);
+                    // r = mu01 exp(d); the max-normalised pair is only built if the workgroup needs it
+                    rr[sl] = P.mu01 * exp_signed(d, P.expc);
                     big |= d > P.ratio_dmax;
+                } else {
+                    const double e = exp_neg(fabs(d), P.expc);
+                    const double e1 = d > 0.0 ? 1.0 : e;
+                    sm.ef[sl] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
                 }
                 sm.ginfo[sl] = (start[j] ? 0x80000000u : 0u) | uint32_t(gene[j] + 1);
             }
@@ -311,7 +314,24 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
     // differences), so the workgroup takes this form only if every slot has d <= 600 / W; otherwise
     // (a run of strongly label-leaning genes: rare) it uses the max-normalised form below.
     bool ratio_ok = false;
-    if (RATIO) ratio_ok = !__syncthreads_or(big ? 1 : 0); else __syncthreads();
+    if (RATIO) {
+        ratio_ok = !__syncthreads_or(big ? 1 : 0);
+        if (!ratio_ok) {  // rare: build (e0, f) over the r values (same LDS), from the differences still in registers
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const int sl = tid + j * NT;
+                if ((TT > 1 || j == 0 || wave == 0) && sl < ns) {
+                    const double d = dsl[j];
+                    const double e = exp_neg(fabs(d), P.expc);
+                    const double e1 = d > 0.0 ? 1.0 : e;
+                    sm.ef[sl] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
 
     if (P.prio) __builtin_amdgcn_s_setprio(0);
     const uint32_t rmask = P.rescale_mask;
@@ -324,14 +344,14 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
         const int my_gene = int(gi & 0x7fffffffu) - 1;
         const f64x2 *ef = sm.ef + sbase;
         if (RATIO && ratio_ok) {
-            const double *rr = sm.rr + sbase;
+            const double *rrs = rr + sbase;
             double A1[WMAX];
-            double a0 = 1.0, a1 = rr[0] * P.kappa_over_mu01;
+            double a0 = 1.0, a1 = rrs[0] * P.kappa_over_mu01;
             A1[0] = a1;
 #pragma unroll
             for (int k = 1; k < WMAX; ++k) {
                 if (EXACT || k < W) {
-                    const double r = rr[k];
+                    const double r = rrs[k];
                     const double t = a0 + a1;
                     a1 = fma(a1, rho, a0) * r;
                     a0 = t;
@@ -359,7 +379,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                     }
                     R = fmax(R, cand);
                     if (k > 0) {
-                        const double u = rr[k] * b1;
+                        const double u = rrs[k] * b1;
                         b1 = fma(u, rho, b0);
                         b0 = b0 + u;
                     }
