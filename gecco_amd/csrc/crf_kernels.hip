@@ -41,6 +41,15 @@ __device__ __forceinline__ double wave_shr1_zero(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// fmax() on a value that went through DPP bit moves first "canonicalises" it (v_max_f64 x, x, x: the
+// compiler cannot see that it is not a signalling NaN), i.e. two VALU ops per step of the diagonal
+// maximum instead of one.  The operands here are finite and non-negative.
+__device__ __forceinline__ double max_nocanon(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Workgroup b runs on XCD b % 8 (observed placement; speed only).  Give each XCD one
 // contiguous range of tiles so that the W-1 slot halo shared by neighbouring tiles is
 // served by the same L2.  Bijective for any nwg.
@@ -377,7 +386,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                         if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
                         R = wave_shr1_zero(R);
                     }
-                    R = fmax(R, cand);
+                    R = max_nocanon(R, cand);
                     if (k > 0) {
                         const double u = rrs[k] * b1;
                         b1 = fma(u, rho, b0);
@@ -439,7 +448,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                         if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
                         R = wave_shr1_zero(R);
                     }
-                    R = fmax(R, cand);
+                    R = max_nocanon(R, cand);
                     if (k > 0) {
                         const f64x2 c = ef[k];
                         const double cc = c.x * b0, u = c.y * b1;
