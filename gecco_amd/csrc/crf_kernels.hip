@@ -198,9 +198,6 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
     // case) maps slots to genes by a constant shift and takes its window-start flags from a
     // host-built bit array, so the CSR loads can leave immediately; otherwise the contig
     // table of its reach goes through LDS and every lane searches it.
-    // stage 1 is a chain of dependent memory round trips with little arithmetic: its few instructions
-    // go ahead of the DP instructions of the other resident workgroups
-    if (P.prio) __builtin_amdgcn_s_setprio(3);
     const int4 td = P.tile_desc[tile];  // (gene - slot shift, first contig, last contig, flags)
     int gene[JMAX];
     bool start[JMAX];
@@ -342,7 +339,6 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
         __syncthreads();
     }
 
-    if (P.prio) __builtin_amdgcn_s_setprio(0);
     const uint32_t rmask = P.rescale_mask;
     const double rho = P.rho;
 #pragma unroll 1

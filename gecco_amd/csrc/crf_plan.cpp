@@ -366,10 +366,6 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     a.n_genes = p.n_genes;
     a.A = m.A;
     a.tiles_per_wg = p.tiles_per_wg;
-    {
-        const char *env = std::getenv("GECCO_CRF_STAGE1_PRIO");
-        a.prio = (env && env[0] == '0') ? 0 : 1;
-    }
     a.rescale_mask = p.rescale_mask;
     {
         // exp() of differences only: every constant is a ratio of transition weights
