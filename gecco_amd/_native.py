@@ -50,7 +50,7 @@ SIGNATURES = {
     "gecco_crf_segment": (
         ctypes.c_int,
         [ctypes.c_int32, _c_f64p, _c_u8p, _c_i32p, ctypes.c_int32, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
-         ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p],
+         ctypes.c_int32, ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p],
     ),
     "gecco_crf_domain_composition": (
         ctypes.c_int,
@@ -68,6 +68,34 @@ SIGNATURES = {
     "gecco_crf_plan_run_decode": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     "gecco_crf_plan_run_marginals_full": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gecco_crf_plan_run_viterbi": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "gecco_crf_plan_run_segment": (
+        ctypes.c_int,
+        [_vp, _vp, _vp, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp],
+    ),
+    "gecco_crf_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "gecco_crf_host_free": (None, [_vp]),
+    "gecco_crf_session_create": (ctypes.c_int, [_vp, _c_i32p, ctypes.c_int32, ctypes.POINTER(_vp)]),
+    "gecco_crf_session_free": (None, [_vp]),
+    "gecco_crf_session_set_chunk_genes": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "gecco_crf_session_stats": (
+        ctypes.c_int,
+        [_vp, _c_i32p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _c_f64p, _c_f64p],
+    ),
+    "gecco_crf_session_windowed": (
+        ctypes.c_int,
+        [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p],
+    ),
+    "gecco_crf_session_decode": (
+        ctypes.c_int,
+        [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p,
+         _c_i8p],
+    ),
+    "gecco_crf_session_clusters": (
+        ctypes.c_int,
+        [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, _c_u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+         ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p, _c_i32p, ctypes.c_int32, _c_i32p, _c_f64p,
+         ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)],
+    ),
     "gecco_crf_plan_time_windowed": (
         ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]
     ),
@@ -270,7 +298,11 @@ def domain_composition(seg, dom_ptr, dom_col, dom_weight, n_cols, normalize=True
     return out
 
 
-def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, trim=True, device=0) -> np.ndarray:
+def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, trim=True, device=0,
+            carry_state=False) -> np.ndarray:
+    """Cluster rows (contig, number, first gene, last gene + 1) of per-gene probabilities.  `carry_state`:
+    False = one grouper per contig (the CLI's ``iter_clusters`` call per contig), True = one grouper
+    over all contigs (a single ``iter_clusters`` call)."""
     lib = load_library()
     p = np.ascontiguousarray(p, dtype=np.float64)
     annotated = np.ascontiguousarray(annotated, dtype=np.uint8)
@@ -281,10 +313,130 @@ def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, t
     _check(
         lib.gecco_crf_segment(
             device, _ptr(p, _c_f64p), _ptr(annotated, _c_u8p), _ptr(contig_ptr, _c_i32p), len(contig_ptr) - 1,
-            float(threshold), int(n_cds), int(edge_distance), int(bool(trim)), _ptr(seg, _c_i32p), cap, ctypes.byref(n_seg),
+            float(threshold), int(n_cds), int(edge_distance), int(bool(trim)), int(bool(carry_state)), _ptr(seg, _c_i32p), cap,
+            ctypes.byref(n_seg),
         )
     )
     return seg[: n_seg.value].copy()
+
+
+class _PinnedBlock:
+    """Owner of one gecco_crf_host_alloc block (freed when the last array over it dies)."""
+
+    def __init__(self, nbytes: int):
+        self._lib = load_library()
+        ptr = _vp()
+        _check(self._lib.gecco_crf_host_alloc(max(int(nbytes), 1), ctypes.byref(ptr)))
+        self.ptr = ptr.value
+        self.nbytes = max(int(nbytes), 1)
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            self._lib.gecco_crf_host_free(ptr)
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """numpy array over pinned (page-locked, device-visible) host memory: the batch driver copies to
+    and from such arrays asynchronously, so uploads, kernels and downloads of a batch overlap."""
+    dtype = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    block = _PinnedBlock(n * dtype.itemsize)
+    buf = (ctypes.c_char * block.nbytes).from_address(block.ptr)
+    buf._pinned_block = block  # numpy keeps `buf` (the buffer exporter) alive, `buf` keeps the block
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def pinned_copy(a, dtype=None) -> np.ndarray:
+    a = np.asarray(a, dtype=dtype)
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
+class Session:
+    """Batch driver over one or several devices (include/gecco_crf.h, `gecco_crf_session_*`): host
+    arrays in, host arrays out; contig chunks are dealt to the devices longest-first and pipelined
+    (upload / compute / download) on each of them."""
+
+    def __init__(self, model: "Model", devices: Sequence[int] = (0,)):
+        self._lib = load_library()
+        self.model = model  # the session must not outlive its model
+        devs = _i32(list(devices))
+        h = _vp()
+        _check(self._lib.gecco_crf_session_create(model._h, _ptr(devs, _c_i32p), len(devs), ctypes.byref(h)))
+        self._h = h
+        self.devices = [int(d) for d in devs]
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.gecco_crf_session_free(h)
+
+    def set_chunk_genes(self, genes: int) -> None:
+        _check(self._lib.gecco_crf_session_set_chunk_genes(self._h, int(genes)))
+
+    def stats(self) -> dict:
+        n = ctypes.c_int32(0)
+        h2d, d2h = ctypes.c_int64(0), ctypes.c_int64(0)
+        plan_s, wall_s = ctypes.c_double(0), ctypes.c_double(0)
+        _check(self._lib.gecco_crf_session_stats(self._h, ctypes.byref(n), ctypes.byref(h2d), ctypes.byref(d2h),
+                                                 ctypes.byref(plan_s), ctypes.byref(wall_s)))
+        return {"n_chunks": n.value, "h2d_bytes": h2d.value, "d2h_bytes": d2h.value, "host_plan_seconds": plan_s.value,
+                "wall_seconds": wall_s.value}
+
+    @staticmethod
+    def _csr(contig_ptr, gene_ptr, attr_id):
+        contig_ptr, gene_ptr, attr_id = _i32(contig_ptr), _i32(gene_ptr), _i32(attr_id)
+        if attr_id.size == 0:
+            attr_id = np.zeros(1, dtype=np.int32)
+        n = int(contig_ptr[-1]) if len(contig_ptr) else 0
+        return contig_ptr, gene_ptr, attr_id, n, max(len(contig_ptr) - 1, 0)
+
+    def windowed_marginals(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True, out=None):
+        contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
+        if out is None:
+            out = np.empty(max(n, 1), dtype=np.float64)
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.size >= n
+        _check(self._lib.gecco_crf_session_windowed(self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p),
+                                                    _ptr(attr_id, _c_i32p), int(window), int(step), int(label), int(bool(pad)),
+                                                    _ptr(out, _c_f64p)))
+        return out[:n]
+
+    def decode(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True):
+        contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
+        p = np.empty(max(n, 1), dtype=np.float64)
+        y = np.empty(max(n, 1), dtype=np.int8)
+        _check(self._lib.gecco_crf_session_decode(self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p),
+                                                  _ptr(attr_id, _c_i32p), int(window), int(step), int(label), int(bool(pad)),
+                                                  _ptr(p, _c_f64p), _ptr(y, _c_i8p)))
+        return p[:n], y[:n]
+
+    def clusters(self, contig_ptr, gene_ptr, attr_id, annotated, window, step=1, label=1, pad=True, threshold=0.8, n_cds=3,
+                 edge_distance=0, trim=True, want_p=False, want_seg_p=True, p_out=None):
+        """Windowed marginals + cluster calls in one pass; the probabilities stay on the device unless
+        `want_p` / `p_out`.  Returns (seg rows (k, 4), seg_p, seg_off, p or None): `seg_p[seg_off[i]:seg_off[i+1]]`
+        are the probabilities of the genes of row i."""
+        contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
+        annotated = np.ascontiguousarray(annotated, dtype=np.uint8)
+        if annotated.size == 0:
+            annotated = np.zeros(1, dtype=np.uint8)
+        if p_out is None and want_p:
+            p_out = np.empty(max(n, 1), dtype=np.float64)
+        cap = min(n, n // 2 + nc) + 1
+        seg = np.empty((cap, 4), dtype=np.int32)
+        seg_p = np.empty(max(n, 1), dtype=np.float64) if want_seg_p else None
+        seg_off = np.zeros(cap + 1, dtype=np.int64)
+        n_seg = ctypes.c_int32(0)
+        _check(self._lib.gecco_crf_session_clusters(
+            self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p), _ptr(attr_id, _c_i32p), _ptr(annotated, _c_u8p),
+            int(window), int(step), int(label), int(bool(pad)), float(threshold), int(n_cds), int(edge_distance), int(bool(trim)),
+            _ptr(p_out, _c_f64p) if p_out is not None else None, _ptr(seg, _c_i32p), cap, ctypes.byref(n_seg),
+            _ptr(seg_p, _c_f64p) if want_seg_p else None, max(n, 1), seg_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        k = n_seg.value
+        return (seg[:k].copy(), (seg_p[: seg_off[k]].copy() if want_seg_p else None), seg_off[: k + 1].copy(),
+                (p_out[:n] if p_out is not None else None))
 
 
 class Plan:
@@ -339,6 +491,13 @@ class Plan:
 
     def run_viterbi(self, d_gene_ptr: int, d_attr_id: int, d_y: int, d_score: int = 0, stream: int = 0):
         _check(self._lib.gecco_crf_plan_run_viterbi(self._h, d_gene_ptr, d_attr_id, d_y, d_score or None, stream or None))
+
+    def run_segment(self, d_p: int, d_annotated: int, d_seg: int, max_seg: int, d_n_seg: int, threshold=0.8, n_cds=3,
+                    edge_distance=0, trim=True, carry_state=False, stream: int = 0):
+        """Cluster rows of device-resident probabilities, on the same stream as the marginals (no copies)."""
+        _check(self._lib.gecco_crf_plan_run_segment(self._h, d_p, d_annotated, float(threshold), int(n_cds), int(edge_distance),
+                                                    int(bool(trim)), int(bool(carry_state)), d_seg, int(max_seg), d_n_seg,
+                                                    stream or None))
 
     def time_windowed(self, d_gene_ptr: int, d_attr_id: int, d_p_out: int, label=1, stream: int = 0, warmup=2, iters=10) -> float:
         ms = ctypes.c_float(0)

@@ -343,54 +343,50 @@ class ClusterCRF(object):
         if self.model is None:
             raise NotFittedError("This ClusterCRF instance is not fitted yet.")
         lab = self.model.native.label_id(label)
-        return self.model.native.windowed_marginals(contig_ptr, gene_ptr, attr_id, self.window_size, self.window_step,
-                                                    lab, pad, device=self.devices[0] if device is None else device)
+        if device is not None and [device] != list(self.devices):
+            return self.model.native.windowed_marginals(contig_ptr, gene_ptr, attr_id, self.window_size, self.window_step,
+                                                        lab, pad, device=device)
+        return self._session().windowed_marginals(contig_ptr, gene_ptr, attr_id, self.window_size, self.window_step, lab, pad)
+
+    def _session(self) -> "_native.Session":
+        """The batch driver bound to ``self.devices`` (``gecco_crf_session_*``): created on first use, kept
+        for the life of the object so that streams, plans and device buffers are reused from call to call."""
+        devices = tuple(self.devices or [0])
+        ses = getattr(self, "_ses", None)
+        if ses is None or ses[0] != devices:
+            ses = (devices, _native.Session(self.model.native, devices))
+            self._ses = ses
+        return ses[1]
 
     def _score(self, batch: "packing.PackedBatch", W: int, step: int, label: int, pad: bool,
                progress: Callable[[int, int], None], total: int) -> np.ndarray:
-        """Run the batch through the HIP engine in launches of <= _BATCH_GENES items, sharded
-        over ``self.devices`` (greedy by item count, independent launches, no collective)."""
+        """Run the batch through the HIP engine.  The native batch driver cuts it into chunks at contig
+        boundaries, deals them to ``self.devices`` longest-first by gene count (independent queues, no
+        collective) and pipelines upload / kernels / download on every device; here the batch is only
+        split into pieces of <= _BATCH_GENES items so that `progress` is called in between."""
         n_contigs = len(batch.item_ptr) - 1
         out = np.full(int(batch.item_ptr[-1]), np.nan, dtype=np.float64)
         if n_contigs == 0:
             return out
-        native = self.model.native
-        # split into contiguous contig ranges of bounded size
-        ranges: List[Tuple[int, int]] = []
+        session = self._session()
+        done = 0
         c0 = 0
         while c0 < n_contigs:
             c1 = c0 + 1
             while c1 < n_contigs and batch.item_ptr[c1 + 1] - batch.item_ptr[c0] <= self._BATCH_GENES:
                 c1 += 1
-            ranges.append((c0, c1))
-            c0 = c1
-        done = 0
-
-        def run(rng: Tuple[int, int], device: int) -> Tuple[Tuple[int, int], np.ndarray]:
-            a, b = rng
-            i0, i1 = int(batch.item_ptr[a]), int(batch.item_ptr[b])
-            cptr = (batch.item_ptr[a:b + 1] - i0).astype(np.int32)
-            gptr = (batch.attr_ptr[i0:i1 + 1] - batch.attr_ptr[i0]).astype(np.int32)
-            attr = batch.attr_id[int(batch.attr_ptr[i0]):int(batch.attr_ptr[i1])]
-            return rng, native.windowed_marginals(cptr, gptr, attr, W, step, label, pad, device=device)
-
-        devices = self.devices or [0]
-        if len(devices) == 1 or len(ranges) == 1:
-            results = (run(r, devices[0]) for r in ranges)
-        else:
-            from concurrent.futures import ThreadPoolExecutor
-
-            pool = ThreadPoolExecutor(max_workers=len(devices))
-            futs = [pool.submit(run, r, devices[i % len(devices)]) for i, r in enumerate(ranges)]
-            results = (f.result() for f in futs)
-        for (a, b), p in results:
-            i0, i1 = int(batch.item_ptr[a]), int(batch.item_ptr[b])
-            out[i0:i1] = p
-            for ci in range(a, b):
-                n_items = int(batch.item_ptr[ci + 1] - batch.item_ptr[ci])
-                if n_items >= W or pad:
-                    done += max(n_items, W) - W + 1
+            i0, i1 = int(batch.item_ptr[c0]), int(batch.item_ptr[c1])
+            a0, a1 = int(batch.attr_ptr[i0]), int(batch.attr_ptr[i1])
+            if c0 == 0 and c1 == n_contigs:
+                cptr, gptr = batch.item_ptr, batch.attr_ptr
+            else:
+                cptr, gptr = batch.item_ptr[c0:c1 + 1] - i0, batch.attr_ptr[i0:i1 + 1] - a0
+            out[i0:i1] = session.windowed_marginals(cptr, gptr, batch.attr_id[a0:a1], W, step, label, pad)
+            n_items = np.diff(batch.item_ptr[c0:c1 + 1])
+            scored = n_items >= W if not pad else np.ones(len(n_items), dtype=bool)
+            done += int((np.maximum(n_items[scored], W) - W + 1).sum())
             progress(done, total)
+            c0 = c1
         return out
 
     # ------------------------------------------------------------------ training (delegated)

@@ -1,10 +1,14 @@
 // extern "C" surface declared in include/gecco_crf.h.
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <new>
+#include <string>
 
 #include "../../include/gecco_crf.h"
 #include "crf_model.hpp"
 #include "crf_plan.hpp"
+#include "crf_session.hpp"
 
 using namespace gecco;
 
@@ -14,6 +18,27 @@ struct gecco_crf_model {
 struct gecco_crf_plan {
     Plan p;
 };
+struct gecco_crf_session {
+    Session *s = nullptr;
+    ~gecco_crf_session() { session_destroy(s); }
+};
+
+// No C++ exception may cross the C boundary (ctypes would std::terminate the interpreter).
+#define GECCO_GUARD_BEGIN try {
+#define GECCO_GUARD_END                                                     \
+    }                                                                       \
+    catch (const std::bad_alloc &) {                                        \
+        set_error("out of host memory");                                    \
+        return GECCO_CRF_ENOMEM;                                            \
+    }                                                                       \
+    catch (const std::exception &e) {                                       \
+        set_error(std::string("internal error: ") + e.what());              \
+        return GECCO_CRF_EHIP;                                              \
+    }                                                                       \
+    catch (...) {                                                           \
+        set_error("internal error");                                        \
+        return GECCO_CRF_EHIP;                                              \
+    }
 
 #define GECCO_API extern "C" __attribute__((visibility("default")))
 
@@ -55,35 +80,31 @@ int check_device(int32_t device) {
 }  // namespace
 
 GECCO_API const char *gecco_crf_last_error(void) { return last_error(); }
-GECCO_API int gecco_crf_version(void) { return 100; }
+GECCO_API int gecco_crf_version(void) { return 200; }
 
 GECCO_API int gecco_crf_model_load(const uint8_t *lcrf, size_t n_bytes, gecco_crf_model **out) {
     if (!out) return GECCO_CRF_EINVAL;
     *out = nullptr;
-    auto *h = new (std::nothrow) gecco_crf_model();
-    if (!h) return GECCO_CRF_ENOMEM;
+    GECCO_GUARD_BEGIN
+    std::unique_ptr<gecco_crf_model> h(new gecco_crf_model());
     int rc = parse_lcrf(lcrf, n_bytes, h->m);
-    if (rc) {
-        delete h;
-        return rc;
-    }
-    *out = h;
+    if (rc) return rc;
+    *out = h.release();
     return GECCO_CRF_OK;
+    GECCO_GUARD_END
 }
 
 GECCO_API int gecco_crf_model_from_tables(const double *state, const double *trans, int32_t num_attrs,
                                           int32_t num_labels, gecco_crf_model **out) {
     if (!out) return GECCO_CRF_EINVAL;
     *out = nullptr;
-    auto *h = new (std::nothrow) gecco_crf_model();
-    if (!h) return GECCO_CRF_ENOMEM;
+    GECCO_GUARD_BEGIN
+    std::unique_ptr<gecco_crf_model> h(new gecco_crf_model());
     int rc = model_from_tables(state, trans, num_attrs, num_labels, h->m);
-    if (rc) {
-        delete h;
-        return rc;
-    }
-    *out = h;
+    if (rc) return rc;
+    *out = h.release();
     return GECCO_CRF_OK;
+    GECCO_GUARD_END
 }
 
 GECCO_API void gecco_crf_model_free(gecco_crf_model *m) { delete m; }
@@ -108,6 +129,7 @@ GECCO_API int32_t gecco_crf_model_attr_id(const gecco_crf_model *m, const char *
 }
 GECCO_API int gecco_crf_model_map_attrs(const gecco_crf_model *m, const char *const *names, int32_t n, int32_t *ids) {
     if (!m || (n > 0 && (!names || !ids))) return GECCO_CRF_EINVAL;
+    GECCO_GUARD_BEGIN
     std::string key;
     for (int32_t i = 0; i < n; ++i) {
         if (!names[i]) {
@@ -119,6 +141,7 @@ GECCO_API int gecco_crf_model_map_attrs(const gecco_crf_model *m, const char *co
         ids[i] = it == m->m.attr_index.end() ? -1 : it->second;
     }
     return GECCO_CRF_OK;
+    GECCO_GUARD_END
 }
 GECCO_API int gecco_crf_model_state_weights(const gecco_crf_model *m, double *w, uint8_t *present) {
     if (!m) return GECCO_CRF_EINVAL;
@@ -151,16 +174,18 @@ GECCO_API int gecco_crf_plan_create(const gecco_crf_model *m, int32_t device, co
         int rc = check_device(device);
         if (rc) return rc;
     }
-    DeviceGuard guard;
-    auto *h = new (std::nothrow) gecco_crf_plan();
-    if (!h) return GECCO_CRF_ENOMEM;
-    int rc = plan_build(m->m, device, contig_ptr, n_contigs, window, step, pad, h->p);
-    if (rc) {
-        delete h;
-        return rc;
+    if (n_contigs > 0 && contig_ptr && contig_ptr[0] != 0) {
+        set_error("contig_ptr[0] must be 0");
+        return GECCO_CRF_EINVAL;
     }
-    *out = h;
+    DeviceGuard guard;
+    GECCO_GUARD_BEGIN
+    std::unique_ptr<gecco_crf_plan> h(new gecco_crf_plan());
+    int rc = plan_build(m->m, device, contig_ptr, n_contigs, window, step, pad, h->p);
+    if (rc) return rc;
+    *out = h.release();
     return GECCO_CRF_OK;
+    GECCO_GUARD_END
 }
 GECCO_API void gecco_crf_plan_free(gecco_crf_plan *p) {
     DeviceGuard guard;
@@ -175,7 +200,9 @@ GECCO_API int gecco_crf_plan_run_windowed(gecco_crf_plan *p, const int32_t *d_ge
                                           int32_t label, double *d_p_out, void *stream) {
     if (!p) return GECCO_CRF_EINVAL;
     DeviceGuard guard;
+    GECCO_GUARD_BEGIN
     return plan_run_windowed(p->p, d_gene_ptr, d_attr_id, label, d_p_out, static_cast<hipStream_t>(stream));
+    GECCO_GUARD_END
 }
 
 GECCO_API int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
@@ -183,6 +210,7 @@ GECCO_API int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_g
                                            int32_t iters, float *ms_per_launch) {
     if (!p || !ms_per_launch || iters <= 0) return GECCO_CRF_EINVAL;
     DeviceGuard guard;
+    GECCO_GUARD_BEGIN
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
     for (int i = 0; i < warmup; ++i)
@@ -200,28 +228,172 @@ GECCO_API int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_g
     (void)hipEventDestroy(e1);
     *ms_per_launch = ms / float(iters);
     return rc;
+    GECCO_GUARD_END
 }
 
 GECCO_API int gecco_crf_plan_run_decode(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                                         int32_t label, double *d_p_out, int8_t *d_y, double *d_score, void *stream) {
     if (!p) return GECCO_CRF_EINVAL;
     DeviceGuard guard;
+    GECCO_GUARD_BEGIN
     return plan_run_decode(p->p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, static_cast<hipStream_t>(stream));
+    GECCO_GUARD_END
 }
 GECCO_API int gecco_crf_plan_run_marginals_full(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                                                 double *d_marg, double *d_lognorm, void *stream) {
     if (!p) return GECCO_CRF_EINVAL;
     DeviceGuard guard;
+    GECCO_GUARD_BEGIN
     return plan_run_marginals_full(p->p, d_gene_ptr, d_attr_id, d_marg, d_lognorm, static_cast<hipStream_t>(stream));
+    GECCO_GUARD_END
 }
 GECCO_API int gecco_crf_plan_run_viterbi(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                                          int8_t *d_y, double *d_score, void *stream) {
     if (!p) return GECCO_CRF_EINVAL;
     DeviceGuard guard;
+    GECCO_GUARD_BEGIN
     return plan_run_viterbi(p->p, d_gene_ptr, d_attr_id, d_y, d_score, static_cast<hipStream_t>(stream));
+    GECCO_GUARD_END
 }
 
-// ---- one-shot host entry points ------------------------------------------------------------
+// ---- pinned host memory -----------------------------------------------------------------------
+GECCO_API int gecco_crf_host_alloc(size_t n_bytes, void **out) {
+    if (!out) return GECCO_CRF_EINVAL;
+    *out = nullptr;
+    int32_t n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device available (pinned memory needs the HIP runtime)");
+        return GECCO_CRF_ENODEV;
+    }
+    return check_hip(hipHostMalloc(out, n_bytes ? n_bytes : 1, hipHostMallocPortable), "hipHostMalloc");
+}
+GECCO_API void gecco_crf_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+// ---- batch driver -------------------------------------------------------------------------------
+GECCO_API int gecco_crf_session_create(const gecco_crf_model *m, const int32_t *devices, int32_t n_devices,
+                                       gecco_crf_session **out) {
+    if (!m || !out) return GECCO_CRF_EINVAL;
+    *out = nullptr;
+    DeviceGuard guard;
+    GECCO_GUARD_BEGIN
+    std::unique_ptr<gecco_crf_session> h(new gecco_crf_session());
+    int rc = session_create(m->m, devices, n_devices, &h->s);
+    if (rc) return rc;
+    *out = h.release();
+    return GECCO_CRF_OK;
+    GECCO_GUARD_END
+}
+GECCO_API void gecco_crf_session_free(gecco_crf_session *s) {
+    DeviceGuard guard;
+    delete s;
+}
+GECCO_API int gecco_crf_session_set_chunk_genes(gecco_crf_session *s, int32_t genes) {
+    if (!s || genes <= 0) return GECCO_CRF_EINVAL;
+    session_set_chunk_genes(*s->s, genes);
+    return GECCO_CRF_OK;
+}
+GECCO_API int gecco_crf_session_stats(const gecco_crf_session *s, int32_t *n_chunks, int64_t *h2d_bytes, int64_t *d2h_bytes,
+                                      double *host_plan_seconds, double *wall_seconds) {
+    if (!s) return GECCO_CRF_EINVAL;
+    const SessionStats st = session_stats(*s->s);
+    if (n_chunks) *n_chunks = st.n_chunks;
+    if (h2d_bytes) *h2d_bytes = st.h2d_bytes;
+    if (d2h_bytes) *d2h_bytes = st.d2h_bytes;
+    if (host_plan_seconds) *host_plan_seconds = st.host_plan_seconds;
+    if (wall_seconds) *wall_seconds = st.wall_seconds;
+    return GECCO_CRF_OK;
+}
+
+namespace {
+int run_guarded(Session &s, const BatchRequest &r) {
+    GECCO_GUARD_BEGIN
+    return session_run(s, r);
+    GECCO_GUARD_END
+}
+BatchRequest csr_request(const int32_t *contig_ptr, int32_t n_contigs, const int32_t *gene_ptr, const int32_t *attr_id) {
+    BatchRequest r;
+    r.contig_ptr = contig_ptr;
+    r.n_contigs = n_contigs;
+    r.gene_ptr = gene_ptr;
+    r.attr_id = attr_id;
+    return r;
+}
+}  // namespace
+
+GECCO_API int gecco_crf_session_windowed(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                         const int32_t *gene_ptr, const int32_t *attr_id, int32_t window, int32_t step,
+                                         int32_t label, int32_t pad, double *p_out) {
+    if (!s || !p_out) return GECCO_CRF_EINVAL;
+    BatchRequest r = csr_request(contig_ptr, n_contigs, gene_ptr, attr_id);
+    r.window = window;
+    r.step = step;
+    r.label = label;
+    r.pad = pad;
+    r.p_out = p_out;
+    return run_guarded(*s->s, r);
+}
+GECCO_API int gecco_crf_session_decode(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                       const int32_t *gene_ptr, const int32_t *attr_id, int32_t window, int32_t step,
+                                       int32_t label, int32_t pad, double *p_out, int8_t *y_out) {
+    if (!s || !p_out || !y_out) return GECCO_CRF_EINVAL;
+    BatchRequest r = csr_request(contig_ptr, n_contigs, gene_ptr, attr_id);
+    r.window = window;
+    r.step = step;
+    r.label = label;
+    r.pad = pad;
+    r.p_out = p_out;
+    r.y_out = y_out;
+    return run_guarded(*s->s, r);
+}
+GECCO_API int gecco_crf_session_clusters(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                         const int32_t *gene_ptr, const int32_t *attr_id, const uint8_t *annotated,
+                                         int32_t window, int32_t step, int32_t label, int32_t pad, double threshold,
+                                         int32_t n_cds, int32_t edge_distance, int32_t trim, double *p_out, int32_t *seg_out,
+                                         int32_t max_seg, int32_t *n_seg, double *seg_p_out, int64_t max_seg_genes,
+                                         int64_t *seg_off_out) {
+    if (!s) return GECCO_CRF_EINVAL;
+    BatchRequest r = csr_request(contig_ptr, n_contigs, gene_ptr, attr_id);
+    r.window = window;
+    r.step = step;
+    r.label = label;
+    r.pad = pad;
+    r.p_out = p_out;
+    r.want_segments = true;
+    r.annotated = annotated;
+    r.threshold = threshold;
+    r.n_cds = n_cds;
+    r.edge_distance = edge_distance;
+    r.trim = trim;
+    r.seg_out = seg_out;
+    r.max_seg = max_seg;
+    r.n_seg = n_seg;
+    r.seg_p_out = seg_p_out;
+    r.max_seg_genes = max_seg_genes;
+    r.seg_off_out = seg_off_out;
+    return run_guarded(*s->s, r);
+}
+
+// ---- one-shot host entry points: thin wrappers over the model's own per-device session ------------
+namespace {
+int default_session(const gecco_crf_model *m, int32_t device, Session **out) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(m->m.dev_mutex);
+    for (auto &e : m->m.sessions)
+        if (e.first == device) {
+            *out = e.second;
+            return GECCO_CRF_OK;
+        }
+    Session *s = nullptr;
+    if ((rc = session_create(m->m, &device, 1, &s))) return rc;
+    m->m.sessions.emplace_back(device, s);
+    *out = s;
+    return GECCO_CRF_OK;
+}
+}  // namespace
+
 GECCO_API int gecco_crf_windowed_marginals(const gecco_crf_model *m, int32_t device, const int32_t *contig_ptr,
                                            int32_t n_contigs, const int32_t *gene_ptr, const int32_t *attr_id,
                                            int32_t window, int32_t step, int32_t label, int32_t pad, double *p_out) {
@@ -239,111 +411,94 @@ GECCO_API int gecco_crf_windowed_marginals(const gecco_crf_model *m, int32_t dev
         set_error("label out of range");
         return GECCO_CRF_EINVAL;
     }
-    int rc = check_device(device);
-    if (rc) return rc;
     DeviceGuard guard;
-    gecco_crf_plan h;
-    if ((rc = plan_build(m->m, device, contig_ptr, n_contigs, window, step, pad, h.p))) return rc;
-    const int32_t n = h.p.n_genes;
-    if (n == 0) return GECCO_CRF_OK;
-    if (!gene_ptr || !p_out) {
+    GECCO_GUARD_BEGIN
+    Session *s = nullptr;
+    int rc = default_session(m, device, &s);
+    if (rc) return rc;
+    if (n_contigs > 0 && contig_ptr && contig_ptr[n_contigs] > 0 && !p_out) {
         set_error("null buffer");
         return GECCO_CRF_EINVAL;
     }
-    const size_t nnz = size_t(gene_ptr[n]);
-    for (size_t k = 0; k < nnz; ++k)
-        if (attr_id[k] < 0 || attr_id[k] >= m->m.A) {
-            set_error("attr_id out of range (unknown attributes must be dropped by the packer)");
-            return GECCO_CRF_EINVAL;
-        }
-    DevBuf<int32_t> d_gp, d_at;
-    DevBuf<double> d_p;
-    if ((rc = d_gp.alloc(size_t(n) + 1, "hipMalloc gene_ptr"))) return rc;
-    if ((rc = d_at.alloc(nnz, "hipMalloc attr_id"))) return rc;
-    if ((rc = d_p.alloc(size_t(n), "hipMalloc p_out"))) return rc;
-    if ((rc = check_hip(hipMemcpy(d_gp.p, gene_ptr, (size_t(n) + 1) * 4, hipMemcpyHostToDevice), "H2D gene_ptr"))) return rc;
-    if (nnz && (rc = check_hip(hipMemcpy(d_at.p, attr_id, nnz * 4, hipMemcpyHostToDevice), "H2D attr_id"))) return rc;
-    if ((rc = check_hip(hipMemset(d_p.p, 0, size_t(n) * 8), "memset"))) return rc;
-    if ((rc = plan_run_windowed(h.p, d_gp.p, d_at.p, label, d_p.p, nullptr))) return rc;
-    if ((rc = check_hip(hipMemcpy(p_out, d_p.p, size_t(n) * 8, hipMemcpyDeviceToHost), "D2H p_out"))) return rc;
-    return GECCO_CRF_OK;
+    BatchRequest r = csr_request(contig_ptr, n_contigs, gene_ptr, attr_id);
+    r.window = window;
+    r.step = step;
+    r.label = label;
+    r.pad = pad;
+    r.p_out = p_out;
+    return session_run(*s, r);
+    GECCO_GUARD_END
 }
-
-namespace {
-// shared front half of the one-shot whole-contig entry points: plan + CSR upload
-struct OneShot {
-    gecco_crf_plan h;
-    DevBuf<int32_t> d_gp, d_at;
-    int32_t n = 0;
-    int prepare(const gecco_crf_model *m, int32_t device, const int32_t *contig_ptr, int32_t n_contigs,
-                const int32_t *gene_ptr, const int32_t *attr_id) {
-        if (!m) return GECCO_CRF_EINVAL;
-        int rc = check_device(device);
-        if (rc) return rc;
-        if ((rc = plan_build(m->m, device, contig_ptr, n_contigs, 1, 1, 1, h.p))) return rc;
-        n = h.p.n_genes;
-        if (n == 0) return GECCO_CRF_OK;
-        if (!gene_ptr) {
-            set_error("null buffer");
-            return GECCO_CRF_EINVAL;
-        }
-        const size_t nnz = size_t(gene_ptr[n]);
-        for (size_t k = 0; k < nnz; ++k)
-            if (attr_id[k] < 0 || attr_id[k] >= m->m.A) {
-                set_error("attr_id out of range (unknown attributes must be dropped by the packer)");
-                return GECCO_CRF_EINVAL;
-            }
-        if ((rc = d_gp.alloc(size_t(n) + 1, "hipMalloc gene_ptr"))) return rc;
-        if ((rc = d_at.alloc(nnz, "hipMalloc attr_id"))) return rc;
-        if ((rc = check_hip(hipMemcpy(d_gp.p, gene_ptr, (size_t(n) + 1) * 4, hipMemcpyHostToDevice), "H2D gene_ptr"))) return rc;
-        if (nnz && (rc = check_hip(hipMemcpy(d_at.p, attr_id, nnz * 4, hipMemcpyHostToDevice), "H2D attr_id"))) return rc;
-        return GECCO_CRF_OK;
-    }
-};
-}  // namespace
 
 GECCO_API int gecco_crf_marginals_full(const gecco_crf_model *m, int32_t device, const int32_t *contig_ptr,
                                        int32_t n_contigs, const int32_t *gene_ptr, const int32_t *attr_id,
                                        double *marg, double *lognorm) {
+    if (!m) return GECCO_CRF_EINVAL;
     DeviceGuard guard;
-    OneShot os;
-    int rc = os.prepare(m, device, contig_ptr, n_contigs, gene_ptr, attr_id);
+    GECCO_GUARD_BEGIN
+    Session *s = nullptr;
+    int rc = default_session(m, device, &s);
     if (rc) return rc;
-    if (n_contigs == 0) return GECCO_CRF_OK;
-    const size_t n = size_t(os.n), L = size_t(m->m.L);
-    DevBuf<double> d_m, d_ln;
-    if ((rc = d_m.alloc(n * L, "hipMalloc marginals"))) return rc;
-    if ((rc = d_ln.alloc(size_t(n_contigs), "hipMalloc lognorm"))) return rc;
-    if ((rc = plan_run_marginals_full(os.h.p, os.d_gp.p, os.d_at.p, d_m.p, d_ln.p, nullptr))) return rc;
-    if (n && marg && (rc = check_hip(hipMemcpy(marg, d_m.p, n * L * 8, hipMemcpyDeviceToHost), "D2H marginals"))) return rc;
-    if (lognorm && (rc = check_hip(hipMemcpy(lognorm, d_ln.p, size_t(n_contigs) * 8, hipMemcpyDeviceToHost), "D2H lognorm")))
-        return rc;
-    return check_hip(hipDeviceSynchronize(), "sync");
+    if (!marg && !lognorm) return GECCO_CRF_OK;
+    BatchRequest r = csr_request(contig_ptr, n_contigs, gene_ptr, attr_id);
+    r.marg_out = marg;
+    r.lognorm_out = lognorm;
+    return session_run(*s, r);
+    GECCO_GUARD_END
 }
 
 GECCO_API int gecco_crf_viterbi(const gecco_crf_model *m, int32_t device, const int32_t *contig_ptr, int32_t n_contigs,
                                 const int32_t *gene_ptr, const int32_t *attr_id, int8_t *y_out, double *score) {
+    if (!m) return GECCO_CRF_EINVAL;
     DeviceGuard guard;
-    OneShot os;
-    int rc = os.prepare(m, device, contig_ptr, n_contigs, gene_ptr, attr_id);
+    GECCO_GUARD_BEGIN
+    Session *s = nullptr;
+    int rc = default_session(m, device, &s);
     if (rc) return rc;
-    if (n_contigs == 0) return GECCO_CRF_OK;
-    const size_t n = size_t(os.n);
-    DevBuf<int8_t> d_y;
-    DevBuf<double> d_sc;
-    if ((rc = d_y.alloc(n, "hipMalloc labels"))) return rc;
-    if (score && (rc = d_sc.alloc(size_t(n_contigs), "hipMalloc scores"))) return rc;
-    if ((rc = plan_run_viterbi(os.h.p, os.d_gp.p, os.d_at.p, d_y.p, score ? d_sc.p : nullptr, nullptr))) return rc;
-    if (n && y_out && (rc = check_hip(hipMemcpy(y_out, d_y.p, n, hipMemcpyDeviceToHost), "D2H labels"))) return rc;
-    if (score && (rc = check_hip(hipMemcpy(score, d_sc.p, size_t(n_contigs) * 8, hipMemcpyDeviceToHost), "D2H scores")))
-        return rc;
-    return check_hip(hipDeviceSynchronize(), "sync");
+    if (!y_out) {
+        if (n_contigs > 0 && contig_ptr && contig_ptr[n_contigs] > 0) {
+            set_error("null buffer");
+            return GECCO_CRF_EINVAL;
+        }
+        return GECCO_CRF_OK;
+    }
+    BatchRequest r = csr_request(contig_ptr, n_contigs, gene_ptr, attr_id);
+    r.y_out = y_out;
+    r.score_out = score;
+    return session_run(*s, r);
+    GECCO_GUARD_END
 }
+
+namespace {
+// grow-only scratch of the stand-alone segmenter / composition calls, one set per host thread
+struct Scratch {
+    int device = -1;
+    char *d = nullptr;
+    size_t cap = 0;
+    ~Scratch() {
+        if (d && hipSetDevice(device) == hipSuccess) (void)hipFree(d);
+    }
+    int reserve(int dev, size_t bytes) {
+        if (d && dev == device && bytes <= cap) return GECCO_CRF_OK;
+        if (d && hipSetDevice(device) == hipSuccess) (void)hipFree(d);
+        d = nullptr;
+        cap = 0;
+        int rc = check_hip(hipSetDevice(dev), "hipSetDevice");
+        if (rc) return rc;
+        const size_t want = bytes + bytes / 8 + 256;
+        if ((rc = check_hip(hipMalloc(reinterpret_cast<void **>(&d), want), "hipMalloc scratch"))) return rc;
+        device = dev;
+        cap = want;
+        return GECCO_CRF_OK;
+    }
+};
+inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
+}  // namespace
+
 GECCO_API int gecco_crf_segment(int32_t device, const double *p, const uint8_t *annotated, const int32_t *contig_ptr,
                                 int32_t n_contigs, double threshold, int32_t n_cds, int32_t edge_distance,
-                                int32_t trim, int32_t *seg_out, int32_t max_seg, int32_t *n_seg) {
-    if (!n_seg || n_contigs < 0 || (n_contigs > 0 && (!contig_ptr || !p || !annotated)) || max_seg < 0 ||
-        (max_seg > 0 && !seg_out)) {
+                                int32_t trim, int32_t carry_state, int32_t *seg_out, int32_t max_seg, int32_t *n_seg) {
+    if (!n_seg || n_contigs < 0 || (n_contigs > 0 && !contig_ptr) || max_seg < 0 || (max_seg > 0 && !seg_out)) {
         set_error("gecco_crf_segment: bad arguments");
         return GECCO_CRF_EINVAL;
     }
@@ -351,34 +506,56 @@ GECCO_API int gecco_crf_segment(int32_t device, const double *p, const uint8_t *
     int rc = check_device(device);
     if (rc) return rc;
     if (n_contigs == 0) return GECCO_CRF_OK;
-    DeviceGuard guard;
-    if ((rc = check_hip(hipSetDevice(device), "hipSetDevice"))) return rc;
+    for (int32_t c = 0; c < n_contigs; ++c)
+        if (contig_ptr[c + 1] < contig_ptr[c] || contig_ptr[0] != 0) {
+            set_error("contig_ptr must start at 0 and be non-decreasing");
+            return GECCO_CRF_EINVAL;
+        }
     const size_t n = size_t(contig_ptr[n_contigs]), nc = size_t(n_contigs);
-    DevBuf<double> d_p;
-    DevBuf<uint8_t> d_a;
-    DevBuf<int32_t> d_c, d_seg, d_work, d_total;
-    if ((rc = d_p.alloc(n, "hipMalloc p"))) return rc;
-    if ((rc = d_a.alloc(n, "hipMalloc annotated"))) return rc;
-    if ((rc = d_c.alloc(nc + 1, "hipMalloc contig_ptr"))) return rc;
-    if ((rc = d_seg.alloc(size_t(max_seg) * 4, "hipMalloc segments"))) return rc;
-    if ((rc = d_work.alloc(nc * 3 + 4, "hipMalloc work"))) return rc;
-    if ((rc = d_total.alloc(1, "hipMalloc total"))) return rc;
-    if (n && (rc = check_hip(hipMemcpy(d_p.p, p, n * 8, hipMemcpyHostToDevice), "H2D p"))) return rc;
-    if (n && (rc = check_hip(hipMemcpy(d_a.p, annotated, n, hipMemcpyHostToDevice), "H2D annotated"))) return rc;
-    if ((rc = check_hip(hipMemcpy(d_c.p, contig_ptr, (nc + 1) * 4, hipMemcpyHostToDevice), "H2D contig_ptr"))) return rc;
-    if ((rc = check_hip(launch_segment(d_p.p, d_a.p, d_c.p, n_contigs, threshold, n_cds, edge_distance, trim, d_seg.p, max_seg,
-                                       d_work.p, d_total.p, nullptr), "segment launch")))
+    if (n == 0) return GECCO_CRF_OK;
+    if (!p || !annotated) {
+        set_error("gecco_crf_segment: bad arguments");
+        return GECCO_CRF_EINVAL;
+    }
+    DeviceGuard guard;
+    GECCO_GUARD_BEGIN
+    static thread_local Scratch scratch;
+    const size_t o_p = 0, o_a = o_p + al256(n * 8), o_c = o_a + al256(n + 8), o_seg = o_c + al256((nc + 1) * 4),
+                 o_tot = o_seg + al256(size_t(max_seg) * 16 + 16), o_ws = o_tot + 256,
+                 bytes = o_ws + segment_workspace_bytes(int(n), n_contigs);
+    if ((rc = scratch.reserve(device, bytes))) return rc;
+    char *d = scratch.d;
+    if ((rc = check_hip(hipMemcpy(d + o_p, p, n * 8, hipMemcpyHostToDevice), "H2D p"))) return rc;
+    if ((rc = check_hip(hipMemcpy(d + o_a, annotated, n, hipMemcpyHostToDevice), "H2D annotated"))) return rc;
+    if ((rc = check_hip(hipMemcpy(d + o_c, contig_ptr, (nc + 1) * 4, hipMemcpyHostToDevice), "H2D contig_ptr"))) return rc;
+    int32_t *d_seg = reinterpret_cast<int32_t *>(d + o_seg), *d_total = reinterpret_cast<int32_t *>(d + o_tot);
+    if ((rc = check_hip(launch_segment(reinterpret_cast<const double *>(d + o_p), reinterpret_cast<const uint8_t *>(d + o_a), nullptr,
+                                       reinterpret_cast<const int32_t *>(d + o_c), int(n), n_contigs, threshold, n_cds, edge_distance,
+                                       trim ? 1 : 0, carry_state ? 1 : 0, d_seg, max_seg, nullptr, d_total, d + o_ws, nullptr),
+                        "segment launch")))
         return rc;
     int32_t total = 0;
-    if ((rc = check_hip(hipMemcpy(&total, d_total.p, 4, hipMemcpyDeviceToHost), "D2H count"))) return rc;
+    if ((rc = check_hip(hipMemcpy(&total, d_total, 4, hipMemcpyDeviceToHost), "D2H count"))) return rc;
     *n_seg = total;
     if (total > max_seg) {
         set_error("gecco_crf_segment: seg_out too small");
         return GECCO_CRF_EINVAL;
     }
-    if (total && (rc = check_hip(hipMemcpy(seg_out, d_seg.p, size_t(total) * 16, hipMemcpyDeviceToHost), "D2H segments")))
+    if (total && (rc = check_hip(hipMemcpy(seg_out, d_seg, size_t(total) * 16, hipMemcpyDeviceToHost), "D2H segments")))
         return rc;
     return GECCO_CRF_OK;
+    GECCO_GUARD_END
+}
+
+GECCO_API int gecco_crf_plan_run_segment(gecco_crf_plan *p, const double *d_p, const uint8_t *d_annotated, double threshold,
+                                         int32_t n_cds, int32_t edge_distance, int32_t trim, int32_t carry_state,
+                                         int32_t *d_seg, int32_t max_seg, int32_t *d_n_seg, void *stream) {
+    if (!p) return GECCO_CRF_EINVAL;
+    DeviceGuard guard;
+    GECCO_GUARD_BEGIN
+    return plan_run_segment(p->p, d_p, d_annotated, threshold, n_cds, edge_distance, trim ? 1 : 0, carry_state ? 1 : 0, d_seg, max_seg,
+                            nullptr, d_n_seg, static_cast<hipStream_t>(stream));
+    GECCO_GUARD_END
 }
 
 GECCO_API int gecco_crf_domain_composition(int32_t device, const int32_t *seg, int32_t n_seg, const int32_t *dom_ptr,
@@ -404,6 +581,7 @@ GECCO_API int gecco_crf_domain_composition(int32_t device, const int32_t *seg, i
         }
     }
     DeviceGuard guard;
+    GECCO_GUARD_BEGIN
     if ((rc = check_hip(hipSetDevice(device), "hipSetDevice"))) return rc;
     DevBuf<int32_t> d_seg, d_ptr, d_col;
     DevBuf<double> d_w, d_tmp, d_out;
@@ -422,4 +600,5 @@ GECCO_API int gecco_crf_domain_composition(int32_t device, const int32_t *seg, i
                                            d_out.p, nullptr), "composition launch")))
         return rc;
     return check_hip(hipMemcpy(comp_out, d_out.p, out_n * 8, hipMemcpyDeviceToHost), "D2H compositions");
+    GECCO_GUARD_END
 }

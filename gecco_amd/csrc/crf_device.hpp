@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 
 namespace gecco {
@@ -122,19 +123,49 @@ struct SeqArgs {
     double *score;    // [n_contigs] or null
 };
 
-hipError_t launch_seq_state(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_genes,
+hipError_t launch_seq_state(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_attrs, int n_genes,
                             double2 *state, hipStream_t stream);
 hipError_t launch_seq_marginals(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream);
 hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream);
 // labels only, from a.dstate; needs trans[0][1] - trans[1][1] <= trans[0][0] - trans[1][0]
 hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream);
-hipError_t launch_seq_state_delta(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_genes,
+hipError_t launch_seq_state_delta(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_attrs, int n_genes,
                                   double *dstate, hipStream_t stream);
 
-// row R on packed arrays (crf_segment.hip); d_work: 2*n_contigs int32 + n_contigs bytes
-hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const int32_t *d_cptr, int n_contigs, double threshold,
-                          int n_cds, int edge_distance, int trim, int32_t *d_seg, int max_seg, int32_t *d_work,
-                          int32_t *d_total, hipStream_t stream);
+// ---- row R on packed arrays (crf_segment.hip) ----------------------------------------------
+struct SegE {  // what a span of genes does to the grouper, as a function of the state it is entered in
+    uint32_t map;       // bit s = state left behind when entered in state s
+    uint32_t ng0, ng1;  // cluster runs started inside the span when entered in state 0 / 1
+    uint32_t ann;       // annotated genes in the span
+};
+struct SegArgs {
+    const double *p;        // [n_genes] probabilities (NaN: none)
+    const uint8_t *ann;     // [n_genes] the gene has at least one domain
+    const uint8_t *flags;   // [n_genes] bit0: first gene of a contig, bit1: last gene
+    const int32_t *cptr;    // [n_contigs+1]
+    int32_t n_genes, n_contigs;
+    double thr;
+    int32_t n_cds, edge, trim, carry;
+    // workspace
+    SegE *lane, *block;     // exclusive prefix per lane inside its workgroup; per workgroup
+    int32_t *pre;           // [n_genes+1] annotated genes before gene g
+    int2 *raw;              // (first gene, one past the last gene) of every run, in order
+    int4 *val;              // (contig or -1-contig if rejected, number, first, last+1) per raw run
+    int2 *tile;             // per 256 raw runs: kept rows, their genes -> exclusive prefixes
+    int32_t *n_raw;
+    // outputs
+    int32_t *seg;           // [max_seg][4]
+    int32_t max_seg;
+    int32_t *seg_off;       // [max_seg+1] or null: gene offsets of the kept rows
+    int32_t *total;
+};
+size_t segment_workspace_bytes(int n_genes, int n_contigs);
+hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t *d_flags, const int32_t *d_cptr,
+                          int n_genes, int n_contigs, double threshold, int n_cds, int edge_distance, int trim, int carry,
+                          int32_t *d_seg, int max_seg, int32_t *d_seg_off, int32_t *d_total, void *d_work,
+                          hipStream_t stream);
+hipError_t launch_segment_gather(const double *d_p, const int32_t *d_seg, const int32_t *d_seg_off, const int32_t *d_total,
+                                 int max_seg, double *d_out, int cap, hipStream_t stream);
 
 // ---- any number of labels (crf_general.hip) -------------------------------------------------
 constexpr int kGenMaxL = 32;  // labels: a group of next-pow2(L) lanes must fit in half a wave
@@ -145,7 +176,7 @@ struct GenArgs {
     const double *exp_trans;  // [L*L] exp(trans)
     const double *trans;      // [L*L] raw transition weights (Viterbi)
     const int32_t *contig_ptr;
-    int32_t L, n_genes, n_contigs;
+    int32_t L, A, n_genes, n_contigs;
     // per-gene workspace
     double *state;  // [n*L] raw state scores            (Viterbi)
     double *E;      // [n*L] exp(state - max_y state)    (marginals)

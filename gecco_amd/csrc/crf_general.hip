@@ -41,7 +41,7 @@ __device__ __forceinline__ double group_max(double v) {
 // state[g][y] = sum_a w[a][y]; E[g][y] = exp(state - max_y); smax[g] = max_y state.
 template <int LP>
 __global__ void __launch_bounds__(kGT) gl_state(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
-                                                const double *__restrict__ wtab, int L, int n_genes,
+                                                const double *__restrict__ wtab, int L, int A, int n_genes,
                                                 double *__restrict__ state, double *__restrict__ E,
                                                 double *__restrict__ smax) {
     const int j = threadIdx.x & (LP - 1);
@@ -50,7 +50,10 @@ __global__ void __launch_bounds__(kGT) gl_state(const int32_t *__restrict__ gene
     const int lo = gene_ptr[g], hi = gene_ptr[g + 1];
     const int jj = j < L ? j : 0;
     double acc = 0.0;
-    for (int a = lo; a < hi; ++a) acc += wtab[static_cast<size_t>(attr_id[a]) * L + jj];
+    for (int a = lo; a < hi; ++a) {
+        const int id = attr_id[a];  // ids outside the model's dictionary are unknown attributes: no weight
+        if (unsigned(id) < unsigned(A)) acc += wtab[static_cast<size_t>(id) * L + jj];
+    }
     const double m = group_max<LP>(j < L ? acc : -DBL_MAX);
     if (j < L) {
         if (state) state[static_cast<size_t>(g) * L + j] = acc;
@@ -306,7 +309,7 @@ hipError_t launch_lp(int what, const GenArgs &a, hipStream_t stream) {
     case 0:  // state scores
         if (a.n_genes > 0)
             hipLaunchKernelGGL(gl_state<LP>, blocks(a.n_genes, G), dim3(kGT), 0, stream, a.gene_ptr, a.attr_id, a.wtab, a.L,
-                               a.n_genes, a.state, a.E, a.smax);
+                               a.A, a.n_genes, a.state, a.E, a.smax);
         break;
     case 1: {
         const size_t lds = (size_t(G) * a.W * (LP + 1) + kGT) * sizeof(double);

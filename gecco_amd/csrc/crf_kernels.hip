@@ -120,7 +120,7 @@ __device__ __forceinline__ SlotInfo slot_lookup(const Smem &sm, int cnt, int q, 
 // first weight gather and all gathers before the first add, so a gene costs two memory round
 // trips instead of two per attribute; padding lanes add +0.0, which leaves the sum bit-exact.
 __device__ __forceinline__ void state_scores_l2(const int32_t *__restrict__ attr_id,
-                                                const double2 *__restrict__ wtab2, int lo, int hi,
+                                                const double2 *__restrict__ wtab2, int n_attrs, int lo, int hi,
                                                 double &s0, double &s1) {
     for (int base = lo; base < hi; base += kGatherUnroll) {
         int a[kGatherUnroll];
@@ -128,7 +128,7 @@ __device__ __forceinline__ void state_scores_l2(const int32_t *__restrict__ attr
         for (int u = 0; u < kGatherUnroll; ++u) a[u] = base + u < hi ? attr_id[base + u] : -1;
         double2 w[kGatherUnroll];
 #pragma unroll
-        for (int u = 0; u < kGatherUnroll; ++u) w[u] = a[u] >= 0 ? wtab2[a[u]] : make_double2(0.0, 0.0);
+        for (int u = 0; u < kGatherUnroll; ++u) w[u] = unsigned(a[u]) < unsigned(n_attrs) ? wtab2[a[u]] : make_double2(0.0, 0.0);
 #pragma unroll
         for (int u = 0; u < kGatherUnroll; ++u) {
             s0 += w[u].x;
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
 // of the fast kernel.
 __device__ __forceinline__ double2 slot_emission(const WinArgs &P, int gene) {
     double s0 = 0.0, s1 = 0.0;
-    if (gene >= 0) state_scores_l2(P.attr_id, P.wtab2, P.gene_ptr[gene], P.gene_ptr[gene + 1], s0, s1);
+    if (gene >= 0) state_scores_l2(P.attr_id, P.wtab2, P.A, P.gene_ptr[gene], P.gene_ptr[gene + 1], s0, s1);
     const double m = fmax(s0, s1);
     return make_double2(exp(s0 - m), exp(s1 - m));  // (other, label)
 }

@@ -6,6 +6,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 namespace gecco {
@@ -13,7 +14,8 @@ namespace gecco {
 void set_error(const std::string &msg);
 const char *last_error();
 
-struct DeviceTables;  // defined in crf_plan.cpp (per-device uploaded copies)
+struct DeviceTables;  // defined in crf_plan.hpp (per-device uploaded copies)
+struct Session;       // defined in crf_session.cpp (batch driver)
 
 struct Model {
     int32_t L = 0, A = 0, n_features = 0;
@@ -27,6 +29,8 @@ struct Model {
     // lazily created per-device copies, owned by the model
     mutable std::mutex dev_mutex;
     mutable std::vector<DeviceTables *> dev_tables;
+    // per-device batch drivers behind the one-shot entry points (created on first use, owned by the model)
+    mutable std::vector<std::pair<int, Session *>> sessions;
     ~Model();
 };
 

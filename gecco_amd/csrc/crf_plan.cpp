@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "../../include/gecco_crf.h"
+#include "crf_session.hpp"
 
 namespace gecco {
 
@@ -30,6 +31,7 @@ int upload(T **dst, const T *src, size_t n, const char *what) {
 }  // namespace
 
 Model::~Model() {
+    for (auto &e : sessions) session_destroy(e.second);  // before the tables their plans point at
     for (DeviceTables *t : dev_tables) {
         if (!t) continue;
         int prev = 0;
@@ -41,8 +43,17 @@ Model::~Model() {
             (void)hipFree(t->trans);
             (void)hipSetDevice(prev);
         }
-        delete t;
+        delete t;  // without a usable device the allocations die with the context
     }
+}
+
+static void free_device_tables(DeviceTables *t) {
+    (void)hipFree(t->wtab);
+    (void)hipFree(t->wtab2[0]);
+    (void)hipFree(t->wtab2[1]);
+    (void)hipFree(t->exp_trans);
+    (void)hipFree(t->trans);
+    delete t;
 }
 
 int get_device_tables(const Model &m, int device, const DeviceTables **out) {
@@ -57,39 +68,59 @@ int get_device_tables(const Model &m, int device, const DeviceTables **out) {
     auto *t = new DeviceTables();
     t->device = device;
     const size_t A = size_t(m.A), L = size_t(m.L);
-    if ((rc = upload(&t->wtab, m.state.data(), A * L, "upload state weights"))) return rc;
     std::vector<double> et(L * L);
     for (size_t i = 0; i < L * L; ++i) et[i] = std::exp(m.trans[i]);
-    if ((rc = upload(&t->exp_trans, et.data(), L * L, "upload transitions"))) return rc;
-    if ((rc = upload(&t->trans, m.trans.data(), L * L, "upload transitions"))) return rc;
-    if (m.L == 2) {
+    rc = upload(&t->wtab, m.state.data(), A * L, "upload state weights");
+    if (!rc) rc = upload(&t->exp_trans, et.data(), L * L, "upload transitions");
+    if (!rc) rc = upload(&t->trans, m.trans.data(), L * L, "upload transitions");
+    if (!rc && m.L == 2) {
         std::vector<double2> w2(A ? A : 1);
-        for (int label = 0; label < 2; ++label) {
+        for (int label = 0; label < 2 && !rc; ++label) {
             for (size_t a = 0; a < A; ++a) w2[a] = make_double2(m.state[a * 2 + (1 - label)], m.state[a * 2 + label]);
-            if ((rc = upload(&t->wtab2[label], w2.data(), A, "upload state weight pairs"))) return rc;
+            rc = upload(&t->wtab2[label], w2.data(), A, "upload state weight pairs");
         }
+    }
+    if (rc) {
+        free_device_tables(t);
+        return rc;
     }
     m.dev_tables.push_back(t);
     *out = t;
     return GECCO_CRF_OK;
 }
 
+int Arena::reserve(size_t bytes, const char *what) {
+    if (bytes <= cap && h) return GECCO_CRF_OK;
+    release();
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);  // head room: chunks of one batch differ a little
+    int rc = check_hip(hipHostMalloc(reinterpret_cast<void **>(&h), want, hipHostMallocDefault), what);
+    if (rc) return rc;
+    if ((rc = check_hip(hipMalloc(reinterpret_cast<void **>(&d), want), what))) {
+        (void)hipHostFree(h);
+        h = nullptr;
+        return rc;
+    }
+    cap = want;
+    return GECCO_CRF_OK;
+}
+
+void Arena::release() {
+    if (h) (void)hipHostFree(h);
+    if (d) (void)hipFree(d);
+    h = d = nullptr;
+    cap = 0;
+}
+
 Plan::~Plan() {
     if (device >= 0) {
         int prev = 0;
         if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess) {
-            (void)hipFree(d_c_slot);
-            (void)hipFree(d_c_gene);
-            (void)hipFree(d_c_n);
-            (void)hipFree(d_contig_ptr);
-            (void)hipFree(d_tile_desc);
-            (void)hipFree(d_start_bits);
-            (void)hipFree(d_skipped);
-            (void)hipFree(d_seq_flags);
-            (void)hipFree(d_seq_blk_cs);
+            tables.release();
+            seq.release();
             (void)hipFree(d_seq_ws);
             (void)hipFree(d_win_scratch);
             (void)hipFree(d_gen_ws);
+            (void)hipFree(d_seg_ws);
             (void)hipSetDevice(prev);
         }
     }
@@ -128,8 +159,40 @@ static bool rescale_mask_for(const Model &m, int W, uint32_t *mask) {
     return true;
 }
 
+// bits [lo, hi) of a bit array
+static inline void set_bit_range(uint64_t *bits, int64_t lo, int64_t hi) {
+    if (lo >= hi) return;
+    const int64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+    const uint64_t m0 = ~0ull << (lo & 63), m1 = ~0ull >> (63 - ((hi - 1) & 63));
+    if (w0 == w1) {
+        bits[w0] |= m0 & m1;
+        return;
+    }
+    bits[w0] |= m0;
+    for (int64_t w = w0 + 1; w < w1; ++w) bits[w] = ~0ull;
+    bits[w1] |= m1;
+}
+
+namespace {
+inline size_t align256p(size_t x) { return (x + 255) & ~size_t(255); }
+
+// grow-only device workspace (hipFree waits for the launches that may still use the old block)
+template <class T>
+int grow_ws(T *&ptr, size_t &cap, size_t bytes, const char *what) {
+    if (ptr && bytes <= cap) return GECCO_CRF_OK;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    int rc = check_hip(hipMalloc(reinterpret_cast<void **>(&ptr), want), what);
+    if (rc) return rc;
+    cap = want;
+    return GECCO_CRF_OK;
+}
+}  // namespace
+
 int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_contigs, int32_t W, int32_t step,
-               int32_t pad, Plan &p) {
+               int32_t pad, Plan &p, hipStream_t upload_stream, bool sync) {
     // same checks, same order as gecco/_meta.py:127-130
     if (W <= 0) {
         set_error("Window size must be strictly positive");
@@ -143,22 +206,38 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
         set_error("bad contig_ptr");
         return GECCO_CRF_EINVAL;
     }
+    if (p.device >= 0 && p.device != device) {
+        set_error("a plan cannot move to another device");
+        return GECCO_CRF_EINVAL;
+    }
     p.model = &m;
     p.device = device;
     p.W = W;
     p.step = step;
     p.pad = pad ? 1 : 0;
     p.n_contigs = n_contigs;
-    p.n_genes = n_contigs ? contig_ptr[n_contigs] : 0;
-    p.contig_ptr.assign(contig_ptr, contig_ptr + (n_contigs ? n_contigs + 1 : 0));
-    if (n_contigs && contig_ptr[0] != 0) {
-        set_error("contig_ptr[0] must be 0");
-        return GECCO_CRF_EINVAL;
+    // a slice of a larger batch is accepted: gene offsets are taken relative to its first contig
+    const int64_t g_base = n_contigs ? contig_ptr[0] : 0;
+    {
+        const int64_t ng = n_contigs ? int64_t(contig_ptr[n_contigs]) - g_base : 0;
+        if (ng < 0) {
+            set_error("contig_ptr must be non-decreasing");
+            return GECCO_CRF_EINVAL;
+        }
+        p.n_genes = int32_t(ng);
     }
+    p.contig_ptr.resize(n_contigs ? size_t(n_contigs) + 1 : 0);
+    p.c_slot.clear();
+    p.c_gene.clear();
+    p.c_n.clear();
+    p.skipped.clear();
+    p.seq_ready = false;
     int64_t S = 0;
     p.n_windows = 0;
+    if (n_contigs) p.contig_ptr[0] = 0;
     for (int32_t c = 0; c < n_contigs; ++c) {
-        const int32_t g0 = contig_ptr[c], n = contig_ptr[c + 1] - g0;
+        const int32_t g0 = int32_t(contig_ptr[c] - g_base), n = contig_ptr[c + 1] - contig_ptr[c];
+        p.contig_ptr[size_t(c) + 1] = g0 + n;
         if (n < 0) {
             set_error("contig_ptr must be non-decreasing");
             return GECCO_CRF_EINVAL;
@@ -209,45 +288,78 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     p.ntiles = p.S > 0 ? (p.S + p.tile_out - 1) / p.tile_out : 0;
     // window-start flags per slot (_meta.py:131: starts at 0, step, 2*step, ... <= n' - W)
     p.start_bits.assign(size_t(p.S) / 64 + 2, 0);
-    // regular[k]: contig k is unpadded; joined[k]: contig k+1 follows k without a skipped contig
-    std::vector<uint8_t> irregular(size_t(p.K) + 1, 0);
+    // irregular[k]: contig k is padded, or a skipped contig lies between it and contig k+1
+    std::vector<int32_t> &irr_prefix = p.irr_prefix;
+    irr_prefix.assign(size_t(p.K) + 1, 0);
     for (int32_t k = 0; k < p.K; ++k) {
         const int32_t s0 = p.c_slot[k], np = p.c_slot[k + 1] - s0;
-        for (int32_t pos = 0; pos + W <= np; pos += step) {
-            const int64_t q = int64_t(s0) + pos;
-            p.start_bits[size_t(q >> 6)] |= 1ull << (q & 63);
+        if (step == 1) {
+            set_bit_range(p.start_bits.data(), s0, int64_t(s0) + np - W + 1);
+        } else {
+            for (int32_t pos = 0; pos + W <= np; pos += step) {
+                const int64_t q = int64_t(s0) + pos;
+                p.start_bits[size_t(q >> 6)] |= 1ull << (q & 63);
+            }
         }
         const bool padded = np != p.c_n[k];
         const bool gap_after = k + 1 < p.K && p.c_gene[k + 1] != p.c_gene[k] + p.c_n[k];
-        irregular[k] = padded || gap_after;
+        irr_prefix[k + 1] = irr_prefix[k] + ((padded || gap_after) ? 1 : 0);
     }
-    std::vector<int32_t> irr_prefix(size_t(p.K) + 1, 0);
-    for (int32_t k = 0; k < p.K; ++k) irr_prefix[k + 1] = irr_prefix[k] + irregular[k];
     p.tile_desc.resize(p.ntiles);
-    for (int32_t b = 0; b < p.ntiles; ++b) {
-        const int64_t q0 = int64_t(b) * p.tile_out - (W - 1);
-        const int64_t q_lo = std::max<int64_t>(q0, 0);
-        const int64_t q_hi = std::min<int64_t>(q0 + p.tile_out + 2 * (W - 1) - 1, p.S - 1);
-        const int first = int(std::upper_bound(p.c_slot.begin(), p.c_slot.begin() + p.K, int32_t(q_lo)) - p.c_slot.begin()) - 1;
-        const int last = int(std::upper_bound(p.c_slot.begin(), p.c_slot.begin() + p.K, int32_t(q_hi)) - p.c_slot.begin()) - 1;
-        // regular: no padded contig in reach and no skipped contig between the contigs in reach
-        // (a gap after the last contig is harmless)
-        const bool padded_or_gap = (irr_prefix[last] - irr_prefix[first]) != 0 || (p.c_slot[last + 1] - p.c_slot[last] != p.c_n[last]);
-        const int shift = p.c_gene[first] - p.c_slot[first];
-        p.tile_desc[b] = make_int4(shift, first, last, padded_or_gap ? 0 : 1);
+    {
+        // contigs in reach of a workgroup: both ends of the reach only move forward from tile to tile
+        int first = 0, last = 0;
+        for (int32_t b = 0; b < p.ntiles; ++b) {
+            const int64_t q0 = int64_t(b) * p.tile_out - (W - 1);
+            const int64_t q_lo = std::max<int64_t>(q0, 0);
+            const int64_t q_hi = std::min<int64_t>(q0 + p.tile_out + 2 * (W - 1) - 1, p.S - 1);
+            while (first + 1 < p.K && p.c_slot[first + 1] <= q_lo) ++first;  // largest k with c_slot[k] <= q_lo
+            if (last < first) last = first;
+            while (last + 1 < p.K && p.c_slot[last + 1] <= q_hi) ++last;
+            // regular: no padded contig in reach and no skipped contig between the contigs in reach
+            // (a gap after the last contig is harmless)
+            const bool padded_or_gap =
+                (irr_prefix[last] - irr_prefix[first]) != 0 || (p.c_slot[last + 1] - p.c_slot[last] != p.c_n[last]);
+            const int shift = p.c_gene[first] - p.c_slot[first];
+            p.tile_desc[b] = make_int4(shift, first, last, padded_or_gap ? 0 : 1);
+        }
     }
     if (device < 0) return GECCO_CRF_OK;
 
     int rc = check_hip(hipSetDevice(device), "hipSetDevice");
     if (rc) return rc;
-    if ((rc = get_device_tables(m, device, &p.tables))) return rc;
-    if ((rc = upload(&p.d_c_slot, p.c_slot.data(), p.c_slot.size(), "upload plan"))) return rc;
-    if ((rc = upload(&p.d_c_gene, p.c_gene.data(), p.c_gene.size(), "upload plan"))) return rc;
-    if ((rc = upload(&p.d_c_n, p.c_n.data(), p.c_n.size(), "upload plan"))) return rc;
-    if ((rc = upload(&p.d_tile_desc, p.tile_desc.data(), p.tile_desc.size(), "upload plan"))) return rc;
-    if ((rc = upload(&p.d_start_bits, p.start_bits.data(), p.start_bits.size(), "upload plan"))) return rc;
-    if ((rc = upload(&p.d_skipped, p.skipped.data(), p.skipped.size(), "upload plan"))) return rc;
-    if ((rc = upload(&p.d_contig_ptr, p.contig_ptr.data(), p.contig_ptr.size(), "upload plan"))) return rc;
+    if ((rc = get_device_tables(m, device, &p.tables_model))) return rc;
+    // one pinned block -> one device block, one copy
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t r = off;
+        off += align256p(bytes ? bytes : 1);
+        return r;
+    };
+    const size_t o_slot = take(p.c_slot.size() * 4), o_gene = take(p.c_gene.size() * 4), o_n = take(p.c_n.size() * 4),
+                 o_tile = take(p.tile_desc.size() * sizeof(int4)), o_bits = take(p.start_bits.size() * 8),
+                 o_skip = take(p.skipped.size() * sizeof(int2)), o_cptr = take(p.contig_ptr.size() * 4);
+    if ((rc = p.tables.reserve(off, "plan tables"))) return rc;
+    char *h = p.tables.h, *d = p.tables.d;
+    auto put = [&](size_t o, const void *src, size_t bytes) {
+        if (bytes) std::memcpy(h + o, src, bytes);
+    };
+    put(o_slot, p.c_slot.data(), p.c_slot.size() * 4);
+    put(o_gene, p.c_gene.data(), p.c_gene.size() * 4);
+    put(o_n, p.c_n.data(), p.c_n.size() * 4);
+    put(o_tile, p.tile_desc.data(), p.tile_desc.size() * sizeof(int4));
+    put(o_bits, p.start_bits.data(), p.start_bits.size() * 8);
+    put(o_skip, p.skipped.data(), p.skipped.size() * sizeof(int2));
+    put(o_cptr, p.contig_ptr.data(), p.contig_ptr.size() * 4);
+    p.d_c_slot = reinterpret_cast<int32_t *>(d + o_slot);
+    p.d_c_gene = reinterpret_cast<int32_t *>(d + o_gene);
+    p.d_c_n = reinterpret_cast<int32_t *>(d + o_n);
+    p.d_tile_desc = reinterpret_cast<int4 *>(d + o_tile);
+    p.d_start_bits = reinterpret_cast<uint64_t *>(d + o_bits);
+    p.d_skipped = reinterpret_cast<int2 *>(d + o_skip);
+    p.d_contig_ptr = reinterpret_cast<int32_t *>(d + o_cptr);
+    if ((rc = check_hip(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, upload_stream), "upload plan tables"))) return rc;
+    if (sync && (rc = check_hip(hipStreamSynchronize(upload_stream), "upload plan tables"))) return rc;
     return GECCO_CRF_OK;
 }
 
@@ -259,20 +371,21 @@ int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, 
     const Model &m = *p.model;
     const size_t n = size_t(p.n_genes), L = size_t(m.L);
     const size_t b_vec = align256g(n * L * 8 + 8), b_one = align256g(n * 8 + 8), b_back = align256g(n * L + 8);
-    if (!p.d_gen_ws) {
-        int rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_gen_ws), 3 * b_vec + 2 * b_one + b_back),
-                           "hipMalloc general-L workspace");
+    {
+        std::lock_guard<std::mutex> lock(p.ws_mutex);
+        int rc = grow_ws(p.d_gen_ws, p.gen_ws_cap, 3 * b_vec + 2 * b_one + b_back, "hipMalloc general-L workspace");
         if (rc) return rc;
     }
     char *w = p.d_gen_ws;
     a = GenArgs{};
     a.gene_ptr = d_gene_ptr;
     a.attr_id = d_attr_id;
-    a.wtab = p.tables->wtab;
-    a.exp_trans = p.tables->exp_trans;
-    a.trans = p.tables->trans;
+    a.wtab = p.tables_model->wtab;
+    a.exp_trans = p.tables_model->exp_trans;
+    a.trans = p.tables_model->trans;
     a.contig_ptr = p.d_contig_ptr;
     a.L = m.L;
+    a.A = m.A;
     a.n_genes = p.n_genes;
     a.n_contigs = p.n_contigs;
     a.state = reinterpret_cast<double *>(w);
@@ -345,9 +458,9 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     WinArgs a{};
     a.gene_ptr = d_gene_ptr;
     a.attr_id = d_attr_id;
-    a.wtab = p.tables->wtab;
-    a.wtab2 = p.tables->wtab2[label];
-    a.exp_trans = p.tables->exp_trans;
+    a.wtab = p.tables_model->wtab;
+    a.wtab2 = p.tables_model->wtab2[label];
+    a.exp_trans = p.tables_model->exp_trans;
     a.c_slot = p.d_c_slot;
     a.c_gene = p.d_c_gene;
     a.c_n = p.d_c_n;
@@ -393,10 +506,11 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     }
     a.generic = p.fast_ok ? 0 : 1;
     if (a.generic) {
-        if (!p.d_win_scratch &&
-            (rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_win_scratch), size_t(p.S) * size_t(p.W) * 16 + 16),
-                            "hipMalloc window scratch")))
-            return rc;
+        {
+            std::lock_guard<std::mutex> lock(p.ws_mutex);
+            if ((rc = grow_ws(p.d_win_scratch, p.win_scratch_cap, size_t(p.S) * size_t(p.W) * 16 + 16, "hipMalloc window scratch")))
+                return rc;
+        }
         a.scratch = p.d_win_scratch;
         // atomic-max accumulation starts from 0.0 (numpy.zeros, crf/__init__.py:251)
         if ((rc = check_hip(hipMemsetAsync(d_p_out, 0, size_t(p.n_genes) * 8, stream), "memset p"))) return rc;
@@ -443,39 +557,58 @@ SeqLayout seq_layout(size_t n) {
     return l;
 }
 
-int ensure_seq(Plan &p) {
+}  // namespace
+
+int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
+    std::lock_guard<std::mutex> lock(p.ws_mutex);
     if (p.seq_ready) return GECCO_CRF_OK;
-    std::vector<uint8_t> flags(size_t(p.n_genes) + 1, 0);
+    if (p.device < 0) {
+        set_error("host-only plan: no HIP device bound (there is no CPU fallback)");
+        return GECCO_CRF_ENODEV;
+    }
+    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
+    if (rc) return rc;
+    const size_t n = size_t(p.n_genes);
+    const size_t nb = (n + kSeqBlockGenes - 1) / kSeqBlockGenes;
+    const size_t o_flags = 0, o_blk = align256p(n + 8), bytes = o_blk + align256p((nb ? nb : 1) * 4);
+    if ((rc = p.seq.reserve(bytes, "contig flags"))) return rc;
+    uint8_t *flags = reinterpret_cast<uint8_t *>(p.seq.h + o_flags);
+    int32_t *blk_cs = reinterpret_cast<int32_t *>(p.seq.h + o_blk);
+    std::memset(flags, 0, n + 8);
+    for (size_t b = 0; b < (nb ? nb : 1); ++b) blk_cs[b] = 0;
+    // per scan block: where the contig of its first gene starts; and whether every contig fits a block
+    p.seq_short = true;
+    size_t b = 0;
     for (int32_t c = 0; c < p.n_contigs; ++c) {
         const int32_t g0 = p.contig_ptr[c], g1 = p.contig_ptr[c + 1];
         if (g1 > g0) {
             flags[g0] |= 1;
             flags[g1 - 1] |= 2;
         }
+        if (g1 - g0 > kSeqBlockGenes) p.seq_short = false;
+        for (; b < nb && int64_t(b) * kSeqBlockGenes < g1; ++b)
+            if (int64_t(b) * kSeqBlockGenes >= g0) blk_cs[b] = g0;
     }
-    // per scan block: where the contig of its first gene starts; and whether every contig fits a block
-    const size_t nb = (size_t(p.n_genes) + kSeqBlockGenes - 1) / kSeqBlockGenes;
-    std::vector<int32_t> blk_cs(nb ? nb : 1, 0);
-    p.seq_short = true;
-    {
-        size_t b = 0;
-        for (int32_t c = 0; c < p.n_contigs; ++c) {
-            const int32_t g0 = p.contig_ptr[c], g1 = p.contig_ptr[c + 1];
-            if (g1 - g0 > kSeqBlockGenes) p.seq_short = false;
-            for (; b < nb && int64_t(b) * kSeqBlockGenes < g1; ++b)
-                if (int64_t(b) * kSeqBlockGenes >= g0) blk_cs[b] = g0;
-        }
-    }
-    int rc;
-    if ((rc = upload(&p.d_seq_flags, flags.data(), flags.size(), "upload contig flags"))) return rc;
-    if ((rc = upload(&p.d_seq_blk_cs, blk_cs.data(), blk_cs.size(), "upload scan block table"))) return rc;
-    const SeqLayout l = seq_layout(size_t(p.n_genes));
-    if ((rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_seq_ws), l.bytes), "hipMalloc scan workspace"))) return rc;
+    p.d_seq_flags = reinterpret_cast<uint8_t *>(p.seq.d + o_flags);
+    p.d_seq_blk_cs = reinterpret_cast<int32_t *>(p.seq.d + o_blk);
+    // launches that read the tables must be ordered behind this copy: `sync` (any stream may follow), or the
+    // caller keeps to `stream` (the batch driver)
+    if ((rc = check_hip(hipMemcpyAsync(p.seq.d, p.seq.h, bytes, hipMemcpyHostToDevice, stream), "upload contig flags"))) return rc;
+    if (sync && (rc = check_hip(hipStreamSynchronize(stream), "upload contig flags"))) return rc;
     p.seq_ready = true;
     return GECCO_CRF_OK;
 }
 
-int fill_seq_args(Plan &p, SeqArgs &a) {
+namespace {
+int ensure_seq(Plan &p, hipStream_t stream) {
+    int rc = plan_ensure_seq(p, stream, !p.async_tables);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(p.ws_mutex);
+    const SeqLayout l = seq_layout(size_t(p.n_genes));
+    return grow_ws(p.d_seq_ws, p.seq_ws_cap, l.bytes, "hipMalloc scan workspace");
+}
+
+int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
     if (p.device < 0) {
         set_error("host-only plan: no HIP device bound (there is no CPU fallback)");
         return GECCO_CRF_ENODEV;
@@ -483,7 +616,7 @@ int fill_seq_args(Plan &p, SeqArgs &a) {
     int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
     if (rc) return rc;
     if (p.general) return GECCO_CRF_OK;  // the any-L path has its own workspace
-    if ((rc = ensure_seq(p))) return rc;
+    if ((rc = ensure_seq(p, stream))) return rc;
     const Model &m = *p.model;
     const SeqLayout l = seq_layout(size_t(p.n_genes));
     char *w = p.d_seq_ws;
@@ -534,7 +667,7 @@ static bool viterbi_delta_ok(const SeqArgs &a, const double *d_score) {
 int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, double *d_marg,
                             double *d_lognorm, hipStream_t stream) {
     SeqArgs a;
-    int rc = fill_seq_args(p, a);
+    int rc = fill_seq_args(p, a, stream);
     if (rc) return rc;
     if (p.n_contigs == 0) return GECCO_CRF_OK;
     if (p.n_genes > 0 && (!d_gene_ptr || !d_marg)) {
@@ -553,7 +686,7 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
     a.marg = d_marg;
     a.lognorm = d_lognorm;
     // wtab2[1] holds (w[a][0], w[a][1]) = (other, label) pairs for label 1
-    if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables->wtab2[1], p.n_genes,
+    if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables_model->wtab2[1], p.model->A, p.n_genes,
                                          const_cast<double2 *>(a.state), stream), "state score launch")))
         return rc;
     return check_hip(launch_seq_marginals(a, p.d_contig_ptr, stream), "marginals launch");
@@ -562,7 +695,7 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
 int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int8_t *d_y, double *d_score,
                      hipStream_t stream) {
     SeqArgs a;
-    int rc = fill_seq_args(p, a);
+    int rc = fill_seq_args(p, a, stream);
     if (rc) return rc;
     if (p.n_contigs == 0) return GECCO_CRF_OK;
     if (p.n_genes > 0 && (!d_gene_ptr || !d_y)) {
@@ -582,12 +715,12 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
     a.y = d_y;
     a.score = d_score;
     if (viterbi_delta_ok(a, d_score)) {
-        if ((rc = check_hip(launch_seq_state_delta(d_gene_ptr, d_attr_id, p.tables->wtab2[1], p.n_genes,
+        if ((rc = check_hip(launch_seq_state_delta(d_gene_ptr, d_attr_id, p.tables_model->wtab2[1], p.model->A, p.n_genes,
                                                    const_cast<double *>(a.dstate), stream), "state score launch")))
             return rc;
         return check_hip(launch_seq_viterbi_delta(a, stream), "viterbi launch");
     }
-    if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables->wtab2[1], p.n_genes,
+    if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables_model->wtab2[1], p.model->A, p.n_genes,
                                          const_cast<double2 *>(a.state), stream), "state score launch")))
         return rc;
     return check_hip(launch_seq_viterbi(a, p.d_contig_ptr, stream), "viterbi launch");
@@ -608,7 +741,7 @@ int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id
         return GECCO_CRF_EINVAL;
     }
     SeqArgs a;
-    int rc = fill_seq_args(p, a);
+    int rc = fill_seq_args(p, a, stream);
     if (rc) return rc;
     if (p.n_contigs == 0 || p.n_genes == 0) return GECCO_CRF_OK;
     if (!d_gene_ptr || !d_p_out || !d_y) {
@@ -625,6 +758,29 @@ int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id
     if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, const_cast<double2 *>(a.state), nullptr, stream)))
         return rc;
     return check_hip(launch_seq_viterbi(a, p.d_contig_ptr, stream), "viterbi launch");
+}
+
+int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, double threshold, int32_t n_cds,
+                     int32_t edge_distance, int32_t trim, int32_t carry, int32_t *d_seg, int32_t max_seg, int32_t *d_seg_off,
+                     int32_t *d_total, hipStream_t stream) {
+    if (!d_total || max_seg < 0 || (max_seg > 0 && !d_seg)) {
+        set_error("plan_run_segment: bad arguments");
+        return GECCO_CRF_EINVAL;
+    }
+    int rc = plan_ensure_seq(p, stream, !p.async_tables);
+    if (rc) return rc;
+    if (p.n_genes > 0 && (!d_p || !d_annotated)) {
+        set_error("null device buffer");
+        return GECCO_CRF_EINVAL;
+    }
+    {
+        std::lock_guard<std::mutex> lock(p.ws_mutex);
+        if ((rc = grow_ws(p.d_seg_ws, p.seg_ws_cap, segment_workspace_bytes(p.n_genes, p.n_contigs), "hipMalloc segment workspace")))
+            return rc;
+    }
+    return check_hip(launch_segment(d_p, d_annotated, p.d_seq_flags, p.d_contig_ptr, p.n_genes, p.n_contigs, threshold, n_cds,
+                                    edge_distance, trim, carry, d_seg, max_seg, d_seg_off, d_total, p.d_seg_ws, stream),
+                     "segment launch");
 }
 
 }  // namespace gecco

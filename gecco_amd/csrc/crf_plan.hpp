@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,16 @@ struct DeviceTables {
     double *trans = nullptr;      // [L*L] raw weights (general-L Viterbi)
 };
 
+// A pinned host block mirrored by a device block: plan tables are written on the host side and reach
+// the device with ONE asynchronous copy.  Grow-only, so a plan that is rebuilt for the next chunk of a
+// batch (crf_session.cpp) allocates nothing once it has seen its largest chunk.
+struct Arena {
+    char *h = nullptr, *d = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes, const char *what);  // the plan's device must be current
+    void release();
+};
+
 struct Plan {
     const Model *model = nullptr;
     int device = -1;  // -1: host-only plan (layout queries work, launches return ENODEV)
@@ -35,30 +46,46 @@ struct Plan {
     std::vector<uint64_t> start_bits;
     std::vector<int2> skipped;  // gene ranges of contigs skipped by pad == 0
     std::vector<int32_t> contig_ptr;
+    std::vector<int32_t> irr_prefix;  // scratch of plan_build (kept for its capacity)
     uint32_t rescale_mask = 0;
     bool fast_ok = false;       // the register-resident kernel takes this shape
     bool force_generic = false; // GECCO_CRF_FORCE_GENERIC=1 (tests): always use the generic kernel
     bool general = false;       // any-L kernels (crf_general.hip): L != 2, or GECCO_CRF_FORCE_GENERAL=1 (tests)
-    char *d_gen_ws = nullptr;   // their per-gene workspace, allocated on first use
-    double *d_win_scratch = nullptr;
     std::string kernel_name;
-    // device copies
+    // device copies (all inside `tables`)
+    Arena tables;
     int32_t *d_c_slot = nullptr, *d_c_gene = nullptr, *d_c_n = nullptr, *d_contig_ptr = nullptr;
     int4 *d_tile_desc = nullptr;
     uint64_t *d_start_bits = nullptr;
     int2 *d_skipped = nullptr;
-    const DeviceTables *tables = nullptr;
-    // whole-contig scans (rows F, V): chunk tables + workspace, built on first use
+    const DeviceTables *tables_model = nullptr;
+    // whole-contig scans (rows F, V) and the segmenter: contig flags + scan block table, built on first use
+    Arena seq;
     bool seq_ready = false;
     uint8_t *d_seq_flags = nullptr;
     int32_t *d_seq_blk_cs = nullptr;  // per 2048-gene scan block: first gene of the contig its first gene belongs to
     bool seq_short = false;           // no contig longer than one scan block: Viterbi looks back by recomputation
-    char *d_seq_ws = nullptr;
+    // workspaces, allocated on first use, grow-only
+    char *d_seq_ws = nullptr, *d_gen_ws = nullptr, *d_seg_ws = nullptr;
+    double *d_win_scratch = nullptr;
+    size_t seq_ws_cap = 0, gen_ws_cap = 0, seg_ws_cap = 0, win_scratch_cap = 0;
+    bool async_tables = false;  // the owner launches everything on ONE stream (batch driver): table uploads are not waited for
+    std::mutex ws_mutex;  // guards the lazy workspace / table creation: launches of one plan may come from several threads
     ~Plan();
 };
 
+// `upload_stream` / `sync`: the device copy of the tables is ONE asynchronous copy on that stream; with
+// sync it is waited for before returning (the caller may then launch on any stream).  `p` may be a plan
+// that has been built before: its allocations are reused.
 int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_contigs, int32_t W, int32_t step,
-               int32_t pad, Plan &p);
+               int32_t pad, Plan &p, hipStream_t upload_stream = nullptr, bool sync = true);
+// contig flags / scan block table on the device (what rows F, V and R need), uploaded on `stream`
+int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync = true);
+// row R chained behind the marginals on the same stream: d_p and d_annotated are device arrays over the
+// plan's genes; rows go to d_seg (device-accessible memory), their number to d_total
+int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, double threshold, int32_t n_cds,
+                     int32_t edge_distance, int32_t trim, int32_t carry, int32_t *d_seg, int32_t max_seg, int32_t *d_seg_off,
+                     int32_t *d_total, hipStream_t stream);
 int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                       hipStream_t stream);
 // windowed marginals + whole-contig Viterbi of the same batch in one pass over the CSR

@@ -1,0 +1,110 @@
+// Workgroup-level scan plumbing shared by the flat segmented scans (crf_sequence.hip: rows F / V;
+// crf_segment.hip: row R): DPP moves of whole scan elements, a 64-lane inclusive scan without LDS
+// traffic, and a workgroup-wide exclusive scan whose wave totals meet in LDS.  gfx950 only.
+#pragma once
+#include "crf_device.hpp"
+
+namespace gecco {
+namespace {
+
+constexpr int kScanThreads = 256;  // lanes per workgroup of every flat-scan kernel
+
+struct MapOp {  // maps {0,1}->{0,1} packed in 2 bits: bit x = image of x
+    static __device__ __forceinline__ uint32_t identity() { return 2u; }
+    // result(x) = a(b(x)): b is applied first.  In the backward label scans the element closer
+    // to the END of the sequence acts first.
+    static __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) {
+        return ((a >> (b & 1u)) & 1u) | (((a >> ((b >> 1) & 1u)) & 1u) << 1);
+    }
+};
+
+
+// ---------------------------------------------------------------- DPP plumbing
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_f64(double old, double src) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, RM, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, RM, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ VE dpp_elem(const VE &old, const VE &s) {
+    return VE{dpp_f64<CTRL, RM>(old.a00, s.a00), dpp_f64<CTRL, RM>(old.a01, s.a01), dpp_f64<CTRL, RM>(old.a10, s.a10),
+              dpp_f64<CTRL, RM>(old.a11, s.a11), dpp_f64<CTRL, RM>(old.rs, s.rs)};
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ FE dpp_elem(const FE &old, const FE &s) {
+    return FE{dpp_f64<CTRL, RM>(old.a00, s.a00), dpp_f64<CTRL, RM>(old.a01, s.a01), dpp_f64<CTRL, RM>(old.a10, s.a10),
+              dpp_f64<CTRL, RM>(old.a11, s.a11), dpp_f64<CTRL, RM>(old.ex, s.ex),   dpp_f64<CTRL, RM>(old.ms, s.ms),
+              dpp_f64<CTRL, RM>(old.rs, s.rs)};
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ CE dpp_elem(const CE &old, const CE &s) {
+    return CE{dpp_f64<CTRL, RM>(old.a, s.a), dpp_f64<CTRL, RM>(old.L, s.L), dpp_f64<CTRL, RM>(old.H, s.H)};
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ SegE dpp_elem(const SegE &old, const SegE &s) {
+    auto mv = [](uint32_t o, uint32_t v) { return uint32_t(__builtin_amdgcn_update_dpp(int(o), int(v), CTRL, RM, 0xF, false)); };
+    return SegE{mv(old.map, s.map), mv(old.ng0, s.ng0), mv(old.ng1, s.ng1), mv(old.ann, s.ann)};
+}
+struct U2 {  // pair of counters (plain sums)
+    uint32_t x, y;
+};
+template <int CTRL, int RM>
+__device__ __forceinline__ U2 dpp_elem(const U2 &old, const U2 &s) {
+    auto mv = [](uint32_t o, uint32_t v) { return uint32_t(__builtin_amdgcn_update_dpp(int(o), int(v), CTRL, RM, 0xF, false)); };
+    return U2{mv(old.x, s.x), mv(old.y, s.y)};
+}
+struct AddOp {
+    static __device__ __forceinline__ U2 identity() { return U2{0u, 0u}; }
+    static __device__ __forceinline__ U2 combine(const U2 &a, const U2 &b) { return U2{a.x + b.x, a.y + b.y}; }
+};
+template <int CTRL, int RM>
+__device__ __forceinline__ uint32_t dpp_elem(const uint32_t &old, const uint32_t &s) {
+    return uint32_t(__builtin_amdgcn_update_dpp(int(old), int(s), CTRL, RM, 0xF, false));
+}
+
+// REV = false: out[l] = e[0] (x) e[1] (x) ... (x) e[l]   (lane order = sequence order)
+// REV = true : out[l] = e[l] (x) e[l-1] (x) ... (x) e[0]  (lanes hold the sequence back to front)
+template <class Op, bool REV, class E>
+__device__ __forceinline__ E comb(const E &earlier_lane, const E &later_lane) {
+    return REV ? Op::combine(later_lane, earlier_lane) : Op::combine(earlier_lane, later_lane);
+}
+template <class Op, bool REV, class E>
+__device__ __forceinline__ E wave_scan_inclusive(E v) {
+    const E id = Op::identity();
+    v = comb<Op, REV>(dpp_elem<0x111, 0xF>(id, v), v);  // row_shr:1
+    v = comb<Op, REV>(dpp_elem<0x112, 0xF>(id, v), v);  // row_shr:2
+    v = comb<Op, REV>(dpp_elem<0x114, 0xF>(id, v), v);  // row_shr:4
+    v = comb<Op, REV>(dpp_elem<0x118, 0xF>(id, v), v);  // row_shr:8
+    v = comb<Op, REV>(dpp_elem<0x142, 0xA>(id, v), v);  // row_bcast:15 -> rows 1,3
+    v = comb<Op, REV>(dpp_elem<0x143, 0xC>(id, v), v);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+template <class E>
+__device__ __forceinline__ E wave_shift_up(const E &id, const E &v) {  // lane l <- lane l-1, lane 0 <- id
+    return dpp_elem<0x138, 0xF>(id, v);                                 // wave_shr:1
+}
+// Workgroup-wide EXCLUSIVE scan of one element per lane (kT lanes); *total = product of all.
+template <class Op, bool REV, class E, int NTH = kScanThreads>
+__device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /* NTH/64 */, E *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const E id = Op::identity();
+    const E incl = wave_scan_inclusive<Op, REV>(mine);
+    if (lane == 63) lds_totals[wave] = incl;
+    E excl = wave_shift_up(id, incl);
+    __syncthreads();
+    E pre = id, all = id;
+#pragma unroll
+    for (int w = 0; w < NTH / 64; ++w) {
+        const E t = lds_totals[w];
+        if (w < wave) pre = comb<Op, REV>(pre, t);
+        all = comb<Op, REV>(all, t);
+    }
+    __syncthreads();  // lds_totals may be reused by the caller
+    *total = all;
+    return comb<Op, REV>(pre, excl);
+}
+
+
+}  // namespace
+}  // namespace gecco

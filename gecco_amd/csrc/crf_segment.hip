@@ -2,170 +2,382 @@
 // reference's stateful grouper, edge trimming and the "gecco" validation criterion
 // (/root/reference/gecco/refine.py:51-64 GeneGrouper, :118-200 ClusterRefiner).
 //   * gene "in" <=> p > threshold (strict); NaN (no probability) inherits the previous gene's
-//     state -- and ONE grouper spans all contigs of a call (:186), so a contig that starts with
-//     NaN genes inherits the state the previous contigs ended in;
+//     state.  One grouper lives for one iter_clusters call (:186): the CLI makes one call per contig
+//     (cli/commands/_common.py:621-623; `carry` = 0: every contig starts "out"), a single call over
+//     many contigs lets a contig that starts with NaN genes inherit the state the previous contigs
+//     ended in (`carry` = 1);
 //   * every maximal "in" run of a contig is numbered from 1 before filtering; trimming drops
 //     un-annotated genes at both ends; kept iff #annotated >= n_cds and
 //     #(genes that are not edge genes) >= n_cds, edge genes being the first/last
 //     `edge_distance` annotated genes of the contig.
-// One lane per contig walks its genes (clusters are a few genes out of hundreds: the walk is
-// a coalescing-unfriendly but tiny stream of 9 B/gene); the cross-contig grouper state and the
-// output offsets are resolved by single-workgroup scans.
+//
+// Nothing here walks a contig: all genes of all contigs form ONE flat sequence (a 50 000-gene
+// contig is 25 workgroups, not one lane).  The grouper is a two-state transducer, so a span of genes
+// is summarised by what it does to either entering state -- the state it leaves, how many runs it
+// starts -- plus its number of annotated genes (SegE, crf_scan.hpp); spans compose associatively:
+//   seg_fold     a lane folds 8 genes for both entering states; wave scan by DPP, wave totals in LDS
+//   seg_top      one workgroup scans the per-workgroup totals (the only serial step: n/2048 elements)
+//   seg_replay   every lane re-walks its 8 genes from its now known entering state: writes the
+//                prefix count of annotated genes pre[] and, at run starts / ends, the raw run table
+//                (runs are dense and ordered: row = number of runs started before)
+//   seg_validate one lane per raw run: contig, cluster number, trimming and the annotated / edge
+//                counts by binary searches in pre[] (no walk over the run either)
+//   seg_kept_top + seg_compact   ordered compaction of the kept rows (+ gene offsets of the kept rows)
+// Bound: HBM, 2 x 10 B/gene read + 4 B/gene written; six short launches.
+#include <algorithm>
+
 #include "crf_device.hpp"
+#include "crf_scan.hpp"
 
 namespace gecco {
 namespace {
 
-constexpr int kT = 256;
+constexpr int kT = kScanThreads;
+constexpr int kGPL = 8;  // genes per lane
+constexpr int kBlockGenes = kT * kGPL;
+constexpr int kTopThreads = 1024;
 
-struct Walk {
-    const double *p;
-    const uint8_t *ann;
-    double thr;
-    int n_cds, edge, trim;
+struct SegOp {
+    static __device__ __forceinline__ SegE identity() { return SegE{2u, 0u, 0u, 0u}; }
+    static __device__ __forceinline__ SegE combine(const SegE &a, const SegE &b) {  // a earlier, b later
+        return SegE{MapOp::combine(b.map, a.map), a.ng0 + ((a.map & 1u) ? b.ng1 : b.ng0),
+                    a.ng1 + ((a.map & 2u) ? b.ng1 : b.ng0), a.ann + b.ann};
+    }
 };
-
-// walks contig [g0,g1) starting in grouper state `st`; calls emit(number, a, b) for kept clusters
-template <class Emit>
-__device__ __forceinline__ int walk_contig(const Walk &w, int g0, int g1, bool st, Emit emit) {
-    int n_ann = 0;
-    if (w.edge > 0)
-        for (int k = g0; k < g1; ++k) n_ann += w.ann[k] ? 1 : 0;
-    int kept = 0, number = 0, run_start = -1;
-    for (int g = g0; g <= g1; ++g) {
-        bool in = false;
-        if (g < g1) {
-            const double pv = w.p[g];
-            if (pv == pv) st = pv > w.thr;
-            in = st;
-        }
-        if (in && run_start < 0) run_start = g;
-        if (!in && run_start >= 0) {
-            ++number;
-            int a = run_start, b = g;
-            run_start = -1;
-            if (w.trim) {
-                while (a < b && !w.ann[a]) ++a;
-                while (b > a && !w.ann[b - 1]) --b;
-            }
-            int ann = 0, inner = 0, rank = 0;
-            if (w.edge > 0)
-                for (int k = g0; k < a; ++k) rank += w.ann[k] ? 1 : 0;
-            for (int k = a; k < b; ++k) {
-                bool is_edge = false;
-                if (w.ann[k]) {
-                    ++ann;
-                    if (w.edge > 0 && (rank < w.edge || rank >= n_ann - w.edge)) is_edge = true;
-                    ++rank;
-                }
-                if (!is_edge) ++inner;
-            }
-            if (ann >= w.n_cds && inner >= w.n_cds) {
-                emit(number, a, b, kept);
-                ++kept;
-            }
-        }
-    }
-    return kept;
+// The workgroup's 2048 probabilities arrive with coalesced 8-B loads and reach the lanes that own 8
+// consecutive ones through padded LDS rows (conflict-free both ways); the 8 annotation / contig
+// flags of a lane are one aligned 8-byte word each.
+struct Stage {
+    double st[kT * (kGPL + 1)];
+};
+struct LaneIn {
+    double p[kGPL];
+    uint64_t ann, fl;
+    int g0, cnt;
+};
+__device__ __forceinline__ uint64_t load_bytes8(const uint8_t *__restrict__ a, int g0, int n) {
+    if (g0 + kGPL <= n) return *reinterpret_cast<const uint64_t *>(a + g0);
+    uint64_t w = 0;
+    for (int k = 0; k < kGPL; ++k)
+        if (g0 + k < n) w |= uint64_t(a[g0 + k]) << (8 * k);
+    return w;
 }
-
-// per contig: index of itself if it holds any gene with a probability (else -1) and the
-// grouper state it leaves behind in that case
-__global__ void __launch_bounds__(kT) seg_contig_state(const double *__restrict__ p, const int32_t *__restrict__ cptr,
-                                                       int n_contigs, double thr, int32_t *__restrict__ last_valid,
-                                                       uint8_t *__restrict__ out_state) {
-    const int c = blockIdx.x * kT + threadIdx.x;
-    if (c >= n_contigs) return;
-    int lv = -1;
-    uint8_t st = 0;
-    for (int g = cptr[c + 1] - 1; g >= cptr[c]; --g) {
-        const double pv = p[g];
-        if (pv == pv) {
-            lv = c;
-            st = pv > thr;
-            break;
-        }
+__device__ __forceinline__ LaneIn load_lane(const SegArgs &A, Stage &stg) {
+    const int slot = threadIdx.x, base = blockIdx.x * kBlockGenes;
+#pragma unroll
+    for (int j = 0; j < kGPL; ++j) {
+        const int idx = j * kT + slot, g = base + idx;
+        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = g < A.n_genes ? A.p[g] : 0.0;
     }
-    last_valid[c] = lv;
-    out_state[c] = st;
-}
-
-// single workgroup: x[i] <- scan over i of op; MODE 0: inclusive running max (in place),
-// MODE 1: exclusive prefix sum (in place), total written to *total
-template <int MODE>
-__global__ void __launch_bounds__(1024) seg_scan(int32_t *x, int n, int32_t *total) {
-    __shared__ int32_t buf[1024];
-    __shared__ int32_t carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) carry = MODE == 0 ? -1 : 0;
+    LaneIn L;
+    L.g0 = base + slot * kGPL;
+    L.cnt = min(kGPL, A.n_genes - L.g0);
+    L.ann = load_bytes8(A.ann, L.g0, A.n_genes);
+    L.fl = load_bytes8(A.flags, L.g0, A.n_genes);
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const int32_t v = i < n ? x[i] : (MODE == 0 ? -1 : 0);
-        buf[tid] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int32_t t = buf[tid];
-            if (tid >= off) t = MODE == 0 ? max(t, buf[tid - off]) : t + buf[tid - off];
-            __syncthreads();
-            buf[tid] = t;
-            __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) L.p[k] = stg.st[slot * (kGPL + 1) + k];
+    return L;
+}
+
+// flags[g]: bit0 = first gene of a contig, bit1 = last gene (the layout of the plan's whole-contig tables)
+__global__ void __launch_bounds__(kT) seg_flags(const int32_t *__restrict__ cptr, int n_contigs, uint8_t *__restrict__ flags) {
+    const int c = blockIdx.x * kT + threadIdx.x;
+    if (c >= n_contigs) return;
+    const int g0 = cptr[c], g1 = cptr[c + 1];
+    if (g1 <= g0) return;
+    if (g1 - g0 == 1) {
+        flags[g0] = 3;
+    } else {
+        flags[g0] = 1;
+        flags[g1 - 1] = 2;
+    }
+}
+
+__global__ void __launch_bounds__(kT) seg_fold(const SegArgs A) {
+    __shared__ Stage stg;
+    __shared__ SegE lds[kT / 64];
+    const LaneIn L = load_lane(A, stg);
+    uint32_t st0 = 0, st1 = 1, ng0 = 0, ng1 = 0, ann = 0;
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        if (k < L.cnt) {
+            const bool first = (L.fl >> (8 * k)) & 1u;
+            const double pv = L.p[k];
+            const uint32_t p0 = first ? 0u : st0, p1 = first ? 0u : st1;  // a contig always opens a new run
+            if (first && !A.carry) st0 = st1 = 0u;
+            if (pv == pv) st0 = st1 = pv > A.thr ? 1u : 0u;
+            ng0 += st0 & ~p0;
+            ng1 += st1 & ~p1;
+            ann += ((L.ann >> (8 * k)) & 0xffu) ? 1u : 0u;
         }
-        const int32_t c = carry;
-        const int32_t incl = MODE == 0 ? max(buf[tid], c) : buf[tid] + c;
-        if (i < n) x[i] = MODE == 0 ? incl : incl - v;
+    }
+    SegE total;
+    const SegE excl = block_scan_exclusive<SegOp, false>(SegE{st0 | (st1 << 1), ng0, ng1, ann}, lds, &total);
+    A.lane[blockIdx.x * kT + threadIdx.x] = excl;
+    if (threadIdx.x == 0) A.block[blockIdx.x] = total;
+}
+
+// exclusive scan in place over the per-workgroup elements; the grand total gives the number of raw runs
+__global__ void __launch_bounds__(kTopThreads) seg_top(const SegArgs A, int nb) {
+    __shared__ SegE lds[kTopThreads / 64];
+    SegE carry = SegOp::identity();
+    for (int base = 0; base < nb; base += kTopThreads) {
+        const int i = base + threadIdx.x;
+        const SegE mine = i < nb ? A.block[i] : SegOp::identity();
+        SegE total;
+        const SegE excl = block_scan_exclusive<SegOp, false, SegE, kTopThreads>(mine, lds, &total);
+        if (i < nb) A.block[i] = SegOp::combine(carry, excl);
+        carry = SegOp::combine(carry, total);
+    }
+    if (threadIdx.x == 0) {
+        *A.n_raw = int32_t(carry.ng0);  // the batch is entered "out"
+        A.pre[A.n_genes] = int32_t(carry.ann);
+    }
+}
+
+__global__ void __launch_bounds__(kT) seg_replay(const SegArgs A) {
+    __shared__ Stage stg;
+    const LaneIn L = load_lane(A, stg);
+    if (L.cnt <= 0) return;
+    const SegE B = A.block[blockIdx.x], X = A.lane[blockIdx.x * kT + threadIdx.x];
+    const uint32_t sb = B.map & 1u;  // the batch is entered "out": evaluate every map at 0
+    uint32_t st = (X.map >> sb) & 1u;
+    uint32_t ng = B.ng0 + (sb ? X.ng1 : X.ng0);
+    uint32_t ann = B.ann + X.ann;
+    const bool need_next = L.cnt == kGPL && L.g0 + kGPL < A.n_genes;
+    const double p_next = need_next ? A.p[L.g0 + kGPL] : 0.0;
+    int32_t pre[kGPL];
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        pre[k] = int32_t(ann);
+        if (k < L.cnt) {
+            const uint32_t f = uint32_t(L.fl >> (8 * k)) & 0xffu;
+            const bool first = f & 1u, last = f & 2u;
+            const double pv = L.p[k];
+            const uint32_t prev = first ? 0u : st;
+            if (first && !A.carry) st = 0u;
+            if (pv == pv) st = pv > A.thr ? 1u : 0u;
+            if (st & ~prev) {
+                A.raw[ng].x = L.g0 + k;
+                ++ng;
+            }
+            if (st) {
+                bool ends = last;
+                if (!last) {  // the state the next gene of the contig will be in
+                    const double pn = k + 1 < kGPL ? L.p[k + 1 < kGPL ? k + 1 : k] : p_next;
+                    ends = pn == pn ? !(pn > A.thr) : false;
+                }
+                if (ends) A.raw[ng - 1].y = L.g0 + k + 1;
+            }
+            ann += ((L.ann >> (8 * k)) & 0xffu) ? 1u : 0u;
+        }
+    }
+    if (L.cnt == kGPL) {
+        int4 *dst = reinterpret_cast<int4 *>(A.pre + L.g0);
+        dst[0] = make_int4(pre[0], pre[1], pre[2], pre[3]);
+        dst[1] = make_int4(pre[4], pre[5], pre[6], pre[7]);
+    } else {
+        for (int k = 0; k < L.cnt; ++k) A.pre[L.g0 + k] = pre[k];
+    }
+}
+
+// smallest i in [lo, hi) with a[i] > v (hi if none)
+__device__ __forceinline__ int upper_bound_i32(const int32_t *__restrict__ a, int lo, int hi, int v) {
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (a[mid] > v) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(kT) seg_validate(const SegArgs A) {
+    const int n_raw = *A.n_raw;
+    const int ntile = (n_raw + kT - 1) / kT;
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int i = t * kT + threadIdx.x;
+        bool kept = false;
+        int len = 0;
+        if (i < n_raw) {
+            const int2 r = A.raw[i];
+            const int s = r.x, e = r.y;
+            // contig of the run: largest c with cptr[c] <= s (empty contigs never win: cptr[c+1] > s is required)
+            const int c = upper_bound_i32(A.cptr, 0, A.n_contigs + 1, s) - 1;
+            const int g0 = A.cptr[c], g1 = A.cptr[c + 1];
+            // cluster number = rank of the run among the runs of its contig (numbered before filtering)
+            int lo = 0, hi = i;  // smallest j with raw[j].x >= g0
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (A.raw[mid].x >= g0) hi = mid; else lo = mid + 1;
+            }
+            const int number = i - lo + 1;
+            int a = s, b = e;
+            const int pre_s = A.pre[s], pre_e = A.pre[e];
+            if (A.trim) {
+                if (pre_e == pre_s) {
+                    a = b = e;  // nothing annotated: the run trims to nothing
+                } else {
+                    a = upper_bound_i32(A.pre, s + 1, e + 1, pre_s) - 1;      // first annotated gene
+                    b = upper_bound_i32(A.pre, a + 1, e + 1, pre_e - 1);      // one past the last annotated gene
+                }
+            }
+            const int pa = A.pre[a], ann = A.pre[b] - pa;
+            int edge = 0;
+            if (A.edge > 0) {
+                const int n_ann = A.pre[g1] - A.pre[g0];
+                const int ra = pa - A.pre[g0], rb = ra + ann;  // ranks of the run's annotated genes
+                const int lo2 = max(A.edge, n_ann - A.edge);   // [0, edge) u [lo2, n_ann)
+                edge = max(0, min(rb, A.edge) - ra) + max(0, rb - max(ra, lo2));
+            }
+            kept = ann >= A.n_cds && (b - a) - edge >= A.n_cds;
+            len = b - a;
+            A.val[i] = make_int4(kept ? c : -1 - c, number, a, b);
+        }
+        const int cnt = __syncthreads_count(kept ? 1 : 0);
+        // genes of the kept rows of this tile: small numbers, an LDS atomic is plenty
+        __shared__ int genes;
+        if (threadIdx.x == 0) genes = 0;
         __syncthreads();
-        if (tid == 1023) carry = incl;
+        if (kept && len) atomicAdd(&genes, len);
+        __syncthreads();
+        if (threadIdx.x == 0) A.tile[t] = make_int2(cnt, genes);
         __syncthreads();
     }
-    if (MODE == 1 && tid == 0 && total) *total = carry;
 }
 
-__global__ void __launch_bounds__(kT) seg_count(const Walk w, const int32_t *__restrict__ cptr, int n_contigs,
-                                                const int32_t *__restrict__ last_valid, const uint8_t *__restrict__ out_state,
-                                                int32_t *__restrict__ cnt) {
-    const int c = blockIdx.x * kT + threadIdx.x;
-    if (c >= n_contigs) return;
-    const int src = c > 0 ? last_valid[c - 1] : -1;  // running max: nearest earlier contig with a value
-    const bool st = src >= 0 ? out_state[src] != 0 : false;
-    cnt[c] = walk_contig(w, cptr[c], cptr[c + 1], st, [](int, int, int, int) {});
+__global__ void __launch_bounds__(kTopThreads) seg_kept_top(const SegArgs A) {
+    __shared__ U2 lds[kTopThreads / 64];
+    const int n_raw = *A.n_raw;
+    const int ntile = (n_raw + kT - 1) / kT;
+    U2 carry{0u, 0u};
+    for (int base = 0; base < ntile; base += kTopThreads) {
+        const int i = base + threadIdx.x;
+        const int2 v = i < ntile ? A.tile[i] : make_int2(0, 0);
+        U2 total;
+        const U2 excl = block_scan_exclusive<AddOp, false, U2, kTopThreads>(U2{uint32_t(v.x), uint32_t(v.y)}, lds, &total);
+        if (i < ntile) A.tile[i] = make_int2(int(carry.x + excl.x), int(carry.y + excl.y));
+        carry = AddOp::combine(carry, total);
+    }
+    if (threadIdx.x == 0) {
+        *A.total = int32_t(carry.x);
+        if (A.seg_off && int(carry.x) <= A.max_seg) A.seg_off[carry.x] = int32_t(carry.y);
+    }
 }
 
-__global__ void __launch_bounds__(kT) seg_write(const Walk w, const int32_t *__restrict__ cptr, int n_contigs,
-                                                const int32_t *__restrict__ last_valid, const uint8_t *__restrict__ out_state,
-                                                const int32_t *__restrict__ off, int32_t *__restrict__ seg, int max_seg) {
-    const int c = blockIdx.x * kT + threadIdx.x;
-    if (c >= n_contigs) return;
-    const int src = c > 0 ? last_valid[c - 1] : -1;
-    const bool st = src >= 0 ? out_state[src] != 0 : false;
-    const int o = off[c];
-    walk_contig(w, cptr[c], cptr[c + 1], st, [&](int number, int a, int b, int k) {
-        if (o + k < max_seg) {
-            int32_t *r = seg + 4 * size_t(o + k);
-            r[0] = c;
-            r[1] = number;
-            r[2] = a;
-            r[3] = b;
+__global__ void __launch_bounds__(kT) seg_compact(const SegArgs A) {
+    __shared__ U2 lds[kT / 64];
+    const int n_raw = *A.n_raw;
+    const int ntile = (n_raw + kT - 1) / kT;
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int i = t * kT + threadIdx.x;
+        int4 v = make_int4(-1, 0, 0, 0);
+        if (i < n_raw) v = A.val[i];
+        const bool kept = v.x >= 0;
+        U2 total;
+        const U2 excl = block_scan_exclusive<AddOp, false>(U2{kept ? 1u : 0u, kept ? uint32_t(v.w - v.z) : 0u}, lds, &total);
+        if (kept) {
+            const int2 base = A.tile[t];
+            const int o = base.x + int(excl.x);
+            if (o < A.max_seg) {
+                reinterpret_cast<int4 *>(A.seg)[o] = v;
+                if (A.seg_off) A.seg_off[o] = base.y + int(excl.y);
+            }
         }
-    });
+    }
 }
+
+// probabilities of the genes of the kept rows, row after row (what cluster tables need of p)
+__global__ void __launch_bounds__(kT) seg_gather(const double *__restrict__ p, const int32_t *__restrict__ seg,
+                                                 const int32_t *__restrict__ seg_off, const int32_t *__restrict__ total,
+                                                 int max_seg, double *__restrict__ out, int cap) {
+    const int n = min(*total, max_seg);
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * kT + threadIdx.x) >> 6, nwaves = (gridDim.x * kT) >> 6;
+    for (int r = wave; r < n; r += nwaves) {
+        const int a = seg[4 * r + 2], b = seg[4 * r + 3], off = seg_off[r];
+        for (int k = lane; k < b - a; k += 64)
+            if (off + k < cap) out[off + k] = p[a + k];
+    }
+}
+
+inline size_t align256s(size_t x) { return (x + 255) & ~size_t(255); }
 
 }  // namespace
 
-// d_work: 3*n_contigs int32 + n_contigs bytes (+ 1 int32 total); all device pointers
-hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const int32_t *d_cptr, int n_contigs, double threshold,
-                          int n_cds, int edge_distance, int trim, int32_t *d_seg, int max_seg, int32_t *d_work,
-                          int32_t *d_total, hipStream_t stream) {
-    if (n_contigs <= 0) return hipMemsetAsync(d_total, 0, 4, stream);
-    int32_t *last_valid = d_work, *cnt = d_work + n_contigs;
-    uint8_t *out_state = reinterpret_cast<uint8_t *>(d_work + 2 * size_t(n_contigs));
-    const Walk w{d_p, d_ann, threshold, n_cds, edge_distance, trim};
-    const dim3 grid((n_contigs + kT - 1) / kT), block(kT);
-    hipLaunchKernelGGL(seg_contig_state, grid, block, 0, stream, d_p, d_cptr, n_contigs, threshold, last_valid, out_state);
-    hipLaunchKernelGGL(seg_scan<0>, dim3(1), dim3(1024), 0, stream, last_valid, n_contigs, (int32_t *)nullptr);
-    hipLaunchKernelGGL(seg_count, grid, block, 0, stream, w, d_cptr, n_contigs, last_valid, out_state, cnt);
-    hipLaunchKernelGGL(seg_scan<1>, dim3(1), dim3(1024), 0, stream, cnt, n_contigs, d_total);
-    hipLaunchKernelGGL(seg_write, grid, block, 0, stream, w, d_cptr, n_contigs, last_valid, out_state, cnt, d_seg, max_seg);
+size_t segment_raw_capacity(int n_genes, int n_contigs) {
+    // a run needs a gene, and two runs of one contig a gene between them
+    const size_t n = size_t(n_genes), k = size_t(n_contigs);
+    return std::min(n, n / 2 + k) + 1;
+}
+
+size_t segment_workspace_bytes(int n_genes, int n_contigs) {
+    const size_t n = size_t(n_genes), nb = (n + kBlockGenes - 1) / kBlockGenes, cap = segment_raw_capacity(n_genes, n_contigs);
+    return align256s(nb * kT * sizeof(SegE)) + align256s((nb + 1) * sizeof(SegE)) + align256s((n + 8) * 4) + align256s(cap * 8) +
+           align256s(cap * 16) + align256s((cap / kT + 2) * 8) + align256s(n + 8) + 256;
+}
+
+// All pointers are device pointers; `flags` may be null (built here from d_cptr into the workspace);
+// d_seg_off may be null.  d_total receives the number of kept rows (it may exceed max_seg: the rows
+// beyond are not written).
+hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t *d_flags, const int32_t *d_cptr,
+                          int n_genes, int n_contigs, double threshold, int n_cds, int edge_distance, int trim, int carry,
+                          int32_t *d_seg, int max_seg, int32_t *d_seg_off, int32_t *d_total, void *d_work,
+                          hipStream_t stream) {
+    if (n_contigs <= 0 || n_genes <= 0) {
+        if (d_seg_off) (void)hipMemsetAsync(d_seg_off, 0, 4, stream);
+        return hipMemsetAsync(d_total, 0, 4, stream);
+    }
+    const size_t n = size_t(n_genes), nb = (n + kBlockGenes - 1) / kBlockGenes, cap = segment_raw_capacity(n_genes, n_contigs);
+    char *w = static_cast<char *>(d_work);
+    SegArgs a{};
+    a.p = d_p;
+    a.ann = d_ann;
+    a.cptr = d_cptr;
+    a.n_genes = n_genes;
+    a.n_contigs = n_contigs;
+    a.thr = threshold;
+    a.n_cds = n_cds;
+    a.edge = edge_distance;
+    a.trim = trim;
+    a.carry = carry;
+    a.lane = reinterpret_cast<SegE *>(w);
+    w += align256s(nb * kT * sizeof(SegE));
+    a.block = reinterpret_cast<SegE *>(w);
+    w += align256s((nb + 1) * sizeof(SegE));
+    a.pre = reinterpret_cast<int32_t *>(w);
+    w += align256s((n + 8) * 4);
+    a.raw = reinterpret_cast<int2 *>(w);
+    w += align256s(cap * 8);
+    a.val = reinterpret_cast<int4 *>(w);
+    w += align256s(cap * 16);
+    a.tile = reinterpret_cast<int2 *>(w);
+    w += align256s((cap / kT + 2) * 8);
+    uint8_t *own_flags = reinterpret_cast<uint8_t *>(w);
+    w += align256s(n + 8);
+    a.n_raw = reinterpret_cast<int32_t *>(w);
+    a.seg = d_seg;
+    a.max_seg = max_seg;
+    a.seg_off = d_seg_off;
+    a.total = d_total;
+    if (!d_flags) {
+        hipError_t e = hipMemsetAsync(own_flags, 0, n + 8, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(seg_flags, dim3((n_contigs + kT - 1) / kT), dim3(kT), 0, stream, d_cptr, n_contigs, own_flags);
+        d_flags = own_flags;
+    }
+    a.flags = d_flags;
+    const int tiles_cap = int(std::min<size_t>(cap / kT + 1, 2048));
+    hipLaunchKernelGGL(seg_fold, dim3(nb), dim3(kT), 0, stream, a);
+    hipLaunchKernelGGL(seg_top, dim3(1), dim3(kTopThreads), 0, stream, a, int(nb));
+    hipLaunchKernelGGL(seg_replay, dim3(nb), dim3(kT), 0, stream, a);
+    hipLaunchKernelGGL(seg_validate, dim3(tiles_cap), dim3(kT), 0, stream, a);
+    hipLaunchKernelGGL(seg_kept_top, dim3(1), dim3(kTopThreads), 0, stream, a);
+    hipLaunchKernelGGL(seg_compact, dim3(tiles_cap), dim3(kT), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_segment_gather(const double *d_p, const int32_t *d_seg, const int32_t *d_seg_off, const int32_t *d_total,
+                                 int max_seg, double *d_out, int cap, hipStream_t stream) {
+    hipLaunchKernelGGL(seg_gather, dim3(64), dim3(kT), 0, stream, d_p, d_seg, d_seg_off, d_total, max_seg, d_out, cap);
     return hipGetLastError();
 }
 

@@ -21,6 +21,7 @@
 // composed elements, i.e. they equal the strictly sequential values whenever the additions are
 // exact (integer-valued weights: ties and first-argmax included) and to rounding otherwise.
 #include "crf_device.hpp"
+#include "crf_scan.hpp"
 
 namespace gecco {
 namespace {
@@ -77,15 +78,6 @@ struct FOpB {
         return c;
     }
 };
-struct MapOp {  // maps {0,1}->{0,1} packed in 2 bits: bit x = image of x
-    static __device__ __forceinline__ uint32_t identity() { return 2u; }
-    // result(x) = a(b(x)): b is applied first.  In the backward label scans the element closer
-    // to the END of the sequence acts first.
-    static __device__ __forceinline__ uint32_t combine(uint32_t a, uint32_t b) {
-        return ((a >> (b & 1u)) & 1u) | (((a >> ((b >> 1) & 1u)) & 1u) << 1);
-    }
-};
-
 // Difference form of the 2-label Viterbi recursion.  With Delta = delta[1] - delta[0] and d = s[1] - s[0],
 //   Delta_t = clamp(Delta_{t-1}, lo, hi) + (t11 - t00) + d_t,   lo = t01 - t11,  hi = t00 - t10  (lo <= hi),
 // the back-pointers of gene t are (Delta_{t-1} > hi, Delta_{t-1} > lo) and the end label is Delta_T > 0
@@ -100,75 +92,6 @@ struct COp {
         return CE{a.a + b.a, fmin(fmax(a.L + b.a, b.L), b.H), fmin(fmax(a.H + b.a, b.L), b.H)};
     }
 };
-
-// ---------------------------------------------------------------- DPP plumbing
-template <int CTRL, int RM>
-__device__ __forceinline__ double dpp_f64(double old, double src) {
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, RM, 0xF, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, RM, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL, int RM>
-__device__ __forceinline__ VE dpp_elem(const VE &old, const VE &s) {
-    return VE{dpp_f64<CTRL, RM>(old.a00, s.a00), dpp_f64<CTRL, RM>(old.a01, s.a01), dpp_f64<CTRL, RM>(old.a10, s.a10),
-              dpp_f64<CTRL, RM>(old.a11, s.a11), dpp_f64<CTRL, RM>(old.rs, s.rs)};
-}
-template <int CTRL, int RM>
-__device__ __forceinline__ FE dpp_elem(const FE &old, const FE &s) {
-    return FE{dpp_f64<CTRL, RM>(old.a00, s.a00), dpp_f64<CTRL, RM>(old.a01, s.a01), dpp_f64<CTRL, RM>(old.a10, s.a10),
-              dpp_f64<CTRL, RM>(old.a11, s.a11), dpp_f64<CTRL, RM>(old.ex, s.ex),   dpp_f64<CTRL, RM>(old.ms, s.ms),
-              dpp_f64<CTRL, RM>(old.rs, s.rs)};
-}
-template <int CTRL, int RM>
-__device__ __forceinline__ CE dpp_elem(const CE &old, const CE &s) {
-    return CE{dpp_f64<CTRL, RM>(old.a, s.a), dpp_f64<CTRL, RM>(old.L, s.L), dpp_f64<CTRL, RM>(old.H, s.H)};
-}
-template <int CTRL, int RM>
-__device__ __forceinline__ uint32_t dpp_elem(const uint32_t &old, const uint32_t &s) {
-    return uint32_t(__builtin_amdgcn_update_dpp(int(old), int(s), CTRL, RM, 0xF, false));
-}
-
-// REV = false: out[l] = e[0] (x) e[1] (x) ... (x) e[l]   (lane order = sequence order)
-// REV = true : out[l] = e[l] (x) e[l-1] (x) ... (x) e[0]  (lanes hold the sequence back to front)
-template <class Op, bool REV, class E>
-__device__ __forceinline__ E comb(const E &earlier_lane, const E &later_lane) {
-    return REV ? Op::combine(later_lane, earlier_lane) : Op::combine(earlier_lane, later_lane);
-}
-template <class Op, bool REV, class E>
-__device__ __forceinline__ E wave_scan_inclusive(E v) {
-    const E id = Op::identity();
-    v = comb<Op, REV>(dpp_elem<0x111, 0xF>(id, v), v);  // row_shr:1
-    v = comb<Op, REV>(dpp_elem<0x112, 0xF>(id, v), v);  // row_shr:2
-    v = comb<Op, REV>(dpp_elem<0x114, 0xF>(id, v), v);  // row_shr:4
-    v = comb<Op, REV>(dpp_elem<0x118, 0xF>(id, v), v);  // row_shr:8
-    v = comb<Op, REV>(dpp_elem<0x142, 0xA>(id, v), v);  // row_bcast:15 -> rows 1,3
-    v = comb<Op, REV>(dpp_elem<0x143, 0xC>(id, v), v);  // row_bcast:31 -> rows 2,3
-    return v;
-}
-template <class E>
-__device__ __forceinline__ E wave_shift_up(const E &id, const E &v) {  // lane l <- lane l-1, lane 0 <- id
-    return dpp_elem<0x138, 0xF>(id, v);                                 // wave_shr:1
-}
-// Workgroup-wide EXCLUSIVE scan of one element per lane (kT lanes); *total = product of all.
-template <class Op, bool REV, class E, int NTH = kT>
-__device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /* NTH/64 */, E *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const E id = Op::identity();
-    const E incl = wave_scan_inclusive<Op, REV>(mine);
-    if (lane == 63) lds_totals[wave] = incl;
-    E excl = wave_shift_up(id, incl);
-    __syncthreads();
-    E pre = id, all = id;
-#pragma unroll
-    for (int w = 0; w < NTH / 64; ++w) {
-        const E t = lds_totals[w];
-        if (w < wave) pre = comb<Op, REV>(pre, t);
-        all = comb<Op, REV>(all, t);
-    }
-    __syncthreads();  // lds_totals may be reused by the caller
-    *total = all;
-    return comb<Op, REV>(pre, excl);
-}
 
 // Look-back over per-workgroup totals instead of a separate scan launch: the exclusive prefix of
 // workgroup b is total[j] (x) ... (x) total[b-1] from the nearest workgroup j whose span contains a
@@ -263,7 +186,7 @@ __device__ __forceinline__ FE lookahead_suffix(const FE *__restrict__ totals, in
 // ---------------------------------------------------------------- row S: state scores
 __global__ void __launch_bounds__(kT) seq_state_scores(const int32_t *__restrict__ gene_ptr,
                                                        const int32_t *__restrict__ attr_id,
-                                                       const double2 *__restrict__ wtab01, int n_genes,
+                                                       const double2 *__restrict__ wtab01, int n_attrs, int n_genes,
                                                        double2 *__restrict__ state) {
     const int g = blockIdx.x * kT + threadIdx.x;
     if (g >= n_genes) return;
@@ -275,7 +198,7 @@ __global__ void __launch_bounds__(kT) seq_state_scores(const int32_t *__restrict
         for (int u = 0; u < 4; ++u) a[u] = base + u < hi ? attr_id[base + u] : -1;
         double2 w[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = a[u] >= 0 ? wtab01[a[u]] : make_double2(0.0, 0.0);
+        for (int u = 0; u < 4; ++u) w[u] = unsigned(a[u]) < unsigned(n_attrs) ? wtab01[a[u]] : make_double2(0.0, 0.0);  // unknown ids: no weight
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             s0 += w[u].x;
@@ -287,7 +210,7 @@ __global__ void __launch_bounds__(kT) seq_state_scores(const int32_t *__restrict
 
 __global__ void __launch_bounds__(kT) seq_state_delta(const int32_t *__restrict__ gene_ptr,
                                                        const int32_t *__restrict__ attr_id,
-                                                       const double2 *__restrict__ wtab01, int n_genes,
+                                                       const double2 *__restrict__ wtab01, int n_attrs, int n_genes,
                                                        double *__restrict__ dstate) {
     const int g = blockIdx.x * kT + threadIdx.x;
     if (g >= n_genes) return;
@@ -299,7 +222,7 @@ __global__ void __launch_bounds__(kT) seq_state_delta(const int32_t *__restrict_
         for (int u = 0; u < 4; ++u) a[u] = base + u < hi ? attr_id[base + u] : -1;
         double2 w[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = a[u] >= 0 ? wtab01[a[u]] : make_double2(0.0, 0.0);
+        for (int u = 0; u < 4; ++u) w[u] = unsigned(a[u]) < unsigned(n_attrs) ? wtab01[a[u]] : make_double2(0.0, 0.0);  // unknown ids: no weight
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             s0 += w[u].x;
@@ -866,10 +789,10 @@ __global__ void __launch_bounds__(kT) f_lognorm(const SeqArgs A, const int32_t *
 // ---- launchers ---------------------------------------------------------------------------
 static inline dim3 grid_for(int n, int per) { return dim3((n + per - 1) / per); }
 
-hipError_t launch_seq_state(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_genes,
+hipError_t launch_seq_state(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_attrs, int n_genes,
                             double2 *state, hipStream_t stream) {
     if (n_genes <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seq_state_scores, grid_for(n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_genes, state);
+    hipLaunchKernelGGL(seq_state_scores, grid_for(n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_attrs, n_genes, state);
     return hipGetLastError();
 }
 
@@ -898,10 +821,10 @@ hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_seq_state_delta(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_genes,
+hipError_t launch_seq_state_delta(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_attrs, int n_genes,
                                   double *dstate, hipStream_t stream) {
     if (n_genes <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seq_state_delta, grid_for(n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_genes, dstate);
+    hipLaunchKernelGGL(seq_state_delta, grid_for(n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_attrs, n_genes, dstate);
     return hipGetLastError();
 }
 

@@ -1,0 +1,488 @@
+#include "crf_session.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+
+#include "../../include/gecco_crf.h"
+
+namespace gecco {
+namespace {
+
+constexpr int kLanes = 3;  // upload of chunk k+1, compute of k, download of k-1
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct DevBuf {  // grow-only device block
+    char *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes, const char *what) {
+        if (p && bytes <= cap) return GECCO_CRF_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        int rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p), want), what);
+        if (!rc) cap = want;
+        return rc;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct HostBuf {  // grow-only pinned, device-visible host block: kernels write the (few) segment rows straight into it
+    char *p = nullptr, *dp = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes, const char *what) {
+        if (p && bytes <= cap) return GECCO_CRF_OK;
+        release();
+        const size_t want = bytes + bytes / 8 + 256;
+        int rc = check_hip(hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocMapped | hipHostMallocPortable), what);
+        if (rc) return rc;
+        if ((rc = check_hip(hipHostGetDevicePointer(reinterpret_cast<void **>(&dp), p, 0), what))) {
+            (void)hipHostFree(p);
+            p = nullptr;
+            return rc;
+        }
+        cap = want;
+        return GECCO_CRF_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = dp = nullptr;
+        cap = 0;
+    }
+};
+
+struct Chunk {
+    int32_t c0 = 0, c1 = 0;  // contigs
+    int32_t g0 = 0, g1 = 0;  // genes
+    int32_t device_slot = 0;
+    // segment rows of the chunk, translated to batch indices, and the probabilities of their genes
+    std::vector<int32_t> rows;
+    std::vector<double> seg_p;
+};
+
+struct Lane {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    int chunk = -1;  // index of the chunk in flight, -1: idle
+    Plan plan;
+    DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm;
+    HostBuf h_seg;  // [total][pad..][seg_off: cap+1][rows: cap*4][p of the rows: n_genes]
+    int32_t seg_cap = 0;
+    size_t o_off = 0, o_rows = 0, o_p = 0;
+};
+
+struct DeviceCtx {
+    int device = -1;
+    Lane lanes[kLanes];
+    int next_lane = 0;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+}  // namespace
+
+struct Session {
+    const Model *model = nullptr;
+    std::vector<std::unique_ptr<DeviceCtx>> devs;
+    int32_t chunk_genes = 1 << 19;
+    std::mutex mu;  // one batch at a time per session
+    SessionStats stats;
+    ~Session();
+};
+
+Session::~Session() {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    for (auto &d : devs) {
+        if (hipSetDevice(d->device) != hipSuccess) continue;
+        for (Lane &ln : d->lanes) {
+            if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm}) b->release();
+            ln.h_seg.release();
+            if (ln.done) (void)hipEventDestroy(ln.done);
+            if (ln.stream) (void)hipStreamDestroy(ln.stream);
+        }
+    }
+    devs.clear();  // plans free their blocks under their own device guard
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+int session_create(const Model &m, const int32_t *devices, int32_t n_devices, Session **out) {
+    if (!out || n_devices <= 0 || !devices) {
+        set_error("session: no devices given");
+        return GECCO_CRF_EINVAL;
+    }
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_error("no HIP device available (this library has no CPU fallback)");
+        return GECCO_CRF_ENODEV;
+    }
+    std::unique_ptr<Session> s(new Session());
+    s->model = &m;
+    if (const char *env = std::getenv("GECCO_CRF_CHUNK_GENES")) {
+        const long v = std::atol(env);
+        if (v >= 1024) s->chunk_genes = int32_t(std::min<long>(v, 1 << 28));
+    }
+    for (int32_t i = 0; i < n_devices; ++i) {
+        if (devices[i] < 0 || devices[i] >= count) {
+            set_error("device index out of range");
+            return GECCO_CRF_ENODEV;
+        }
+        for (int32_t j = 0; j < i; ++j)
+            if (devices[j] == devices[i]) {
+                set_error("session: a device is listed twice");
+                return GECCO_CRF_EINVAL;
+            }
+        int rc = check_hip(hipSetDevice(devices[i]), "hipSetDevice");
+        if (rc) return rc;
+        std::unique_ptr<DeviceCtx> d(new DeviceCtx());
+        d->device = devices[i];
+        for (Lane &ln : d->lanes) {
+            ln.device = devices[i];
+            ln.plan.async_tables = true;
+            if ((rc = check_hip(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
+            if ((rc = check_hip(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming), "hipEventCreate"))) return rc;
+        }
+        s->devs.push_back(std::move(d));
+    }
+    *out = s.release();
+    return GECCO_CRF_OK;
+}
+
+void session_destroy(Session *s) { delete s; }
+void session_set_chunk_genes(Session &s, int32_t genes) {
+    std::lock_guard<std::mutex> lock(s.mu);
+    s.chunk_genes = std::max(1024, genes);
+}
+SessionStats session_stats(const Session &s) { return s.stats; }
+
+namespace {
+
+// Cut the batch into chunks of about `target` genes at contig boundaries (a contig is never split:
+// its windows overlap).  With several devices there are at least two chunks per device when the
+// batch is large enough to make that worthwhile.
+void cut_chunks(const BatchRequest &r, int32_t target, int n_devices, std::vector<Chunk> &chunks) {
+    chunks.clear();
+    const int32_t nc = r.n_contigs;
+    if (nc <= 0) return;
+    const int64_t n = int64_t(r.contig_ptr[nc]) - r.contig_ptr[0];
+    int64_t want = std::max<int64_t>(1, (n + target / 2) / target);
+    if (n_devices > 1) want = std::max<int64_t>(want, std::min<int64_t>(2 * n_devices, std::max<int64_t>(1, n / 65536)));
+    want = std::min<int64_t>(want, nc);
+    const double per = double(n) / double(want);
+    int32_t c = 0;
+    for (int64_t k = 0; k < want && c < nc; ++k) {
+        Chunk ck;
+        ck.c0 = c;
+        const int64_t goal = r.contig_ptr[0] + int64_t(per * double(k + 1) + 0.5);
+        if (k == want - 1) {
+            c = nc;
+        } else {
+            // first contig boundary at or past the goal, leaving at least one contig per remaining chunk
+            const int32_t *e = std::lower_bound(r.contig_ptr + c + 1, r.contig_ptr + nc, int32_t(std::min<int64_t>(goal, INT32_MAX)));
+            c = int32_t(e - r.contig_ptr);
+            c = std::min<int32_t>(c, nc - int32_t(want - 1 - k));
+            c = std::max<int32_t>(c, ck.c0 + 1);
+        }
+        ck.c1 = c;
+        ck.g0 = r.contig_ptr[ck.c0];
+        ck.g1 = r.contig_ptr[ck.c1];
+        chunks.push_back(std::move(ck));
+    }
+}
+
+// Chunks to devices, longest first onto the least loaded device (the greedy partition of SURVEY.md
+// 8e / gecco_amd/sharding.py, at chunk granularity: every chunk is a contiguous slice of the caller's
+// arrays, so nothing is gathered on the host).
+void deal_chunks(std::vector<Chunk> &chunks, int n_devices) {
+    std::vector<int> order(chunks.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return (chunks[a].g1 - chunks[a].g0) > (chunks[b].g1 - chunks[b].g0);
+    });
+    std::vector<int64_t> load(size_t(n_devices), 0);
+    for (int i : order) {
+        const int d = int(std::min_element(load.begin(), load.end()) - load.begin());
+        chunks[i].device_slot = d;
+        load[d] += chunks[i].g1 - chunks[i].g0;
+    }
+}
+
+struct RunCtx {
+    Session &S;
+    const BatchRequest &r;
+    std::vector<Chunk> &chunks;
+    bool windowed, viterbi, full;
+    int32_t W, step, pad;
+};
+
+int submit(RunCtx &X, Lane &ln, int chunk_index) {
+    Session &S = X.S;
+    const BatchRequest &r = X.r;
+    Chunk &ck = X.chunks[chunk_index];
+    const Model &m = *S.model;
+    int rc = check_hip(hipSetDevice(ln.device), "hipSetDevice");
+    if (rc) return rc;
+    const int32_t nc = ck.c1 - ck.c0, ng = ck.g1 - ck.g0;
+    const double t0 = now_s();
+    if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.stream, false))) return rc;
+    if ((X.viterbi || X.full || r.want_segments) && (rc = plan_ensure_seq(ln.plan, ln.stream, false))) return rc;
+    S.stats.host_plan_seconds += now_s() - t0;
+    ln.chunk = chunk_index;
+    if (ng == 0) return check_hip(hipEventRecord(ln.done, ln.stream), "hipEventRecord");
+    const int64_t a0 = r.gene_ptr[ck.g0], a1 = r.gene_ptr[ck.g1];
+    if (a0 < 0 || a1 < a0) {
+        set_error("gene_ptr must be non-decreasing and start at a non-negative offset");
+        return GECCO_CRF_EINVAL;
+    }
+    const size_t nnz = size_t(a1 - a0), L = size_t(m.L);
+    if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
+    if ((rc = ln.d_at.reserve((nnz + 4) * 4, "hipMalloc attr_id"))) return rc;
+    if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.g0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.stream), "H2D gene_ptr")))
+        return rc;
+    if (nnz && (rc = check_hip(hipMemcpyAsync(ln.d_at.p, r.attr_id + a0, nnz * 4, hipMemcpyHostToDevice, ln.stream), "H2D attr_id")))
+        return rc;
+    S.stats.h2d_bytes += int64_t((size_t(ng) + 1 + nnz) * 4);
+    // gene_ptr keeps the caller's offsets: the attribute array is addressed from where its element 0 would be
+    const int32_t *d_gp = reinterpret_cast<const int32_t *>(ln.d_gp.p);
+    const int32_t *d_at = reinterpret_cast<const int32_t *>(ln.d_at.p) - a0;
+    double *d_p = nullptr, *d_score = nullptr;
+    int8_t *d_y = nullptr;
+    if (X.windowed) {
+        if ((rc = ln.d_p.reserve(size_t(ng) * 8, "hipMalloc p"))) return rc;
+        d_p = reinterpret_cast<double *>(ln.d_p.p);
+    }
+    if (X.viterbi) {
+        if ((rc = ln.d_y.reserve(size_t(ng) + 8, "hipMalloc labels"))) return rc;
+        d_y = reinterpret_cast<int8_t *>(ln.d_y.p);
+        if (r.score_out) {
+            if ((rc = ln.d_score.reserve(size_t(nc) * 8, "hipMalloc scores"))) return rc;
+            d_score = reinterpret_cast<double *>(ln.d_score.p);
+        }
+    }
+    if (X.windowed && X.viterbi) {
+        rc = plan_run_decode(ln.plan, d_gp, d_at, r.label, d_p, d_y, d_score, ln.stream);
+    } else if (X.windowed) {
+        rc = plan_run_windowed(ln.plan, d_gp, d_at, r.label, d_p, ln.stream);
+    } else if (X.viterbi) {
+        rc = plan_run_viterbi(ln.plan, d_gp, d_at, d_y, d_score, ln.stream);
+    }
+    if (rc) return rc;
+    if (X.full) {
+        if ((rc = ln.d_marg.reserve(size_t(ng) * L * 8, "hipMalloc marginals"))) return rc;
+        if ((rc = ln.d_lognorm.reserve(size_t(nc) * 8, "hipMalloc lognorm"))) return rc;
+        if ((rc = plan_run_marginals_full(ln.plan, d_gp, d_at, reinterpret_cast<double *>(ln.d_marg.p),
+                                          reinterpret_cast<double *>(ln.d_lognorm.p), ln.stream)))
+            return rc;
+    }
+    if (r.want_segments) {
+        // rows, their offsets and the probabilities of their genes are written by the kernels into pinned
+        // host memory: nothing but those few bytes crosses PCIe for a cluster call
+        const size_t cap = std::min<size_t>(size_t(ng), size_t(ng) / 2 + size_t(nc)) + 1;
+        ln.seg_cap = int32_t(cap);
+        ln.o_off = 256;
+        ln.o_rows = ln.o_off + align256((cap + 1) * 4);
+        ln.o_p = ln.o_rows + align256(cap * 16);
+        const size_t bytes = ln.o_p + (r.seg_p_out ? size_t(ng) * 8 : 0) + 256;
+        if ((rc = ln.h_seg.reserve(bytes, "hipHostMalloc segments"))) return rc;
+        if ((rc = ln.d_ann.reserve(size_t(ng) + 8, "hipMalloc annotated"))) return rc;
+        if ((rc = check_hip(hipMemcpyAsync(ln.d_ann.p, r.annotated + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.stream), "H2D annotated")))
+            return rc;
+        S.stats.h2d_bytes += ng;
+        char *dp = ln.h_seg.dp;
+        int32_t *d_total = reinterpret_cast<int32_t *>(dp), *d_off = reinterpret_cast<int32_t *>(dp + ln.o_off),
+                *d_rows = reinterpret_cast<int32_t *>(dp + ln.o_rows);
+        if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(ln.d_ann.p), r.threshold, r.n_cds, r.edge_distance,
+                                   r.trim, 0, d_rows, int32_t(cap), d_off, d_total, ln.stream)))
+            return rc;
+        if (r.seg_p_out &&
+            (rc = check_hip(launch_segment_gather(d_p, d_rows, d_off, d_total, int32_t(cap), reinterpret_cast<double *>(dp + ln.o_p), ng,
+                                                  ln.stream), "segment gather launch")))
+            return rc;
+    }
+    auto d2h = [&](void *dst, const void *src, size_t bytes, const char *what) {
+        S.stats.d2h_bytes += int64_t(bytes);
+        return bytes ? check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ln.stream), what) : GECCO_CRF_OK;
+    };
+    if (r.p_out && (rc = d2h(r.p_out + ck.g0, d_p, size_t(ng) * 8, "D2H p"))) return rc;
+    if (r.y_out && (rc = d2h(r.y_out + ck.g0, d_y, size_t(ng), "D2H labels"))) return rc;
+    if (r.score_out && (rc = d2h(r.score_out + ck.c0, d_score, size_t(nc) * 8, "D2H scores"))) return rc;
+    if (r.marg_out && (rc = d2h(r.marg_out + size_t(ck.g0) * L, ln.d_marg.p, size_t(ng) * L * 8, "D2H marginals"))) return rc;
+    if (r.lognorm_out && (rc = d2h(r.lognorm_out + ck.c0, ln.d_lognorm.p, size_t(nc) * 8, "D2H lognorm"))) return rc;
+    return check_hip(hipEventRecord(ln.done, ln.stream), "hipEventRecord");
+}
+
+// wait for the lane's chunk and take its segment rows over (translated to batch indices)
+int retire(RunCtx &X, Lane &ln) {
+    if (ln.chunk < 0) return GECCO_CRF_OK;
+    int rc = check_hip(hipEventSynchronize(ln.done), "chunk completion");
+    Chunk &ck = X.chunks[ln.chunk];
+    ln.chunk = -1;
+    if (rc) return rc;
+    if (X.r.want_segments && ck.g1 > ck.g0) {
+        const char *hp = ln.h_seg.p;
+        const int32_t total = *reinterpret_cast<const int32_t *>(hp);
+        if (total < 0 || total > ln.seg_cap) {
+            set_error("segmenter returned an impossible row count");
+            return GECCO_CRF_EHIP;
+        }
+        const int32_t *rows = reinterpret_cast<const int32_t *>(hp + ln.o_rows), *off = reinterpret_cast<const int32_t *>(hp + ln.o_off);
+        ck.rows.resize(size_t(total) * 4);
+        for (int32_t i = 0; i < total; ++i) {
+            ck.rows[4 * size_t(i) + 0] = rows[4 * i + 0] + ck.c0;
+            ck.rows[4 * size_t(i) + 1] = rows[4 * i + 1];
+            ck.rows[4 * size_t(i) + 2] = rows[4 * i + 2] + ck.g0;
+            ck.rows[4 * size_t(i) + 3] = rows[4 * i + 3] + ck.g0;
+        }
+        if (X.r.seg_p_out) {
+            const double *sp = reinterpret_cast<const double *>(hp + ln.o_p);
+            ck.seg_p.assign(sp, sp + off[total]);
+        }
+    }
+    return GECCO_CRF_OK;
+}
+
+}  // namespace
+
+int session_run(Session &S, const BatchRequest &r) {
+    const Model &m = *S.model;
+    const bool windowed = r.p_out || r.want_segments, viterbi = r.y_out != nullptr,
+               full = r.marg_out != nullptr || r.lognorm_out != nullptr;
+    // argument errors first, so that they surface even on a box without a GPU (texts: gecco/_meta.py:127-130)
+    if (windowed) {
+        if (r.window <= 0) {
+            set_error("Window size must be strictly positive");
+            return GECCO_CRF_EINVAL;
+        }
+        if (r.step <= 0 || r.step > r.window) {
+            set_error("Window step must be strictly positive and under `window_size`");
+            return GECCO_CRF_EINVAL;
+        }
+        if (r.label < 0 || r.label >= m.L) {
+            set_error("label out of range");
+            return GECCO_CRF_EINVAL;
+        }
+    }
+    if (r.n_contigs < 0 || (r.n_contigs > 0 && !r.contig_ptr)) {
+        set_error("bad contig_ptr");
+        return GECCO_CRF_EINVAL;
+    }
+    if (r.n_contigs > 0 && r.contig_ptr[0] != 0) {
+        set_error("contig_ptr[0] must be 0");
+        return GECCO_CRF_EINVAL;
+    }
+    if (r.score_out && !viterbi) {
+        set_error("path scores come with the labels: y_out is required");
+        return GECCO_CRF_EINVAL;
+    }
+    if (r.want_segments && (!r.n_seg || r.max_seg < 0 || (r.max_seg > 0 && !r.seg_out) || (r.seg_p_out && !r.seg_off_out))) {
+        set_error("segments: bad output arguments");
+        return GECCO_CRF_EINVAL;
+    }
+    if (r.n_seg) *r.n_seg = 0;
+    for (int32_t c = 0; c < r.n_contigs; ++c)
+        if (r.contig_ptr[c + 1] < r.contig_ptr[c]) {
+            set_error("contig_ptr must be non-decreasing");
+            return GECCO_CRF_EINVAL;
+        }
+    const int64_t n_genes = r.n_contigs ? r.contig_ptr[r.n_contigs] : 0;
+    if (n_genes > 0 && (!r.gene_ptr || (r.want_segments && !r.annotated))) {
+        set_error("null buffer");
+        return GECCO_CRF_EINVAL;
+    }
+    if (n_genes > 0 && r.gene_ptr[n_genes] > r.gene_ptr[0] && !r.attr_id) {
+        set_error("null buffer");
+        return GECCO_CRF_EINVAL;
+    }
+    std::lock_guard<std::mutex> lock(S.mu);
+    const double t_start = now_s();
+    S.stats = SessionStats{};
+    S.stats.n_devices = int32_t(S.devs.size());
+    if (r.seg_off_out) r.seg_off_out[0] = 0;
+    if (!windowed && !viterbi && !full) return GECCO_CRF_OK;
+    int prev_device = -1;
+    if (hipGetDevice(&prev_device) != hipSuccess) prev_device = -1;
+
+    std::vector<Chunk> chunks;
+    cut_chunks(r, S.chunk_genes, int(S.devs.size()), chunks);
+    deal_chunks(chunks, int(S.devs.size()));
+    S.stats.n_chunks = int32_t(chunks.size());
+    RunCtx X{S, r, chunks, windowed, viterbi, full, windowed ? r.window : 1, windowed ? r.step : 1, windowed ? r.pad : 1};
+
+    // per-device queues in batch order; devices are fed round-robin so that all of them start at once
+    std::vector<std::vector<int>> queue(S.devs.size());
+    for (size_t i = 0; i < chunks.size(); ++i) queue[size_t(chunks[i].device_slot)].push_back(int(i));
+    std::vector<size_t> head(S.devs.size(), 0);
+    int rc = GECCO_CRF_OK;
+    for (bool any = true; any && !rc;) {
+        any = false;
+        for (size_t d = 0; d < S.devs.size() && !rc; ++d) {
+            if (head[d] >= queue[d].size()) continue;
+            any = true;
+            DeviceCtx &D = *S.devs[d];
+            Lane &ln = D.lanes[D.next_lane];
+            D.next_lane = (D.next_lane + 1) % kLanes;
+            if ((rc = retire(X, ln))) break;
+            rc = submit(X, ln, queue[d][head[d]++]);
+        }
+    }
+    // drain (also after an error: nothing of this call may still be in flight when it returns)
+    for (auto &d : S.devs)
+        for (Lane &ln : d->lanes) {
+            if (rc) {  // the failed submission may have left work behind an unrecorded event
+                if (hipSetDevice(ln.device) == hipSuccess) (void)hipStreamSynchronize(ln.stream);
+                ln.chunk = -1;
+                continue;
+            }
+            rc = retire(X, ln);
+        }
+    if (prev_device >= 0) (void)hipSetDevice(prev_device);
+    if (rc) return rc;
+
+    if (r.want_segments) {
+        int64_t total = 0, genes = 0;
+        for (const Chunk &ck : chunks) total += int64_t(ck.rows.size() / 4);
+        *r.n_seg = int32_t(std::min<int64_t>(total, INT32_MAX));
+        if (total > r.max_seg) {
+            set_error("segments: seg_out too small");
+            return GECCO_CRF_EINVAL;
+        }
+        int64_t row = 0;
+        for (const Chunk &ck : chunks) {
+            const int64_t k = int64_t(ck.rows.size() / 4);
+            if (k) std::memcpy(r.seg_out + 4 * row, ck.rows.data(), size_t(k) * 16);
+            if (r.seg_p_out) {
+                size_t at = 0;
+                for (int64_t i = 0; i < k; ++i) {
+                    const int64_t len = ck.rows[4 * size_t(i) + 3] - ck.rows[4 * size_t(i) + 2];
+                    if (genes + len > r.max_seg_genes) {
+                        set_error("segments: seg_p_out too small");
+                        return GECCO_CRF_EINVAL;
+                    }
+                    std::memcpy(r.seg_p_out + genes, ck.seg_p.data() + at, size_t(len) * 8);
+                    at += size_t(len);
+                    genes += len;
+                    r.seg_off_out[row + i + 1] = genes;
+                }
+            }
+            row += k;
+        }
+    }
+    S.stats.wall_seconds = now_s() - t_start;
+    return GECCO_CRF_OK;
+}
+
+}  // namespace gecco

@@ -48,8 +48,15 @@ def predict_tables(genes_t: tables.GeneTable, feats_t: tables.FeatureTable, crf:
                           f"padding with {W - n} {unit}")
         else:
             warnings.warn(f"Contig {cid!r} does not contain enough proteins ({n}) for sliding window of size {W}")
-    p = crf.predict_probabilities_csr(cptr, gptr, attr, pad=pad, device=dev)
-    seg = _native.segment(p, annotated, cptr, threshold, n_cds, edge_distance, trim, device=dev)
+    # marginals and cluster rows in one pass of the batch driver: the refiner runs on the device right behind
+    # the marginals (one grouper per contig, like the CLI: cli/commands/_common.py:621-623); the probabilities
+    # come back once, for the output tables
+    label = crf.model.native.label_id("1")
+    if label < 0:
+        raise ValueError("the model has no label '1'")
+    session = crf._session() if device is None else _native.Session(crf.model.native, [dev])
+    seg, _, _, p = session.clusters(cptr, gptr, attr, annotated, W, crf.window_step, label, pad, threshold, n_cds,
+                                    edge_distance, trim, want_p=True, want_seg_p=False)
 
     # ---- genes table, in the order of ClusterCRF.predict_probabilities (contig id, start); every
     # column is gathered at once (no per-gene Python work)

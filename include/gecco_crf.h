@@ -13,11 +13,14 @@
  * INTEGRATION.md and implemented in gecco_amd/crf.py.
  *
  * Conventions: plain pointers and sizes; every function returns an int status (0 = OK,
- * <0 = error, text via gecco_crf_last_error()); caller owns all buffers; handles are
- * immutable after creation and may be shared between threads.  Batches are CSR:
+ * <0 = error, text via gecco_crf_last_error()); caller owns all buffers.  Model handles are
+ * immutable after creation and may be shared between threads; a plan may be launched from several
+ * threads (its lazily created work space is guarded), but concurrent launches of ONE plan share that
+ * work space and must therefore go to one stream; sessions serialise their batches.  Batches are CSR:
  *   contig_ptr[n_contigs+1]  gene offsets of each contig          (host memory, always)
  *   gene_ptr  [n_genes+1]    attribute offsets of each gene
- *   attr_id   [nnz]          attribute ids (unknown names already dropped, as CRFsuite does)
+ *   attr_id   [nnz]          attribute ids; ids outside [0, num_attrs) count as unknown attributes
+ *                            and carry no weight, as names CRFsuite does not know do
  * Genes are in the reference's order: sorted by (contig id, start) -- crf/__init__.py:199.
  * There is NO CPU fallback in this library: without a HIP device the compute entry points
  * return GECCO_CRF_ENODEV.
@@ -100,11 +103,15 @@ int gecco_crf_viterbi(const gecco_crf_model *m, int32_t device,
 /* Row R (gecco/refine.py:51-64,118-200, criterion "gecco"): threshold run-length
  * segmentation with the stateful grouper, optional trimming of un-annotated edge genes and
  * validation.  seg_out rows = (contig, cluster_number, first_gene, last_gene_exclusive);
- * *n_seg receives the number of rows; GECCO_CRF_EINVAL if max_seg is too small. */
+ * *n_seg receives the number of rows; GECCO_CRF_EINVAL if max_seg is too small.
+ * carry_state: the grouper lives for one `iter_clusters` call (refine.py:186).  0 = one call per
+ * contig, what the CLI does (cli/commands/_common.py:621-623): every contig starts "out".
+ * 1 = one call over all contigs: a contig that starts with genes without probability inherits the
+ * state the previous contig ended in. */
 int gecco_crf_segment(int32_t device, const double *p, const uint8_t *annotated,
                       const int32_t *contig_ptr, int32_t n_contigs,
                       double threshold, int32_t n_cds, int32_t edge_distance, int32_t trim,
-                      int32_t *seg_out, int32_t max_seg, int32_t *n_seg);
+                      int32_t carry_state, int32_t *seg_out, int32_t max_seg, int32_t *n_seg);
 
 /* Weighted domain composition of called clusters (gecco/model.py:458-503
  * `Cluster.domain_composition(all_possible, normalize)`, assembled per cluster for the type
@@ -146,11 +153,61 @@ int gecco_crf_plan_run_viterbi(gecco_crf_plan *p, const int32_t *d_gene_ptr, con
  * gecco_crf_plan_run_windowed followed by gecco_crf_plan_run_viterbi; d_score may be NULL. */
 int gecco_crf_plan_run_decode(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                               int32_t label, double *d_p_out, int8_t *d_y, double *d_score, void *stream);
+/* Row R chained behind the marginals, on the same stream, without moving them: d_p (e.g. the output
+ * of gecco_crf_plan_run_windowed) and d_annotated are device arrays over the plan's genes; rows go
+ * to d_seg[max_seg][4] and their number to *d_n_seg, both device-accessible (device memory, or
+ * memory from gecco_crf_host_alloc).  The reference runs this right behind predict_probabilities
+ * (cli/commands/_common.py:595-625 -> refine.py:118-200). */
+int gecco_crf_plan_run_segment(gecco_crf_plan *p, const double *d_p, const uint8_t *d_annotated,
+                               double threshold, int32_t n_cds, int32_t edge_distance, int32_t trim,
+                               int32_t carry_state, int32_t *d_seg, int32_t max_seg, int32_t *d_n_seg,
+                               void *stream);
 /* Average milliseconds per launch of `iters` back-to-back windowed launches, measured with
  * HIP events on `stream` (after `warmup` untimed launches). */
 int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                                  int32_t label, double *d_p_out, void *stream,
                                  int32_t warmup, int32_t iters, float *ms_per_launch);
+
+/* ---- batch driver: host buffers in, host buffers out, one or several devices ----------------
+ * What `gecco run` reaches through ClusterCRF.predict_probabilities (gecco/crf/__init__.py:244-258:
+ * one loop iteration per contig, nothing shared).  A session owns, per device, a ring of lanes
+ * (stream + reusable plan + device buffers); a batch is cut into chunks at contig boundaries, the
+ * chunks are dealt to the devices longest-first by gene count (per-GPU queues, no collective), and
+ * chunk k+1 is uploaded while chunk k computes and chunk k-1 is downloaded.  Host buffers from
+ * gecco_crf_host_alloc (pinned) make every copy asynchronous; any other host memory works too.
+ * Nothing is allocated once a session has seen its largest chunk.  One batch at a time per session
+ * (calls are serialised); free a session before its model.  The one-shot entry points above run on
+ * a per-device session owned by the model. */
+typedef struct gecco_crf_session gecco_crf_session;
+int gecco_crf_host_alloc(size_t n_bytes, void **out);
+void gecco_crf_host_free(void *p);
+int gecco_crf_session_create(const gecco_crf_model *m, const int32_t *devices, int32_t n_devices,
+                             gecco_crf_session **out);
+void gecco_crf_session_free(gecco_crf_session *s);
+int gecco_crf_session_set_chunk_genes(gecco_crf_session *s, int32_t genes); /* default 2^19 */
+/* Figures of the last batch (any pointer may be NULL). */
+int gecco_crf_session_stats(const gecco_crf_session *s, int32_t *n_chunks, int64_t *h2d_bytes,
+                            int64_t *d2h_bytes, double *host_plan_seconds, double *wall_seconds);
+/* = gecco_crf_windowed_marginals over the session's devices. */
+int gecco_crf_session_windowed(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                               const int32_t *gene_ptr, const int32_t *attr_id, int32_t window,
+                               int32_t step, int32_t label, int32_t pad, double *p_out);
+/* Windowed marginals + Viterbi labels of the same batch (state scores gathered once). */
+int gecco_crf_session_decode(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                             const int32_t *gene_ptr, const int32_t *attr_id, int32_t window,
+                             int32_t step, int32_t label, int32_t pad, double *p_out, int8_t *y_out);
+/* predict_probabilities + ClusterRefiner in one pass, one grouper per contig like the CLI
+ * (cli/commands/_common.py:595-625): the probabilities never leave the device unless p_out is given;
+ * what comes back is the rows (batch-wide contig / gene indices) and, if seg_p_out is given, the
+ * probabilities of the genes of every row (row k at seg_off_out[k] .. seg_off_out[k+1]), which is
+ * all a cluster table needs of them (average_p, max_p: gecco/model.py:442-454). */
+int gecco_crf_session_clusters(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                               const int32_t *gene_ptr, const int32_t *attr_id, const uint8_t *annotated,
+                               int32_t window, int32_t step, int32_t label, int32_t pad,
+                               double threshold, int32_t n_cds, int32_t edge_distance, int32_t trim,
+                               double *p_out /* n_genes or NULL */, int32_t *seg_out, int32_t max_seg,
+                               int32_t *n_seg, double *seg_p_out /* or NULL */, int64_t max_seg_genes,
+                               int64_t *seg_off_out /* max_seg + 1, with seg_p_out */);
 
 #ifdef __cplusplus
 }

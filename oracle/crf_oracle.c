@@ -267,7 +267,7 @@ ORACLE_API int oracle_viterbi(const double *w, const double *trans, int A, int L
 
 /* ---- row R: GeneGrouper + ClusterRefiner, criterion "gecco" ------------------------
  * gecco/refine.py:51-64 (stateful grouper: a gene without probability inherits the
- * previous gene's state; ONE grouper instance spans all contigs of a call, :186),
+ * previous gene's state; ONE grouper instance spans all contigs of an iter_clusters call, :186),
  * :182-200 (runs of in_cluster genes per contig, numbered from 1 BEFORE filtering),
  * :167-180 (trim unannotated edge genes), :139-157 (validate: #annotated >= n_cds and
  * #(cluster genes - edge genes) >= n_cds, edge genes = first/last `edge_distance`
@@ -278,12 +278,15 @@ ORACLE_API int oracle_viterbi(const double *w, const double *trans, int A, int L
 ORACLE_API int oracle_segment(const double *p, const uint8_t *annotated,
                               const int32_t *contig_ptr, int n_contigs,
                               double threshold, int n_cds, int edge_distance, int trim,
-                              int32_t *seg_out, int max_seg)
+                              int carry_state, int32_t *seg_out, int max_seg)
 {
     int kept = 0;
-    int in_cluster = 0; /* grouper state persists across contigs (refine.py:186) */
+    int in_cluster = 0; /* one grouper per iter_clusters call (refine.py:186) */
     for (int ci = 0; ci < n_contigs; ++ci) {
         int g0 = contig_ptr[ci], g1 = contig_ptr[ci + 1];
+        /* carry_state = 0: one iter_clusters call per contig, as the CLI does
+         * (cli/commands/_common.py:621-623) -> a fresh grouper; 1: one call over all contigs */
+        if (!carry_state) in_cluster = 0;
         int number = 0;
         int g = g0;
         /* edge genes: indices of annotated genes near both ends */

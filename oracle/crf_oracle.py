@@ -198,7 +198,7 @@ def viterbi_seq(state, trans):
     return lab, sc.value
 
 
-def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, trim=True):
+def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, trim=True, carry_state=False):
     p = np.ascontiguousarray(p, dtype=np.float64)
     annotated = np.ascontiguousarray(annotated, dtype=np.uint8)
     contig_ptr = np.ascontiguousarray(contig_ptr, dtype=np.int32)
@@ -206,7 +206,7 @@ def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, t
     seg = np.zeros((cap, 4), dtype=np.int32)
     k = lib().oracle_segment(
         _p(p, _D), _p(annotated, _B), _p(contig_ptr, _I), len(contig_ptr) - 1, _D(threshold), int(n_cds),
-        int(edge_distance), int(bool(trim)), _p(seg, _I), cap,
+        int(edge_distance), int(bool(trim)), int(bool(carry_state)), _p(seg, _I), cap,
     )
     if k < 0:
         raise RuntimeError("oracle_segment overflow")

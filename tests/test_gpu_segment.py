@@ -27,11 +27,12 @@ def test_segment_matches_oracle(n_cds, edge, trim):
     from oracle import crf_oracle as orc
 
     rng = np.random.default_rng(100 * n_cds + edge)
-    for n_contigs, max_len in [(1, 50), (40, 80), (3000, 60), (5, 5000)]:
+    for n_contigs, max_len in [(1, 50), (40, 80), (3000, 60), (5, 5000), (3, 40000)]:
         p, ann, cptr = _random_case(rng, n_contigs, max_len)
-        exp = orc.segment(p, ann, cptr, 0.8, n_cds, edge, trim)
-        got = nat.segment(p, ann, cptr, 0.8, n_cds, edge, trim)
-        assert got.tolist() == exp.tolist()
+        for carry in (False, True):  # one grouper per contig (the CLI) / one for the whole call
+            exp = orc.segment(p, ann, cptr, 0.8, n_cds, edge, trim, carry_state=carry)
+            got = nat.segment(p, ann, cptr, 0.8, n_cds, edge, trim, carry_state=carry)
+            assert got.tolist() == exp.tolist()
 
 
 def test_segment_golden(oracle_model):
@@ -43,3 +44,23 @@ def test_segment_golden(oracle_model):
     seg = nat.segment(expected, ann, cptr, 0.8, 3, 0, True)
     assert seg.tolist() == [[0, 1, 0, 23]]
     assert nat.segment(np.zeros(0), np.zeros(0, dtype=np.uint8), [0]).shape == (0, 4)
+
+
+def test_segment_long_runs_and_empty_contigs():
+    """Runs that span many scan blocks, contigs without genes, runs without any annotated gene."""
+    from gecco_amd import _native as nat
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(5)
+    n = 30000
+    p = np.full(n, 0.95)
+    p[rng.integers(0, n, size=6)] = 0.1          # a handful of cuts: runs of thousands of genes
+    p[20000:20100] = np.nan
+    ann = (rng.random(n) < 0.5).astype(np.uint8)
+    ann[:3000] = 0                                # the first run trims to nothing
+    cptr = np.array([0, 0, 12000, 12000, 12001, n, n], dtype=np.int32)
+    for n_cds, edge, trim in [(3, 0, True), (1, 5, True), (0, 0, True), (2, 0, False), (3, 100000, True)]:
+        for carry in (False, True):
+            exp = orc.segment(p, ann, cptr, 0.8, n_cds, edge, trim, carry_state=carry)
+            got = nat.segment(p, ann, cptr, 0.8, n_cds, edge, trim, carry_state=carry)
+            assert got.tolist() == exp.tolist(), (n_cds, edge, trim, carry)

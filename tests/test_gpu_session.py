@@ -1,0 +1,176 @@
+"""GPU parity of the batch driver (gecco_crf_session_*: chunked, pipelined, host buffers in / out) and
+of the resident refiner epilogue, against the CPU oracle.  Chunk sizes are forced small so that one
+batch goes through many chunks and every lane of the ring is reused."""
+import numpy as np
+import pytest
+
+from tests.helpers import synth_contigs
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from gecco_amd import _native
+
+    assert _native.device_count() >= 1, "no HIP device: the GPU suite must run on an MI355X"
+    return _native
+
+
+@pytest.fixture(scope="module")
+def real_model(nat):
+    import os
+
+    from oracle import lcrf
+    from tests.helpers import GOLDEN
+
+    st = lcrf.load_pickle(os.path.join(GOLDEN, "model.pkl"))
+    return nat.Model.from_lcrf(st["blob"])
+
+
+def _batch(oracle_model, seed, n_contigs=300, hi=400):
+    rng = np.random.default_rng(seed)
+    lengths = list(rng.integers(1, hi, size=n_contigs)) + [1, 2, 19, 20, 21, 3000]
+    rng.shuffle(lengths)
+    return synth_contigs(rng, lengths, oracle_model["state"].shape[0])
+
+
+def _same(got, exp):
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    assert np.abs(np.nan_to_num(got) - np.nan_to_num(exp)).max() <= TOL
+
+
+@pytest.mark.parametrize("chunk,pad,pinned", [(1024, True, False), (5000, False, False), (20000, True, True), (1 << 19, True, False)])
+def test_session_windowed_chunks(nat, real_model, oracle_model, chunk, pad, pinned):
+    from oracle import crf_oracle as orc
+
+    cptr, gptr, attr = _batch(oracle_model, 11)
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, pad)
+    ses = nat.Session(real_model, [0])
+    ses.set_chunk_genes(chunk)
+    out = None
+    if pinned:
+        cptr, gptr, attr = nat.pinned_copy(cptr), nat.pinned_copy(gptr), nat.pinned_copy(attr)
+        out = nat.pinned_empty(len(exp), np.float64)
+    for _ in range(2):  # second pass: every buffer and plan of the ring is reused
+        got = ses.windowed_marginals(cptr, gptr, attr, 20, 1, 1, pad, out=out)
+        _same(got, exp)
+    st = ses.stats()
+    assert st["n_chunks"] == max(1, min(len(cptr) - 1, (int(cptr[-1]) + chunk // 2) // chunk))
+    assert st["d2h_bytes"] == 8 * len(exp)
+
+
+def test_session_decode_and_one_shot_agree(nat, real_model, oracle_model):
+    from oracle import crf_oracle as orc
+
+    cptr, gptr, attr = _batch(oracle_model, 12)
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, True)
+    ey, _ = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    ses = nat.Session(real_model, [0])
+    ses.set_chunk_genes(3000)
+    p, y = ses.decode(cptr, gptr, attr, 20)
+    _same(p, exp)
+    np.testing.assert_array_equal(y.astype(np.int32), ey)
+    # the one-shot entry points run on the model's own session: same numbers, bit for bit
+    np.testing.assert_array_equal(real_model.windowed_marginals(cptr, gptr, attr, 20), p)
+    y1, sc = real_model.viterbi(cptr, gptr, attr)
+    np.testing.assert_array_equal(y1, y)
+    _, esc = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    assert np.abs(sc - esc).max() <= 1e-9
+    marg, ln = real_model.marginals_full(cptr, gptr, attr)
+    em, eln = orc.full_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    assert np.abs(marg - em).max() <= TOL and np.abs(ln - eln).max() <= 1e-9
+
+
+def test_session_unknown_attribute_ids_carry_no_weight(nat, real_model, oracle_model):
+    """ids outside the model's dictionary count as unknown attributes ([EXT] CRFsuite drops unknown names)."""
+    from oracle import crf_oracle as orc
+
+    A = oracle_model["state"].shape[0]
+    cptr, gptr, attr = _batch(oracle_model, 13, n_contigs=40)
+    rng = np.random.default_rng(0)
+    bad = attr.copy()
+    hit = rng.random(len(bad)) < 0.2
+    bad[hit] = np.where(rng.random(int(hit.sum())) < 0.5, A + 5, -3)
+    # the same batch with those attributes dropped
+    keep = ~hit
+    owner = np.repeat(np.arange(len(gptr) - 1), np.diff(gptr))
+    g2 = np.concatenate([[0], np.cumsum(np.bincount(owner[keep], minlength=len(gptr) - 1))]).astype(np.int32)
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, g2, attr[keep], 20, 1, 1, True)
+    ey, _ = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, g2, attr[keep])
+    ses = nat.Session(real_model, [0])
+    _same(ses.windowed_marginals(cptr, gptr, bad, 20), exp)
+    y, _ = real_model.viterbi(cptr, gptr, bad)
+    np.testing.assert_array_equal(y.astype(np.int32), ey)
+
+
+@pytest.mark.parametrize("chunk,pad,n_cds,edge,trim", [(2000, True, 3, 0, True), (1 << 19, False, 1, 2, True), (7000, False, 2, 0, False)])
+def test_session_clusters_resident(nat, real_model, oracle_model, chunk, pad, n_cds, edge, trim):
+    """predict_probabilities + refiner in one pass: rows equal the oracle's segmentation (one grouper per
+    contig, like the CLI) of the oracle's probabilities, and only the rows' probabilities come back."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(14)
+    cptr, gptr, attr = _batch(oracle_model, 14)
+    ann = (np.diff(gptr) > 0).astype(np.uint8)
+    ann[rng.random(len(ann)) < 0.05] ^= 1
+    p_exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, pad)
+    thr = float(np.nanmedian(p_exp))  # the random batch has few genes above 0.8: cut where there are many runs
+    exp = orc.segment(p_exp, ann, cptr, thr, n_cds, edge, trim, carry_state=False)
+    assert len(exp) > 20
+    ses = nat.Session(real_model, [0])
+    ses.set_chunk_genes(chunk)
+    seg, seg_p, seg_off, p = ses.clusters(cptr, gptr, attr, ann, 20, 1, 1, pad, thr, n_cds, edge, trim)
+    assert p is None
+    assert seg.tolist() == exp.tolist()
+    for (c, num, a, b), o0, o1 in zip(seg.tolist(), seg_off[:-1], seg_off[1:]):
+        assert o1 - o0 == b - a
+        _same(seg_p[o0:o1], p_exp[a:b])
+    assert ses.stats()["d2h_bytes"] == 0  # the rows arrive through pinned memory written by the kernels
+    seg2, _, _, p2 = ses.clusters(cptr, gptr, attr, ann, 20, 1, 1, pad, thr, n_cds, edge, trim, want_p=True, want_seg_p=False)
+    assert seg2.tolist() == exp.tolist()
+    _same(p2, p_exp)
+
+
+def test_plan_run_segment_on_device_arrays(nat, real_model, oracle_model):
+    """gecco_crf_plan_run_segment chained behind gecco_crf_plan_run_windowed on one stream: p never leaves the device."""
+    import torch
+
+    from oracle import crf_oracle as orc
+
+    cptr, gptr, attr = _batch(oracle_model, 15)
+    ann = (np.diff(gptr) > 0).astype(np.uint8)
+    n = int(cptr[-1])
+    dev = torch.device("cuda", 0)
+    plan = nat.Plan(real_model, cptr, 20, 1, True, device=0)
+    d_gp, d_at, d_ann = (torch.from_numpy(x).to(dev) for x in (gptr, attr, ann))
+    d_p = torch.zeros(n, dtype=torch.float64, device=dev)
+    d_seg = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    p_exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, True)
+    thr = float(np.median(p_exp))
+    for carry in (False, True):
+        plan.run_windowed(d_gp.data_ptr(), d_at.data_ptr(), d_p.data_ptr(), 1, stream)
+        plan.run_segment(d_p.data_ptr(), d_ann.data_ptr(), d_seg.data_ptr(), n, d_n.data_ptr(), thr, 3, 0, True, carry, stream)
+        torch.cuda.synchronize(dev)
+        k = int(d_n.item())
+        exp = orc.segment(p_exp, ann, cptr, thr, 3, 0, True, carry_state=carry)
+        assert d_seg[:k].cpu().numpy().tolist() == exp.tolist()
+
+
+def test_session_argument_errors(nat, real_model):
+    ses = nat.Session(real_model, [0])
+    with pytest.raises(ValueError, match="Window size must be strictly positive"):
+        ses.windowed_marginals([0, 1], [0, 0], [], 0)
+    with pytest.raises(ValueError, match="Window step"):
+        ses.windowed_marginals([0, 1], [0, 0], [], 5, step=6)
+    with pytest.raises(ValueError, match="label out of range"):
+        ses.windowed_marginals([0, 1], [0, 0], [], 5, label=2)
+    with pytest.raises(ValueError, match="non-decreasing"):
+        ses.windowed_marginals([0, 5, 3], [0] * 6, [], 5)
+    assert len(ses.windowed_marginals([0], [0], [], 5)) == 0
+    with pytest.raises(Exception):
+        nat.Session(real_model, [0, 0])

@@ -9,6 +9,8 @@ import shutil
 import statistics
 import warnings
 
+import itertools
+
 import numpy as np
 import pytest
 
@@ -280,12 +282,22 @@ def test_refiner_matches_oracle_segment():
         ann_all += ann.tolist()
         cptr.append(cptr[-1] + n)
     for n_cds, edge, trim in [(3, 0, True), (1, 0, False), (2, 2, True), (5, 1, True)]:
-        seg = orc.segment(np.array(p_all), np.array(ann_all, dtype=np.uint8), np.array(cptr), 0.8, n_cds, edge, trim)
+        # one iter_clusters call over every contig: one grouper, its state carries across contigs
+        seg = orc.segment(np.array(p_all), np.array(ann_all, dtype=np.uint8), np.array(cptr), 0.8, n_cds, edge, trim,
+                          carry_state=True)
         rng.shuffle(genes)
-        got = list(refine.ClusterRefiner(threshold=0.8, n_cds=n_cds, edge_distance=edge, trim=trim,
-                                         cluster_type=Cluster).iter_clusters(genes))
+        refiner = refine.ClusterRefiner(threshold=0.8, n_cds=n_cds, edge_distance=edge, trim=trim, cluster_type=Cluster)
+        got = list(refiner.iter_clusters(genes))
         exp = [(f"ctg{c:03d}_cluster_{k}", [f"ctg{c:03d}_{g - cptr[c]}" for g in range(a, b)]) for c, k, a, b in seg.tolist()]
         assert [(c.id, [g.id for g in c.genes]) for c in got] == exp
+        # one call per contig, what the CLI does (cli/commands/_common.py:621-623): a fresh grouper each time
+        seg0 = orc.segment(np.array(p_all), np.array(ann_all, dtype=np.uint8), np.array(cptr), 0.8, n_cds, edge, trim,
+                           carry_state=False)
+        got0 = []
+        for _, group in itertools.groupby(sorted(genes, key=lambda g: g.source.id), key=lambda g: g.source.id):
+            got0.extend(refiner.iter_clusters(list(group)))
+        exp0 = [(f"ctg{c:03d}_cluster_{k}", [f"ctg{c:03d}_{g - cptr[c]}" for g in range(a, b)]) for c, k, a, b in seg0.tolist()]
+        assert [(c.id, [g.id for g in c.genes]) for c in got0] == exp0
 
 
 def test_refiner_defaults_and_antismash():

@@ -98,5 +98,13 @@ def test_segment_semantics():
     assert seg.tolist() == [[0, 2, 6, 9]]  # cluster 1: {1,2,3}-edge={3} <2 ; cluster 2: {6,7,8}-edge={6,7}
     # grouper state leaks across contigs: second contig starts with NaN after an "in" gene
     p2 = np.array([.1, .9, nan, .9, .9])
-    seg = orc.segment(p2, np.ones(5, dtype=np.uint8), np.array([0, 2, 5], dtype=np.int32), 0.8, 1, 0, True)
+    seg = orc.segment(p2, np.ones(5, dtype=np.uint8), np.array([0, 2, 5], dtype=np.int32), 0.8, 1, 0, True, carry_state=True)
     assert seg.tolist() == [[0, 1, 1, 2], [1, 1, 2, 5]]
+    # ... unless every contig gets its own iter_clusters call, as in the CLI (_common.py:621-623)
+    seg = orc.segment(p2, np.ones(5, dtype=np.uint8), np.array([0, 2, 5], dtype=np.int32), 0.8, 1, 0, True, carry_state=False)
+    assert seg.tolist() == [[0, 1, 1, 2], [1, 1, 3, 5]]
+    # a skipped (all-NaN) contig behind a contig that ends "in" is no cluster for the CLI
+    p3 = np.array([.95] * 5 + [nan] * 5)
+    cp3 = np.array([0, 5, 10], dtype=np.int32)
+    assert len(orc.segment(p3, np.ones(10, dtype=np.uint8), cp3, 0.8, 3, 0, True, carry_state=False)) == 1
+    assert len(orc.segment(p3, np.ones(10, dtype=np.uint8), cp3, 0.8, 3, 0, True, carry_state=True)) == 2
