@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -12,11 +13,30 @@
 namespace gecco {
 namespace {
 
-constexpr int kLanes = 3;  // upload of chunk k+1, compute of k, download of k-1
+constexpr int kLanes = 4;  // buffers in flight per device: uploading, computing, downloading + one being laid out
 
 double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+// GECCO_CRF_TRACE=1: host-side time of every step of a submission, to stderr (is a call blocking?)
+bool trace_on() {
+    static const bool on = [] {
+        const char *e = std::getenv("GECCO_CRF_TRACE");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+struct TraceMark {
+    double t;
+    TraceMark() : t(trace_on() ? now_s() : 0.0) {}
+    void lap(const char *what, int chunk) {
+        if (!trace_on()) return;
+        const double n = now_s();
+        std::fprintf(stderr, "[gecco_crf] chunk %d %-14s %8.1f us\n", chunk, what, (n - t) * 1e6);
+        t = n;
+    }
+};
 
 struct DevBuf {  // grow-only device block
     char *p = nullptr;
@@ -71,10 +91,15 @@ struct Chunk {
     std::vector<double> seg_p;
 };
 
+// Streams are per DIRECTION, not per chunk: all uploads of a device go through `up`, all kernels through
+// `comp`, all downloads through `down`, chained by events.  Measured on MI355X (tools/ubench/pipe_test.hip):
+// with one stream per chunk (upload, kernel, download in each) the copies of consecutive chunks do not
+// overlap at all on this runtime -- 0.66 ms for a 2 M-gene batch however it is cut, the same as no
+// pipelining; one stream per direction: 0.56 ms.
 struct Lane {
     int device = -1;
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
+    hipStream_t up = nullptr, comp = nullptr, down = nullptr;  // the device's three streams (not owned)
+    hipEvent_t ev_up = nullptr, ev_comp = nullptr, done = nullptr;
     int chunk = -1;  // index of the chunk in flight, -1: idle
     Plan plan;
     DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm;
@@ -85,6 +110,7 @@ struct Lane {
 
 struct DeviceCtx {
     int device = -1;
+    hipStream_t up = nullptr, comp = nullptr, down = nullptr;
     Lane lanes[kLanes];
     int next_lane = 0;
 };
@@ -107,13 +133,15 @@ Session::~Session() {
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     for (auto &d : devs) {
         if (hipSetDevice(d->device) != hipSuccess) continue;
+        (void)hipDeviceSynchronize();
         for (Lane &ln : d->lanes) {
-            if (ln.stream) (void)hipStreamSynchronize(ln.stream);
             for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm}) b->release();
             ln.h_seg.release();
-            if (ln.done) (void)hipEventDestroy(ln.done);
-            if (ln.stream) (void)hipStreamDestroy(ln.stream);
+            for (hipEvent_t e : {ln.ev_up, ln.ev_comp, ln.done})
+                if (e) (void)hipEventDestroy(e);
         }
+        for (hipStream_t st : {d->up, d->comp, d->down})
+            if (st) (void)hipStreamDestroy(st);
     }
     devs.clear();  // plans free their blocks under their own device guard
     if (prev >= 0) (void)hipSetDevice(prev);
@@ -141,22 +169,24 @@ int session_create(const Model &m, const int32_t *devices, int32_t n_devices, Se
             set_error("device index out of range");
             return GECCO_CRF_ENODEV;
         }
-        for (int32_t j = 0; j < i; ++j)
-            if (devices[j] == devices[i]) {
-                set_error("session: a device is listed twice");
-                return GECCO_CRF_EINVAL;
-            }
+        // a device may be listed more than once: every entry gets its own ring of lanes
         int rc = check_hip(hipSetDevice(devices[i]), "hipSetDevice");
         if (rc) return rc;
         std::unique_ptr<DeviceCtx> d(new DeviceCtx());
         d->device = devices[i];
-        for (Lane &ln : d->lanes) {
+        s->devs.push_back(std::move(d));  // from here on the session's destructor cleans up
+        DeviceCtx &D = *s->devs.back();
+        for (hipStream_t *st : {&D.up, &D.comp, &D.down})
+            if ((rc = check_hip(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
+        for (Lane &ln : D.lanes) {
             ln.device = devices[i];
+            ln.up = D.up;
+            ln.comp = D.comp;
+            ln.down = D.down;
             ln.plan.async_tables = true;
-            if ((rc = check_hip(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
-            if ((rc = check_hip(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming), "hipEventCreate"))) return rc;
+            for (hipEvent_t *e : {&ln.ev_up, &ln.ev_comp, &ln.done})
+                if ((rc = check_hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate"))) return rc;
         }
-        s->devs.push_back(std::move(d));
     }
     *out = s.release();
     return GECCO_CRF_OK;
@@ -237,25 +267,39 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
     int rc = check_hip(hipSetDevice(ln.device), "hipSetDevice");
     if (rc) return rc;
     const int32_t nc = ck.c1 - ck.c0, ng = ck.g1 - ck.g0;
-    const double t0 = now_s();
-    if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.stream, false))) return rc;
-    if ((X.viterbi || X.full || r.want_segments) && (rc = plan_ensure_seq(ln.plan, ln.stream, false))) return rc;
-    S.stats.host_plan_seconds += now_s() - t0;
+    TraceMark tm;
     ln.chunk = chunk_index;
-    if (ng == 0) return check_hip(hipEventRecord(ln.done, ln.stream), "hipEventRecord");
-    const int64_t a0 = r.gene_ptr[ck.g0], a1 = r.gene_ptr[ck.g1];
+    const int64_t a0 = ng ? r.gene_ptr[ck.g0] : 0, a1 = ng ? r.gene_ptr[ck.g1] : 0;
     if (a0 < 0 || a1 < a0) {
         set_error("gene_ptr must be non-decreasing and start at a non-negative offset");
         return GECCO_CRF_EINVAL;
     }
     const size_t nnz = size_t(a1 - a0), L = size_t(m.L);
-    if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
-    if ((rc = ln.d_at.reserve((nnz + 4) * 4, "hipMalloc attr_id"))) return rc;
-    if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.g0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.stream), "H2D gene_ptr")))
-        return rc;
-    if (nnz && (rc = check_hip(hipMemcpyAsync(ln.d_at.p, r.attr_id + a0, nnz * 4, hipMemcpyHostToDevice, ln.stream), "H2D attr_id")))
-        return rc;
-    S.stats.h2d_bytes += int64_t((size_t(ng) + 1 + nnz) * 4);
+    // ---- uploads first: the bulk copies are on their way while the host lays the chunk out
+    if (ng) {
+        if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
+        if ((rc = ln.d_at.reserve((nnz + 4) * 4, "hipMalloc attr_id"))) return rc;
+        if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.g0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.up), "H2D gene_ptr")))
+            return rc;
+        if (nnz && (rc = check_hip(hipMemcpyAsync(ln.d_at.p, r.attr_id + a0, nnz * 4, hipMemcpyHostToDevice, ln.up), "H2D attr_id")))
+            return rc;
+        S.stats.h2d_bytes += int64_t((size_t(ng) + 1 + nnz) * 4);
+        if (r.want_segments) {
+            if ((rc = ln.d_ann.reserve(size_t(ng) + 8, "hipMalloc annotated"))) return rc;
+            if ((rc = check_hip(hipMemcpyAsync(ln.d_ann.p, r.annotated + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D annotated")))
+                return rc;
+            S.stats.h2d_bytes += ng;
+        }
+    }
+    tm.lap("h2d csr", chunk_index);
+    const double t0 = now_s();
+    if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.up, false))) return rc;
+    if ((X.viterbi || X.full || r.want_segments) && (rc = plan_ensure_seq(ln.plan, ln.up, false))) return rc;
+    S.stats.host_plan_seconds += now_s() - t0;
+    tm.lap("plan_build", chunk_index);
+    if ((rc = check_hip(hipEventRecord(ln.ev_up, ln.up), "hipEventRecord"))) return rc;
+    if ((rc = check_hip(hipStreamWaitEvent(ln.comp, ln.ev_up, 0), "hipStreamWaitEvent"))) return rc;
+    if (ng == 0) return check_hip(hipEventRecord(ln.done, ln.comp), "hipEventRecord");
     // gene_ptr keeps the caller's offsets: the attribute array is addressed from where its element 0 would be
     const int32_t *d_gp = reinterpret_cast<const int32_t *>(ln.d_gp.p);
     const int32_t *d_at = reinterpret_cast<const int32_t *>(ln.d_at.p) - a0;
@@ -274,18 +318,18 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
         }
     }
     if (X.windowed && X.viterbi) {
-        rc = plan_run_decode(ln.plan, d_gp, d_at, r.label, d_p, d_y, d_score, ln.stream);
+        rc = plan_run_decode(ln.plan, d_gp, d_at, r.label, d_p, d_y, d_score, ln.comp);
     } else if (X.windowed) {
-        rc = plan_run_windowed(ln.plan, d_gp, d_at, r.label, d_p, ln.stream);
+        rc = plan_run_windowed(ln.plan, d_gp, d_at, r.label, d_p, ln.comp);
     } else if (X.viterbi) {
-        rc = plan_run_viterbi(ln.plan, d_gp, d_at, d_y, d_score, ln.stream);
+        rc = plan_run_viterbi(ln.plan, d_gp, d_at, d_y, d_score, ln.comp);
     }
     if (rc) return rc;
     if (X.full) {
         if ((rc = ln.d_marg.reserve(size_t(ng) * L * 8, "hipMalloc marginals"))) return rc;
         if ((rc = ln.d_lognorm.reserve(size_t(nc) * 8, "hipMalloc lognorm"))) return rc;
         if ((rc = plan_run_marginals_full(ln.plan, d_gp, d_at, reinterpret_cast<double *>(ln.d_marg.p),
-                                          reinterpret_cast<double *>(ln.d_lognorm.p), ln.stream)))
+                                          reinterpret_cast<double *>(ln.d_lognorm.p), ln.comp)))
             return rc;
     }
     if (r.want_segments) {
@@ -298,37 +342,43 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
         ln.o_p = ln.o_rows + align256(cap * 16);
         const size_t bytes = ln.o_p + (r.seg_p_out ? size_t(ng) * 8 : 0) + 256;
         if ((rc = ln.h_seg.reserve(bytes, "hipHostMalloc segments"))) return rc;
-        if ((rc = ln.d_ann.reserve(size_t(ng) + 8, "hipMalloc annotated"))) return rc;
-        if ((rc = check_hip(hipMemcpyAsync(ln.d_ann.p, r.annotated + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.stream), "H2D annotated")))
-            return rc;
-        S.stats.h2d_bytes += ng;
         char *dp = ln.h_seg.dp;
         int32_t *d_total = reinterpret_cast<int32_t *>(dp), *d_off = reinterpret_cast<int32_t *>(dp + ln.o_off),
                 *d_rows = reinterpret_cast<int32_t *>(dp + ln.o_rows);
         if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(ln.d_ann.p), r.threshold, r.n_cds, r.edge_distance,
-                                   r.trim, 0, d_rows, int32_t(cap), d_off, d_total, ln.stream)))
+                                   r.trim, 0, d_rows, int32_t(cap), d_off, d_total, ln.comp)))
             return rc;
         if (r.seg_p_out &&
             (rc = check_hip(launch_segment_gather(d_p, d_rows, d_off, d_total, int32_t(cap), reinterpret_cast<double *>(dp + ln.o_p), ng,
-                                                  ln.stream), "segment gather launch")))
+                                                  ln.comp), "segment gather launch")))
             return rc;
     }
+    tm.lap("launch", chunk_index);
+    const bool any_d2h = r.p_out || r.y_out || r.score_out || r.marg_out || r.lognorm_out;
+    if (!any_d2h) return check_hip(hipEventRecord(ln.done, ln.comp), "hipEventRecord");
+    if ((rc = check_hip(hipEventRecord(ln.ev_comp, ln.comp), "hipEventRecord"))) return rc;
+    if ((rc = check_hip(hipStreamWaitEvent(ln.down, ln.ev_comp, 0), "hipStreamWaitEvent"))) return rc;
     auto d2h = [&](void *dst, const void *src, size_t bytes, const char *what) {
         S.stats.d2h_bytes += int64_t(bytes);
-        return bytes ? check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ln.stream), what) : GECCO_CRF_OK;
+        return bytes ? check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ln.down), what) : GECCO_CRF_OK;
     };
     if (r.p_out && (rc = d2h(r.p_out + ck.g0, d_p, size_t(ng) * 8, "D2H p"))) return rc;
     if (r.y_out && (rc = d2h(r.y_out + ck.g0, d_y, size_t(ng), "D2H labels"))) return rc;
     if (r.score_out && (rc = d2h(r.score_out + ck.c0, d_score, size_t(nc) * 8, "D2H scores"))) return rc;
     if (r.marg_out && (rc = d2h(r.marg_out + size_t(ck.g0) * L, ln.d_marg.p, size_t(ng) * L * 8, "D2H marginals"))) return rc;
     if (r.lognorm_out && (rc = d2h(r.lognorm_out + ck.c0, ln.d_lognorm.p, size_t(nc) * 8, "D2H lognorm"))) return rc;
-    return check_hip(hipEventRecord(ln.done, ln.stream), "hipEventRecord");
+    tm.lap("d2h", chunk_index);
+    rc = check_hip(hipEventRecord(ln.done, ln.down), "hipEventRecord");
+    tm.lap("event", chunk_index);
+    return rc;
 }
 
 // wait for the lane's chunk and take its segment rows over (translated to batch indices)
 int retire(RunCtx &X, Lane &ln) {
     if (ln.chunk < 0) return GECCO_CRF_OK;
+    TraceMark tm;
     int rc = check_hip(hipEventSynchronize(ln.done), "chunk completion");
+    tm.lap("wait", ln.chunk);
     Chunk &ck = X.chunks[ln.chunk];
     ln.chunk = -1;
     if (rc) return rc;
@@ -443,7 +493,7 @@ int session_run(Session &S, const BatchRequest &r) {
     for (auto &d : S.devs)
         for (Lane &ln : d->lanes) {
             if (rc) {  // the failed submission may have left work behind an unrecorded event
-                if (hipSetDevice(ln.device) == hipSuccess) (void)hipStreamSynchronize(ln.stream);
+                if (hipSetDevice(ln.device) == hipSuccess) (void)hipDeviceSynchronize();
                 ln.chunk = -1;
                 continue;
             }

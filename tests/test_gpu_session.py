@@ -37,6 +37,16 @@ def _batch(oracle_model, seed, n_contigs=300, hi=400):
     return synth_contigs(rng, lengths, oracle_model["state"].shape[0])
 
 
+def _threshold(p):
+    """A cut near the median that no probability comes close to: device and oracle values differ in the
+    last bits, so a gene sitting ON the threshold would be called differently."""
+    v = np.sort(p[~np.isnan(p)])
+    k = len(v) // 2
+    while v[k + 1] - v[k] < 1e-6:
+        k += 1
+    return float(0.5 * (v[k] + v[k + 1]))
+
+
 def _same(got, exp):
     np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
     assert np.abs(np.nan_to_num(got) - np.nan_to_num(exp)).max() <= TOL
@@ -117,7 +127,7 @@ def test_session_clusters_resident(nat, real_model, oracle_model, chunk, pad, n_
     ann = (np.diff(gptr) > 0).astype(np.uint8)
     ann[rng.random(len(ann)) < 0.05] ^= 1
     p_exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, pad)
-    thr = float(np.nanmedian(p_exp))  # the random batch has few genes above 0.8: cut where there are many runs
+    thr = _threshold(p_exp)  # the random batch has few genes above 0.8: cut where there are many runs
     exp = orc.segment(p_exp, ann, cptr, thr, n_cds, edge, trim, carry_state=False)
     assert len(exp) > 20
     ses = nat.Session(real_model, [0])
@@ -151,7 +161,7 @@ def test_plan_run_segment_on_device_arrays(nat, real_model, oracle_model):
     d_n = torch.zeros(1, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     p_exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, True)
-    thr = float(np.median(p_exp))
+    thr = _threshold(p_exp)
     for carry in (False, True):
         plan.run_windowed(d_gp.data_ptr(), d_at.data_ptr(), d_p.data_ptr(), 1, stream)
         plan.run_segment(d_p.data_ptr(), d_ann.data_ptr(), d_seg.data_ptr(), n, d_n.data_ptr(), thr, 3, 0, True, carry, stream)
@@ -173,4 +183,23 @@ def test_session_argument_errors(nat, real_model):
         ses.windowed_marginals([0, 5, 3], [0] * 6, [], 5)
     assert len(ses.windowed_marginals([0], [0], [], 5)) == 0
     with pytest.raises(Exception):
-        nat.Session(real_model, [0, 0])
+        nat.Session(real_model, [nat.device_count()])
+
+
+def test_session_several_device_entries(nat, real_model, oracle_model):
+    """Chunks dealt longest-first over several device entries (the same physical device listed three times
+    here: every entry has its own lanes and queue, exactly as three GPUs would)."""
+    from oracle import crf_oracle as orc
+
+    cptr, gptr, attr = _batch(oracle_model, 16, n_contigs=500)
+    exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, True)
+    ey, _ = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    ses = nat.Session(real_model, [0, 0, 0])
+    ses.set_chunk_genes(4096)
+    p, y = ses.decode(cptr, gptr, attr, 20)
+    _same(p, exp)
+    np.testing.assert_array_equal(y.astype(np.int32), ey)
+    ann = (np.diff(gptr) > 0).astype(np.uint8)
+    thr = _threshold(exp)
+    seg = ses.clusters(cptr, gptr, attr, ann, 20, threshold=thr)[0]
+    assert seg.tolist() == orc.segment(exp, ann, cptr, thr, 3, 0, True, carry_state=False).tolist()

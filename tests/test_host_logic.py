@@ -37,6 +37,22 @@ def oracle_engine(monkeypatch, oracle_model):
 
     monkeypatch.setattr(_native.Model, "windowed_marginals", fake)
 
+    class FakeSession:  # stands in for the native batch driver (gecco_crf_session_*) on a box without a GPU
+        def windowed_marginals(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True, out=None):
+            return fake(None, contig_ptr, gene_ptr, attr_id, window, step, label, pad)
+
+        def clusters(self, contig_ptr, gene_ptr, attr_id, annotated, window, step=1, label=1, pad=True, threshold=0.8,
+                     n_cds=3, edge_distance=0, trim=True, want_p=False, want_seg_p=True, p_out=None):
+            p = self.windowed_marginals(contig_ptr, gene_ptr, attr_id, window, step, label, pad)
+            seg = orc.segment(p, annotated, contig_ptr, threshold, n_cds, edge_distance, trim, carry_state=False)
+            off = np.concatenate([[0], np.cumsum(seg[:, 3] - seg[:, 2])]).astype(np.int64) if len(seg) else np.zeros(1, np.int64)
+            seg_p = np.concatenate([p[a:b] for _, _, a, b in seg.tolist()]) if len(seg) and want_seg_p else (np.zeros(0) if want_seg_p else None)
+            return seg, seg_p, off, (p if want_p else None)
+
+    from gecco_amd.crf import ClusterCRF
+
+    monkeypatch.setattr(ClusterCRF, "_session", lambda self: FakeSession())
+
 
 def _gene(contig, pid, start, domains):
     return Gene(Source(contig), start, start + 100, Strand.Coding,
