@@ -96,6 +96,28 @@ SIGNATURES = {
          ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p, _c_i32p, ctypes.c_int32, _c_i32p, _c_f64p,
          ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)],
     ),
+    "gecco_crf_pack_columns": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp)]),
+    "gecco_crf_packed_free": (None, [_vp]),
+    "gecco_crf_packed_info": (
+        ctypes.c_int,
+        [_vp, _c_i32p, _c_i32p, ctypes.POINTER(ctypes.c_int64), _c_i32p, _c_i32p, _c_i32p],
+    ),
+    "gecco_crf_packed_contig_ptr": (_vp, [_vp]),
+    "gecco_crf_packed_gene_ptr": (_vp, [_vp]),
+    "gecco_crf_packed_attr_id": (_vp, [_vp]),
+    "gecco_crf_packed_annotated": (_vp, [_vp]),
+    "gecco_crf_packed_gene_row": (_vp, [_vp]),
+    "gecco_crf_packed_row_gene": (_vp, [_vp]),
+    "gecco_crf_packed_row_order": (_vp, [_vp]),
+    "gecco_crf_packed_row_ptr": (_vp, [_vp]),
+    "gecco_crf_cluster_rows_build": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_i32p, ctypes.c_int32, _c_f64p, _vp, ctypes.POINTER(_vp)]),
+    "gecco_crf_cluster_rows_free": (None, [_vp]),
+    "gecco_crf_cluster_rows_start": (_vp, [_vp]),
+    "gecco_crf_cluster_rows_end": (_vp, [_vp]),
+    "gecco_crf_cluster_rows_average_p": (_vp, [_vp]),
+    "gecco_crf_cluster_rows_max_p": (_vp, [_vp]),
+    "gecco_crf_cluster_rows_strings": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "gecco_crf_exact_mean": (ctypes.c_double, [_c_f64p, ctypes.c_int64]),
     "gecco_crf_plan_time_windowed": (
         ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]
     ),
@@ -318,6 +340,136 @@ def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, t
         )
     )
     return seg[: n_seg.value].copy()
+
+
+# ---- columnar host side (gecco_crf_pack_columns / gecco_crf_cluster_rows_build) ----------------------
+class _Strings(ctypes.Structure):
+    _fields_ = [("data", _vp), ("offsets", _vp)]
+
+
+class _TableColumns(ctypes.Structure):
+    _fields_ = [("n_rows", ctypes.c_int64), ("sequence_id", _Strings), ("protein_id", _Strings), ("domain", _Strings),
+                ("start", _vp), ("domain_start", _vp), ("n_genes", ctypes.c_int64), ("gene_sequence_id", _Strings),
+                ("gene_protein_id", _Strings), ("gene_start", _vp)]
+
+
+def _view(ptr, n, dtype, owner):
+    """numpy view over `n` items of library-owned memory; `owner` (the handle wrapper) is kept alive by it."""
+    n = int(n)
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    buf._owner = owner
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+def _strings_arg(col, keep):
+    """(data uint8, offsets int64) of a string column -> the C struct; arrays are parked in `keep`."""
+    data = np.ascontiguousarray(col.data, dtype=np.uint8)
+    off = np.ascontiguousarray(col.offsets, dtype=np.int64)
+    if data.size == 0:
+        data = np.zeros(1, dtype=np.uint8)
+    keep.extend((data, off))
+    return _Strings(data.ctypes.data, off.ctypes.data)
+
+
+def _i64_arg(a, keep):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    if a.size == 0:
+        a = np.zeros(1, dtype=np.int64)
+    keep.append(a)
+    return a.ctypes.data
+
+
+class PackedTables:
+    """CSR batch + row bookkeeping of a feature table (and gene table), built by `gecco_crf_pack_columns`.
+    The arrays are views of library-owned memory (pinned when a device is present)."""
+
+    def __init__(self, model: "Model", f_sequence_id, f_protein_id, f_start, f_domain, f_domain_start,
+                 g_sequence_id=None, g_protein_id=None, g_start=None):
+        self._lib = load_library()
+        keep = []
+        t = _TableColumns()
+        t.n_rows = len(f_protein_id)
+        t.sequence_id = _strings_arg(f_sequence_id, keep)
+        t.protein_id = _strings_arg(f_protein_id, keep)
+        t.domain = _strings_arg(f_domain, keep)
+        t.start = _i64_arg(f_start, keep)
+        t.domain_start = _i64_arg(f_domain_start, keep)
+        t.n_genes = 0 if g_protein_id is None else len(g_protein_id)
+        if g_protein_id is not None:
+            t.gene_sequence_id = _strings_arg(g_sequence_id, keep)
+            t.gene_protein_id = _strings_arg(g_protein_id, keep)
+            t.gene_start = _i64_arg(g_start, keep)
+        self._cols, self._keep = t, keep  # the cluster-row builder reads the same columns again
+        h = _vp()
+        _check(self._lib.gecco_crf_pack_columns(model._h, ctypes.byref(t), ctypes.byref(h)))
+        self._h = h
+        ng, nc, dup, unl, pin = (ctypes.c_int32(0) for _ in range(5))
+        nnz = ctypes.c_int64(0)
+        _check(self._lib.gecco_crf_packed_info(h, ctypes.byref(ng), ctypes.byref(nc), ctypes.byref(nnz), ctypes.byref(dup),
+                                               ctypes.byref(unl), ctypes.byref(pin)))
+        self.n_genes, self.n_contigs, self.nnz = ng.value, nc.value, nnz.value
+        self.n_rows = int(t.n_rows)
+        self.n_duplicate_gene_ids, self.n_unlisted_proteins, self.pinned = dup.value, unl.value, bool(pin.value)
+        L = self._lib
+        self.contig_ptr = _view(L.gecco_crf_packed_contig_ptr(h), self.n_contigs + 1, np.int32, self)
+        self.gene_ptr = _view(L.gecco_crf_packed_gene_ptr(h), self.n_genes + 1, np.int32, self)
+        self.attr_id = _view(L.gecco_crf_packed_attr_id(h), self.nnz, np.int32, self)
+        self.annotated = _view(L.gecco_crf_packed_annotated(h), self.n_genes, np.uint8, self)
+        self.gene_row = _view(L.gecco_crf_packed_gene_row(h), self.n_genes, np.int64, self)
+        self.row_gene = _view(L.gecco_crf_packed_row_gene(h), self.n_rows, np.int32, self)
+        self.row_order = _view(L.gecco_crf_packed_row_order(h), self.n_rows, np.int64, self)
+        self.row_ptr = _view(L.gecco_crf_packed_row_ptr(h), self.n_genes + 1, np.int64, self)
+        if self.n_contigs == 0:
+            self.contig_ptr = np.zeros(1, dtype=np.int32)
+        if self.n_genes == 0:
+            self.gene_ptr = np.zeros(1, dtype=np.int32)
+            self.row_ptr = np.zeros(1, dtype=np.int64)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.gecco_crf_packed_free(h)
+
+    def cluster_rows(self, seg, seg_p, seg_off, gene_end, feature_end) -> dict:
+        """Columns of clusters.tsv for `seg` rows: dict of numpy arrays and (data, offsets) string columns."""
+        seg = np.ascontiguousarray(seg, dtype=np.int32).reshape(-1, 4)
+        seg_p = np.ascontiguousarray(seg_p, dtype=np.float64)
+        seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+        keep = []
+        h = _vp()
+        k = len(seg)
+        segb = seg if k else np.zeros((1, 4), dtype=np.int32)
+        spb = seg_p if seg_p.size else np.zeros(1, dtype=np.float64)
+        _check(self._lib.gecco_crf_cluster_rows_build(
+            self._h, ctypes.byref(self._cols), _i64_arg(gene_end if gene_end is not None else [], keep),
+            _i64_arg(feature_end if feature_end is not None else [], keep), _ptr(segb, _c_i32p), k, _ptr(spb, _c_f64p),
+            seg_off.ctypes.data, ctypes.byref(h)))
+        try:
+            L = self._lib
+            out = {
+                "start": _view(L.gecco_crf_cluster_rows_start(h), k, np.int64, None).copy(),
+                "end": _view(L.gecco_crf_cluster_rows_end(h), k, np.int64, None).copy(),
+                "average_p": _view(L.gecco_crf_cluster_rows_average_p(h), k, np.float64, None).copy(),
+                "max_p": _view(L.gecco_crf_cluster_rows_max_p(h), k, np.float64, None).copy(),
+            }
+            for which, name in enumerate(("sequence_id", "cluster_id", "proteins", "domains")):
+                d, o = _vp(), _vp()
+                _check(L.gecco_crf_cluster_rows_strings(h, which, ctypes.byref(d), ctypes.byref(o)))
+                off = _view(o.value, k + 1, np.int64, None).copy()
+                out[name] = (_view(d.value, int(off[-1]) if k else 0, np.uint8, None).copy(), off)
+        finally:
+            self._lib.gecco_crf_cluster_rows_free(h)
+        return out
+
+
+def exact_mean(values) -> float:
+    """``statistics.mean`` of the non-NaN values (exact sum, one rounding), natively."""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    if v.size == 0:
+        return float("nan")
+    return float(load_library().gecco_crf_exact_mean(_ptr(v, _c_f64p), v.size))
 
 
 class _PinnedBlock:

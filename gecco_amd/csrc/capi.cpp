@@ -1,4 +1,5 @@
 // extern "C" surface declared in include/gecco_crf.h.
+#include <cmath>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -9,6 +10,7 @@
 #include "crf_model.hpp"
 #include "crf_plan.hpp"
 #include "crf_session.hpp"
+#include "crf_tables.hpp"
 
 using namespace gecco;
 
@@ -17,6 +19,12 @@ struct gecco_crf_model {
 };
 struct gecco_crf_plan {
     Plan p;
+};
+struct gecco_crf_packed {
+    Packed p;
+};
+struct gecco_crf_cluster_rows {
+    ClusterRows r;
 };
 struct gecco_crf_session {
     Session *s = nullptr;
@@ -602,3 +610,68 @@ GECCO_API int gecco_crf_domain_composition(int32_t device, const int32_t *seg, i
     return check_hip(hipMemcpy(comp_out, d_out.p, out_n * 8, hipMemcpyDeviceToHost), "D2H compositions");
     GECCO_GUARD_END
 }
+
+// ---- columnar host side ---------------------------------------------------------------------------
+GECCO_API int gecco_crf_pack_columns(const gecco_crf_model *m, const gecco_crf_table_columns *t, gecco_crf_packed **out) {
+    if (!m || !t || !out) return GECCO_CRF_EINVAL;
+    *out = nullptr;
+    GECCO_GUARD_BEGIN
+    std::unique_ptr<gecco_crf_packed> h(new gecco_crf_packed());
+    int rc = pack_columns(m->m, *t, h->p);
+    if (rc) return rc;
+    *out = h.release();
+    return GECCO_CRF_OK;
+    GECCO_GUARD_END
+}
+GECCO_API void gecco_crf_packed_free(gecco_crf_packed *p) { delete p; }
+GECCO_API int gecco_crf_packed_info(const gecco_crf_packed *p, int32_t *n_genes, int32_t *n_contigs, int64_t *nnz,
+                                    int32_t *n_duplicate_gene_ids, int32_t *n_unlisted_proteins, int32_t *pinned) {
+    if (!p) return GECCO_CRF_EINVAL;
+    if (n_genes) *n_genes = p->p.n_genes;
+    if (n_contigs) *n_contigs = p->p.n_contigs;
+    if (nnz) *nnz = p->p.nnz;
+    if (n_duplicate_gene_ids) *n_duplicate_gene_ids = p->p.n_duplicate_gene_ids;
+    if (n_unlisted_proteins) *n_unlisted_proteins = p->p.n_unlisted_proteins;
+    if (pinned) *pinned = p->p.pinned ? 1 : 0;
+    return GECCO_CRF_OK;
+}
+GECCO_API const int32_t *gecco_crf_packed_contig_ptr(const gecco_crf_packed *p) { return p ? p->p.contig_ptr : nullptr; }
+GECCO_API const int32_t *gecco_crf_packed_gene_ptr(const gecco_crf_packed *p) { return p ? p->p.gene_ptr : nullptr; }
+GECCO_API const int32_t *gecco_crf_packed_attr_id(const gecco_crf_packed *p) { return p ? p->p.attr_id : nullptr; }
+GECCO_API const uint8_t *gecco_crf_packed_annotated(const gecco_crf_packed *p) { return p ? p->p.annotated : nullptr; }
+GECCO_API const int64_t *gecco_crf_packed_gene_row(const gecco_crf_packed *p) { return p ? p->p.gene_row.data() : nullptr; }
+GECCO_API const int32_t *gecco_crf_packed_row_gene(const gecco_crf_packed *p) { return p ? p->p.row_gene.data() : nullptr; }
+GECCO_API const int64_t *gecco_crf_packed_row_order(const gecco_crf_packed *p) { return p ? p->p.row_order.data() : nullptr; }
+GECCO_API const int64_t *gecco_crf_packed_row_ptr(const gecco_crf_packed *p) { return p ? p->p.row_ptr.data() : nullptr; }
+
+GECCO_API int gecco_crf_cluster_rows_build(const gecco_crf_packed *p, const gecco_crf_table_columns *t, const int64_t *gene_end,
+                                           const int64_t *feature_end, const int32_t *seg, int32_t n_seg, const double *seg_p,
+                                           const int64_t *seg_off, gecco_crf_cluster_rows **out) {
+    if (!p || !t || !out || n_seg < 0 || (n_seg > 0 && (!seg || !seg_p || !seg_off))) return GECCO_CRF_EINVAL;
+    *out = nullptr;
+    if ((t->n_genes > 0 && !gene_end) || (t->n_rows > 0 && !feature_end)) {
+        set_error("cluster_rows: the tables' `end` columns are required");
+        return GECCO_CRF_EINVAL;
+    }
+    GECCO_GUARD_BEGIN
+    std::unique_ptr<gecco_crf_cluster_rows> h(new gecco_crf_cluster_rows());
+    int rc = cluster_rows(p->p, *t, gene_end, feature_end, seg, n_seg, seg_p, seg_off, h->r);
+    if (rc) return rc;
+    *out = h.release();
+    return GECCO_CRF_OK;
+    GECCO_GUARD_END
+}
+GECCO_API void gecco_crf_cluster_rows_free(gecco_crf_cluster_rows *r) { delete r; }
+GECCO_API const int64_t *gecco_crf_cluster_rows_start(const gecco_crf_cluster_rows *r) { return r ? r->r.start.data() : nullptr; }
+GECCO_API const int64_t *gecco_crf_cluster_rows_end(const gecco_crf_cluster_rows *r) { return r ? r->r.end.data() : nullptr; }
+GECCO_API const double *gecco_crf_cluster_rows_average_p(const gecco_crf_cluster_rows *r) { return r ? r->r.average_p.data() : nullptr; }
+GECCO_API const double *gecco_crf_cluster_rows_max_p(const gecco_crf_cluster_rows *r) { return r ? r->r.max_p.data() : nullptr; }
+GECCO_API int gecco_crf_cluster_rows_strings(const gecco_crf_cluster_rows *r, int32_t which, const uint8_t **data,
+                                             const int64_t **offsets) {
+    if (!r || !data || !offsets || which < 0 || which > 3) return GECCO_CRF_EINVAL;
+    const StrOut *c = which == 0 ? &r->r.sequence_id : which == 1 ? &r->r.cluster_id : which == 2 ? &r->r.proteins : &r->r.domains;
+    *data = c->data.data();
+    *offsets = c->offsets.data();
+    return GECCO_CRF_OK;
+}
+GECCO_API double gecco_crf_exact_mean(const double *v, int64_t n) { return (v && n > 0) ? exact_mean(v, n) : std::nan(""); }

@@ -90,7 +90,10 @@ int parse_lcrf(const uint8_t *blob, size_t n, Model &m) {
     const uint32_t L = r.u32(20), A = r.u32(24);
     const size_t off_feat = r.u32(28), off_labels = r.u32(32), off_attrs = r.u32(36), off_lref = r.u32(40),
                  off_aref = r.u32(44);
-    if (L == 0 || L > (1u << 20) || A > (1u << 28)) {
+    // every label and every attribute owns a CQDB record of >= 10 bytes: counts a blob of this size cannot
+    // hold are corruption, and the dense A x L table must stay allocatable (2^28 weights = 2 GiB)
+    if (L == 0 || L > (1u << 20) || A > (1u << 28) || uint64_t(L) * 10 > n || uint64_t(A) * 10 > n ||
+        uint64_t(A) * uint64_t(L) > (1ull << 28)) {
         set_error("lCRF: implausible label/attribute counts");
         return GECCO_CRF_EFORMAT;
     }

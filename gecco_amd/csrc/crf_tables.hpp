@@ -1,0 +1,42 @@
+// Columnar host side of the path: table columns -> CSR batch, called clusters -> clusters.tsv rows.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/gecco_crf.h"
+#include "crf_model.hpp"
+
+namespace gecco {
+
+struct Packed {
+    int32_t n_genes = 0, n_contigs = 0;
+    int64_t nnz = 0;
+    int32_t n_duplicate_gene_ids = 0, n_unlisted_proteins = 0;
+    bool pinned = false;
+    // the CSR batch, in memory the batch driver copies from asynchronously (pinned when a device is present)
+    char *block = nullptr;  // one allocation behind the four arrays
+    int32_t *contig_ptr = nullptr, *gene_ptr = nullptr, *attr_id = nullptr;
+    uint8_t *annotated = nullptr;
+    std::vector<int64_t> gene_row;   // [n_genes] gene-table row of every gene, or -1 - (its first feature row)
+    std::vector<int32_t> row_gene;   // [n_rows]  position (scoring order) of every feature row's gene
+    std::vector<int64_t> row_order;  // [n_rows]  feature rows by (gene position, domain_start), stable
+    std::vector<int64_t> row_ptr;    // [n_genes+1] offsets of every gene's rows in row_order
+    ~Packed();
+};
+
+struct StrOut {
+    std::vector<uint8_t> data;
+    std::vector<int64_t> offsets;
+};
+struct ClusterRows {
+    std::vector<int64_t> start, end;
+    std::vector<double> average_p, max_p;
+    StrOut sequence_id, cluster_id, proteins, domains;
+};
+
+int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out);
+int cluster_rows(const Packed &pk, const gecco_crf_table_columns &t, const int64_t *gene_end, const int64_t *feat_end,
+                 const int32_t *seg, int32_t n_seg, const double *seg_p, const int64_t *seg_off, ClusterRows &out);
+double exact_mean(const double *v, int64_t n);
+
+}  // namespace gecco

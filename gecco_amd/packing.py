@@ -150,6 +150,21 @@ def pack_columns(sequence_id: Sequence[str], protein_id: Sequence[str], start: S
     return PackedColumns(contig_ids, order, contig_ptr, gene_ptr, attr, annotated, row_gene, row_order, row_ptr)
 
 
+def pack_tables(native_model: Any, feats_t: Any, genes_t: Any = None):
+    """Native columnar packer (``gecco_crf_pack_columns``, csrc/crf_tables.cpp): the same result as `pack_columns`
+    from tables whose text columns are in Arrow layout (``tables.StringColumn``), without a Python object per
+    row -- strings are hashed at most once, orders are checked before anything is sorted, and the CSR lands in
+    pinned memory ready for the batch driver.  Returns a ``_native.PackedTables``."""
+    from . import _native
+
+    g = (None, None, None)
+    if genes_t is not None:
+        g = (genes_t.string_column("sequence_id"), genes_t.string_column("protein_id"), genes_t.start)
+    return _native.PackedTables(
+        native_model, feats_t.string_column("sequence_id"), feats_t.string_column("protein_id"), feats_t.start,
+        feats_t.string_column("domain"), feats_t.domain_start, *g)
+
+
 def pack_columns_py(sequence_id: Sequence[str], protein_id: Sequence[str], start: Sequence[int], domain: Sequence[str],
                  domain_start: Sequence[int], attr_index: Dict[str, int], gene_sequence_id: Sequence[str] = None,
                  gene_protein_id: Sequence[str] = None, gene_start: Sequence[int] = None):

@@ -32,6 +32,95 @@ _GENE_COLUMNS = [
 ]
 
 
+try:
+    import pyarrow as _pa
+except ImportError:  # pragma: no cover - pyarrow is optional
+    _pa = None
+
+
+class StringColumn:
+    """A text column in Arrow layout: one utf-8 byte buffer + int64 offsets (``offsets[i]:offsets[i+1]`` is row
+    i).  This is what the native packer (``gecco_crf_pack_columns``) consumes without touching a Python
+    object per row; everything else sees a sequence of ``str`` (``__getitem__``, iteration, ``__array__``)."""
+
+    __slots__ = ("data", "offsets", "_objects")
+
+    def __init__(self, data: np.ndarray, offsets: np.ndarray, objects: Optional[np.ndarray] = None):
+        self.data = np.ascontiguousarray(data, dtype=np.uint8)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self._objects = objects
+
+    @classmethod
+    def from_sequence(cls, seq: Sequence[Any]) -> "StringColumn":
+        if isinstance(seq, StringColumn):
+            return seq
+        objects = seq if isinstance(seq, np.ndarray) and seq.dtype == object else None
+        if _pa is not None:
+            arr = seq if isinstance(seq, (_pa.Array, _pa.ChunkedArray)) else _pa.array(seq, type=_pa.large_string())
+            return cls.from_arrow(arr, objects)
+        enc = [str(x).encode("utf-8") for x in seq]
+        off = np.zeros(len(enc) + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in enc], out=off[1:])
+        return cls(np.frombuffer(b"".join(enc), dtype=np.uint8), off, objects)
+
+    @classmethod
+    def from_arrow(cls, arr: Any, objects: Optional[np.ndarray] = None) -> "StringColumn":
+        if isinstance(arr, _pa.ChunkedArray):
+            arr = arr.combine_chunks() if arr.num_chunks != 1 else arr.chunk(0)
+        if arr.type != _pa.large_string():
+            arr = arr.cast(_pa.large_string())
+        if arr.null_count:
+            arr = arr.fill_null("")
+        _, off_buf, data_buf = arr.buffers()
+        off = np.frombuffer(off_buf, dtype=np.int64)[arr.offset:arr.offset + len(arr) + 1]
+        data = np.frombuffer(data_buf, dtype=np.uint8) if data_buf is not None else np.zeros(0, dtype=np.uint8)
+        if len(off) and off[0] != 0:  # a slice: rebase
+            data, off = data[off[0]:off[-1]], off - off[0]
+        if len(off) == 0:
+            off = np.zeros(1, dtype=np.int64)
+        return cls(data, off, objects)
+
+    def __len__(self) -> int:
+        return len(self.offsets) - 1
+
+    def to_objects(self) -> np.ndarray:
+        if self._objects is None:
+            raw = self.data.tobytes()
+            off = self.offsets.tolist()
+            self._objects = np.array([raw[a:b].decode("utf-8") for a, b in zip(off[:-1], off[1:])] or [], dtype=object)
+        return self._objects
+
+    def __array__(self, dtype=None, copy=None):
+        obj = self.to_objects()
+        return obj if dtype in (None, object) else obj.astype(dtype)
+
+    def __iter__(self):
+        return iter(self.to_objects())
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)):
+            if self._objects is not None:
+                return self._objects[i]
+            a, b = int(self.offsets[i]), int(self.offsets[i + 1])
+            return self.data[a:b].tobytes().decode("utf-8")
+        return self.take(np.arange(len(self))[i])
+
+    def take(self, idx: np.ndarray) -> "StringColumn":
+        idx = np.asarray(idx, dtype=np.int64)
+        lens = self.offsets[idx + 1] - self.offsets[idx]
+        off = np.zeros(len(idx) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        src = np.repeat(self.offsets[idx] - off[:-1], lens) + np.arange(int(off[-1]), dtype=np.int64)
+        return StringColumn(self.data[src], off, None if self._objects is None else self._objects[idx])
+
+    def tolist(self) -> List[str]:
+        return self.to_objects().tolist()
+
+
+def as_string_column(col: Any) -> StringColumn:
+    return col if isinstance(col, StringColumn) else StringColumn.from_sequence(col)
+
+
 def _fmt(v: Any) -> str:
     if v is None:
         return ""
@@ -58,6 +147,13 @@ class _Table:
             if name not in self.columns:
                 self.columns[name] = [default] * n
 
+    def string_column(self, name: str) -> "StringColumn":
+        """The column in Arrow layout (converted once and kept: bulk tables are handed to the native packer)."""
+        col = self.columns[name]
+        if not isinstance(col, StringColumn):
+            col = self.columns[name] = StringColumn.from_sequence(col)
+        return col
+
     def __len__(self) -> int:
         return len(next(iter(self.columns.values()))) if self.columns else 0
 
@@ -72,6 +168,28 @@ class _Table:
         """Columns come back as numpy arrays (object arrays for text) when pandas is available,
         as lists otherwise; floats are parsed correctly rounded either way."""
         types = {name: typ for name, typ, _ in cls.COLUMNS}
+        if _pa is not None:
+            # Arrow's multi-threaded reader: text columns stay in Arrow layout (no Python object per cell),
+            # floats are parsed correctly rounded, an empty numeric cell is NaN, an empty text cell is ""
+            import pyarrow.csv as _pcsv
+
+            tmap = {name: (_pa.float64() if typ is float else _pa.int64() if typ is int else _pa.large_string())
+                    for name, typ in types.items()}
+            tab = _pcsv.read_csv(
+                fh, parse_options=_pcsv.ParseOptions(delimiter="\t", quote_char=False),
+                convert_options=_pcsv.ConvertOptions(column_types=tmap, null_values=[""], strings_can_be_null=False))
+            cols: Dict[str, Any] = {}
+            for h in tab.column_names:
+                c = tab.column(h)
+                if _pa.types.is_large_string(c.type) or _pa.types.is_string(c.type):
+                    cols[h] = StringColumn.from_arrow(c)
+                elif _pa.types.is_floating(c.type):
+                    cols[h] = c.to_numpy(zero_copy_only=False).astype(np.float64, copy=False)
+                elif _pa.types.is_integer(c.type):
+                    cols[h] = c.to_numpy(zero_copy_only=False).astype(np.int64, copy=False)
+                else:
+                    cols[h] = np.array(c.to_pylist(), dtype=object)
+            return cls(cols)
         if _pd is not None:
             dt = {name: (np.float64 if typ is float else np.int64 if typ is int else str) for name, typ in types.items()}
             df = _pd.read_csv(fh, sep="\t", dtype=dt, keep_default_na=False,
@@ -110,7 +228,8 @@ class _Table:
         names = self._dump_columns()
         if _pd is not None and len(self) > 64:
             # floats are written with repr() digits (shortest round trip), NaN as an empty field
-            _pd.DataFrame({n: self.columns[n] for n in names}, columns=names).to_csv(
+            _pd.DataFrame({n: (self.columns[n].to_objects() if isinstance(self.columns[n], StringColumn) else self.columns[n])
+                           for n in names}, columns=names).to_csv(
                 fh, sep="\t", index=False, na_rep="", quoting=csv.QUOTE_NONE, lineterminator="\n")
             return
         own = isinstance(fh, str)

@@ -209,6 +209,62 @@ int gecco_crf_session_clusters(gecco_crf_session *s, const int32_t *contig_ptr, 
                                int32_t *n_seg, double *seg_p_out /* or NULL */, int64_t max_seg_genes,
                                int64_t *seg_off_out /* max_seg + 1, with seg_p_out */);
 
+/* ---- columnar host side: table columns -> CSR batch, called clusters -> clusters.tsv rows --------
+ * Strings travel as Arrow-style columns: one byte buffer + int64 offsets[n+1] per column (what
+ * pandas / polars / pyarrow hold them in).  gecco_crf_pack_columns does, on columns, what the reference
+ * does on Gene objects before the tagger sees them: genes by (sequence_id, start) with ties in
+ * first-appearance order (sorted() is stable, gecco/crf/__init__.py:199-206), a gene's domains by
+ * domain_start (:200-201), repeated names collapsed (crf/features.py:31-35), names the model does not know
+ * dropped ([EXT] CRFsuite attribute lookup).  Feature rows: one per domain hit (gecco/model.py:629-642);
+ * gene rows (optional, so that genes without any domain are kept): one per gene (:781-789).  The CSR lands
+ * in pinned memory when a device is present.  Pointers returned by the accessors live as long as the handle. */
+typedef struct {
+    const uint8_t *data;
+    const int64_t *offsets;
+} gecco_crf_strings;
+typedef struct {
+    int64_t n_rows; /* feature table */
+    gecco_crf_strings sequence_id, protein_id, domain;
+    const int64_t *start, *domain_start;
+    int64_t n_genes; /* gene table, may be 0 */
+    gecco_crf_strings gene_sequence_id, gene_protein_id;
+    const int64_t *gene_start;
+} gecco_crf_table_columns;
+typedef struct gecco_crf_packed gecco_crf_packed;
+typedef struct gecco_crf_cluster_rows gecco_crf_cluster_rows;
+int gecco_crf_pack_columns(const gecco_crf_model *m, const gecco_crf_table_columns *t, gecco_crf_packed **out);
+void gecco_crf_packed_free(gecco_crf_packed *p);
+/* Sizes and diagnostics (any pointer may be NULL): duplicated ids in the gene table (the last row of an id
+ * stands for it) and proteins of the feature table the gene table does not list -- the reference raises on
+ * both (`annotate_genes`, gecco/cli/commands/_common.py), callers that mirror it check these. */
+int gecco_crf_packed_info(const gecco_crf_packed *p, int32_t *n_genes, int32_t *n_contigs, int64_t *nnz,
+                          int32_t *n_duplicate_gene_ids, int32_t *n_unlisted_proteins, int32_t *pinned);
+const int32_t *gecco_crf_packed_contig_ptr(const gecco_crf_packed *p); /* [n_contigs+1] */
+const int32_t *gecco_crf_packed_gene_ptr(const gecco_crf_packed *p);   /* [n_genes+1] */
+const int32_t *gecco_crf_packed_attr_id(const gecco_crf_packed *p);    /* [nnz] */
+const uint8_t *gecco_crf_packed_annotated(const gecco_crf_packed *p);  /* [n_genes] has >= 1 feature row */
+const int64_t *gecco_crf_packed_gene_row(const gecco_crf_packed *p);   /* [n_genes] gene-table row, or -1 - first feature row */
+const int32_t *gecco_crf_packed_row_gene(const gecco_crf_packed *p);   /* [n_rows] gene position of every feature row */
+const int64_t *gecco_crf_packed_row_order(const gecco_crf_packed *p);  /* [n_rows] rows by (gene position, domain_start) */
+const int64_t *gecco_crf_packed_row_ptr(const gecco_crf_packed *p);    /* [n_genes+1] */
+/* Rows of clusters.tsv (gecco/model.py:731-760) for segments as returned by gecco_crf_session_clusters:
+ * start / end over the member genes (gene_end: the gene table's `end`, feature_end: the feature table's),
+ * average_p = statistics.mean of the members' probabilities, exactly rounded (:442-447), max_p, the sorted
+ * protein ids and the sorted domain names joined by ';', "<sequence_id>_cluster_<number>". */
+int gecco_crf_cluster_rows_build(const gecco_crf_packed *p, const gecco_crf_table_columns *t, const int64_t *gene_end,
+                                 const int64_t *feature_end, const int32_t *seg, int32_t n_seg, const double *seg_p,
+                                 const int64_t *seg_off, gecco_crf_cluster_rows **out);
+void gecco_crf_cluster_rows_free(gecco_crf_cluster_rows *r);
+const int64_t *gecco_crf_cluster_rows_start(const gecco_crf_cluster_rows *r);
+const int64_t *gecco_crf_cluster_rows_end(const gecco_crf_cluster_rows *r);
+const double *gecco_crf_cluster_rows_average_p(const gecco_crf_cluster_rows *r);
+const double *gecco_crf_cluster_rows_max_p(const gecco_crf_cluster_rows *r);
+/* which: 0 sequence_id, 1 cluster_id, 2 proteins, 3 domains */
+int gecco_crf_cluster_rows_strings(const gecco_crf_cluster_rows *r, int32_t which, const uint8_t **data,
+                                   const int64_t **offsets);
+/* statistics.mean of the non-NaN values: the exact sum divided by the count, rounded once. */
+double gecco_crf_exact_mean(const double *v, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

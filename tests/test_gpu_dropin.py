@@ -131,3 +131,115 @@ def test_multi_device_sharding_code_path(oracle_model):
     a = [g.average_probability for g in one.predict_probabilities(list(genes))]
     b = [g.average_probability for g in two.predict_probabilities(list(genes))]
     assert a == b
+
+
+def _random_tables(rng, n_contigs, attrs, shuffle):
+    """Gene + feature tables of `n_contigs` contigs (lengths 3..120: some shorter than the window)."""
+    from gecco_amd import tables
+
+    g_sid, g_pid, g_start, g_end = [], [], [], []
+    f_rows = []
+    for c in range(n_contigs):
+        n = int(rng.integers(3, 120))
+        pos = 0
+        for i in range(n):
+            pos += int(rng.integers(50, 900))
+            g_sid.append(f"ctg{c:03d}")
+            g_pid.append(f"ctg{c:03d}_{i}")
+            g_start.append(pos)
+            g_end.append(pos + int(rng.integers(60, 800)))
+            for _ in range(int(rng.integers(0, 4))):
+                f_rows.append((g_sid[-1], g_pid[-1], g_start[-1], g_end[-1], attrs[int(rng.integers(0, len(attrs)))],
+                               int(rng.integers(1, 200))))
+    gi = np.arange(len(g_pid))
+    fi = np.arange(len(f_rows))
+    if shuffle:
+        rng.shuffle(gi)
+        rng.shuffle(fi)
+    genes_t = tables.GeneTable({"sequence_id": np.array(g_sid, dtype=object)[gi], "protein_id": np.array(g_pid, dtype=object)[gi],
+                                "start": np.array(g_start)[gi], "end": np.array(g_end)[gi],
+                                "strand": np.full(len(gi), "+", dtype=object)})
+    fr = [f_rows[i] for i in fi]
+    feats_t = tables.FeatureTable({
+        "sequence_id": np.array([r[0] for r in fr], dtype=object), "protein_id": np.array([r[1] for r in fr], dtype=object),
+        "start": np.array([r[2] for r in fr]), "end": np.array([r[3] for r in fr]), "strand": np.full(len(fr), "+", dtype=object),
+        "domain": np.array([r[4] for r in fr], dtype=object), "hmm": np.full(len(fr), "Pfam", dtype=object),
+        "i_evalue": np.full(len(fr), 1e-10), "pvalue": np.full(len(fr), 1e-12),
+        "domain_start": np.array([r[5] for r in fr]), "domain_end": np.array([r[5] + 10 for r in fr])})
+    return genes_t, feats_t
+
+
+@pytest.mark.parametrize("shuffle,pad", [(False, True), (True, True), (True, False)])
+def test_columnar_predict_equals_object_path(oracle_model, shuffle, pad):
+    """predict_tables (native packer -> batch driver -> resident refiner -> native cluster rows) against the
+    object path (predict_probabilities + ClusterRefiner per contig, i.e. what `gecco run` does with Gene
+    objects) on random tables, in order and shuffled, with and without padding."""
+    import warnings
+
+    from gecco_amd import predict, tables
+    from gecco_amd.crf import ClusterCRF
+    from gecco_amd.refine import ClusterRefiner
+
+    rng = np.random.default_rng(21)
+    genes_t, feats_t = _random_tables(rng, 40, oracle_model["attrs"][:400], shuffle)
+    crf = ClusterCRF.trained(GOLDEN)
+    with warnings.catch_warnings(record=True) as w_col:
+        warnings.simplefilter("always")
+        g_out, f_out, c_out = predict.predict_tables(genes_t, feats_t, crf, pad=pad, threshold=0.3, n_cds=2)
+    # object path on the same data
+    by_pid = {g.protein.id: g for g in genes_t.to_genes()}
+    for g in feats_t.to_genes():
+        by_pid[g.protein.id].protein.domains.extend(g.protein.domains)
+    with warnings.catch_warnings(record=True) as w_obj:
+        warnings.simplefilter("always")
+        annotated = crf.predict_probabilities(list(by_pid.values()), pad=pad)
+    assert sorted(str(x.message) for x in w_col) == sorted(str(x.message) for x in w_obj)
+    assert list(g_out.protein_id) == [g.protein.id for g in annotated]
+    exp_p = np.array([np.nan if g.average_probability is None else g.average_probability for g in annotated])
+    np.testing.assert_array_equal(np.isnan(g_out.average_p), np.isnan(exp_p))
+    assert np.nanmax(np.abs(g_out.average_p - exp_p)) == 0.0  # same kernels, same order: bit-identical
+    refiner = ClusterRefiner(threshold=0.3, n_cds=2)
+    clusters = []
+    import itertools
+
+    for _, group in itertools.groupby(annotated, key=lambda g: g.source.id):
+        clusters.extend(refiner.iter_clusters(list(group)))
+    exp_t = tables.ClusterTable.from_clusters(clusters)
+    assert len(c_out) == len(exp_t) and len(exp_t) > 5
+    for name in ("sequence_id", "cluster_id", "start", "end", "average_p", "max_p", "proteins", "domains"):
+        assert list(c_out.columns[name]) == list(exp_t.columns[name]), name
+    # every domain row carries its gene's probability
+    p_of = {g.protein.id: g.average_probability for g in annotated}
+    exp_fp = np.array([np.nan if p_of[pid] is None else p_of[pid] for pid in feats_t.protein_id])
+    np.testing.assert_array_equal(f_out.cluster_probability, exp_fp)
+
+
+def test_columnar_predict_refuses_inconsistent_tables(oracle_model):
+    """The reference raises when the tables do not describe the same genes (annotate_genes); so does this path."""
+    from gecco_amd import predict, tables
+    from gecco_amd.crf import ClusterCRF
+
+    rng = np.random.default_rng(22)
+    genes_t, feats_t = _random_tables(rng, 3, oracle_model["attrs"][:50], False)
+    crf = ClusterCRF.trained(GOLDEN)
+    cols = {k: np.asarray(v).copy() for k, v in feats_t.columns.items()}
+    cols["protein_id"][0] = "not_in_the_gene_table"
+    with pytest.raises(ValueError, match="missing from the gene table"):
+        predict.predict_tables(genes_t, tables.FeatureTable(cols), crf)
+    gcols = {k: np.asarray(v).copy() for k, v in genes_t.columns.items()}
+    gcols["protein_id"][1] = gcols["protein_id"][0]
+    with pytest.raises(ValueError, match="duplicated protein ids"):
+        predict.predict_tables(tables.GeneTable(gcols), feats_t, crf)
+
+
+def test_filter_features_is_filter_domains():
+    from gecco_amd import predict, tables
+
+    f = tables.FeatureTable.load(os.path.join(GOLDEN, "BGC0001866.features.tsv"))
+    assert predict.filter_features(f, None, 1e-9) is f  # the fixture's largest p-value is 3e-10
+    g = predict.filter_features(f, None, 1e-20)
+    keep = np.asarray(f.pvalue) < 1e-20
+    assert 0 < len(g) == int(keep.sum()) < len(f)
+    assert list(g.domain) == [d for d, k in zip(f.domain, keep) if k]
+    h = predict.filter_features(f, 1e-30, None)
+    assert len(h) == int((np.asarray(f.i_evalue) < 1e-30).sum())

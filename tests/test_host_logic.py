@@ -373,3 +373,130 @@ def test_domain_feature_mode(oracle_engine, trained, monkeypatch):
             assert g._probability is not None
     two = [g for g in out if len(g.protein.domains) == 2]
     assert any(g.protein.domains[0].probability != g.protein.domains[1].probability for g in two)
+
+
+@pytest.mark.parametrize("threads,grain", [(1, 16384), (5, 3), (16, 1)])
+def test_native_column_packer_equals_row_by_row_statement(monkeypatch, threads, grain):
+    """`gecco_crf_pack_columns` (csrc/crf_tables.cpp: Arrow-layout strings, interning with adjacency shortcuts,
+    order checks + radix sorts) against `pack_columns_py` on the same random tables as above, plus tables that
+    are already in order (the fast paths) and coordinates that do not fit the radix keys."""
+    from gecco_amd import _native as nat
+
+    # the per-row passes run on several host threads for large tables: cut these tiny ones the same way
+    monkeypatch.setenv("GECCO_CRF_HOST_THREADS", str(threads))
+    monkeypatch.setenv("GECCO_CRF_HOST_GRAIN", str(grain))
+    A = 12
+    model = nat.Model.from_tables(np.zeros((A, 2)), np.zeros((2, 2)))  # attribute names "a0" .. "a11"
+    idx = {f"a{i}": i for i in range(A)}
+    rng = np.random.default_rng(1)
+    for trial in range(300):
+        ng, nf = int(rng.integers(0, 40)), int(rng.integers(0, 80))
+        nsid, ndom = int(rng.integers(1, 5)), int(rng.integers(1, 16))
+        sids = [f"c{int(i):03d}" for i in rng.integers(0, nsid, size=ng)]
+        pids = [f"p{i}" for i in range(ng)]
+        big = 1 << 45 if trial % 11 == 0 else 50
+        starts = rng.integers(-3 if trial % 5 == 0 else 0, big, size=ng).tolist()
+        if trial % 4 == 0:  # a table GECCO wrote: genes in order, feature rows following them
+            order = sorted(range(ng), key=lambda i: (sids[i], starts[i]))
+            sids, starts = [sids[i] for i in order], [starts[i] for i in order]
+            fi = np.sort(rng.integers(0, max(ng, 1), size=nf)) if ng else rng.integers(0, 3, size=nf)
+        else:
+            fi = rng.integers(0, ng + 3, size=nf)
+        if trial % 7 == 0 and ng > 3:
+            pids[3] = pids[1]
+        f_sid = [sids[i] if i < ng else "zz" for i in fi]
+        f_pid = [pids[i] if i < ng else f"x{i}" for i in fi]
+        f_start = [starts[i] if i < ng else 7 for i in fi]
+        f_dom = [f"a{int(i)}" if i < A else f"unknown{int(i)}" for i in rng.integers(0, ndom, size=nf)]
+        f_ds = rng.integers(0, 6 if trial % 13 else (1 << 40), size=nf).tolist()
+        args = (f_sid, f_pid, f_start, f_dom, f_ds, idx)
+        S = tables.StringColumn.from_sequence
+        gargs = (None, None, None)
+        if trial % 3:
+            args += (sids, pids, starts)
+            gargs = (S(sids), S(pids), np.array(starts, dtype=np.int64))
+        a = packing.pack_columns_py(*args)
+        b = nat.PackedTables(model, S(f_sid), S(f_pid), np.array(f_start, dtype=np.int64), S(f_dom),
+                             np.array(f_ds, dtype=np.int64), *gargs)
+        n = len(a[1])
+        assert b.n_genes == n and b.n_contigs == len(a[0]), trial
+        all_pid = (pids if trial % 3 else [])
+        names = [all_pid[r] if r >= 0 else f_pid[-1 - r] for r in b.gene_row.tolist()]
+        assert names == list(a[1]), trial
+        assert b.contig_ptr.tolist() == a[2].tolist() and b.gene_ptr.tolist() == a[3].tolist(), trial
+        assert b.attr_id.tolist() == a[4].tolist() and b.annotated.tolist() == a[5].tolist(), trial
+        for k in range(n):
+            rows = b.row_order[b.row_ptr[k]:b.row_ptr[k + 1]]
+            exp = sorted([r for r in range(nf) if f_pid[r] == names[k]], key=lambda r: f_ds[r])
+            assert rows.tolist() == exp, trial
+            assert all(b.row_gene[r] == k for r in exp), trial
+        if trial % 3:
+            assert b.n_duplicate_gene_ids == (1 if (trial % 7 == 0 and ng > 3) else 0), trial
+            assert b.n_unlisted_proteins == (len({p for p in f_pid if p not in set(pids)}) if ng else 0), trial
+
+
+def test_exact_mean_is_statistics_mean():
+    """average_p of a cluster is `statistics.mean` (gecco/model.py:442-447): exact sum, ONE rounding."""
+    import statistics
+
+    from gecco_amd import _native as nat
+
+    rng = np.random.default_rng(2)
+    for trial in range(400):
+        k = int(rng.integers(1, 60))
+        kind = trial % 5
+        if kind == 0:
+            v = rng.random(k)
+        elif kind == 1:
+            v = 1.0 - rng.random(k) * 1e-9         # saturated probabilities: the interesting case
+        elif kind == 2:
+            v = rng.random(k) * 10.0 ** rng.integers(-320, 10, size=k)   # subnormals, huge spread
+        elif kind == 3:
+            v = np.full(k, 0.1)
+        else:
+            v = np.ldexp(rng.integers(1, 1 << 53, size=k).astype(np.float64), int(rng.integers(-1074 - 30, -1000)))
+        assert nat.exact_mean(v) == statistics.mean(v.tolist()), (trial, v)
+    assert np.isnan(nat.exact_mean([float("nan")])) and nat.exact_mean([float("nan"), 0.25, 0.5]) == 0.375
+    assert nat.exact_mean([5e-324, 5e-324, 0.0]) == statistics.mean([5e-324, 5e-324, 0.0])
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_native_cluster_rows_match_python_assembly(monkeypatch, threads):
+    import statistics
+
+    from gecco_amd import _native as nat
+
+    monkeypatch.setenv("GECCO_CRF_HOST_THREADS", str(threads))
+    monkeypatch.setenv("GECCO_CRF_HOST_GRAIN", "1")
+
+    model = nat.Model.from_tables(np.zeros((4, 2)), np.zeros((2, 2)))
+    S = tables.StringColumn.from_sequence
+    rng = np.random.default_rng(3)
+    ng = 60
+    sids = ["ctgB"] * 30 + ["ctgA"] * 30
+    pids = [f"g{rng.integers(0, 1000):03d}_{i}" for i in range(ng)]
+    starts = (np.arange(ng) % 30 * 100).astype(np.int64)
+    ends = starts + rng.integers(50, 500, size=ng)
+    fi = np.sort(rng.integers(0, ng, size=150))
+    f_dom = [f"PF{rng.integers(0, 30):05d}" for _ in fi]
+    pk = nat.PackedTables(model, S([sids[i] for i in fi]), S([pids[i] for i in fi]), starts[fi], S(f_dom),
+                          rng.integers(0, 300, size=len(fi)).astype(np.int64), S(sids), S(pids), starts)
+    order = [pids[r] for r in pk.gene_row.tolist()]
+    p = rng.random(ng)
+    seg = np.array([[0, 1, 2, 9], [0, 3, 12, 13], [1, 1, 30, 55], [1, 2, 58, 58]], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(seg[:, 3] - seg[:, 2])]).astype(np.int64)
+    seg_p = np.concatenate([p[a:b] for _, _, a, b in seg.tolist()])
+    cr = pk.cluster_rows(seg, seg_p, off, ends, ends[fi])
+    col = lambda name: tables.StringColumn(*cr[name]).tolist()
+    for k, (c, number, a, b) in enumerate(seg.tolist()):
+        rows = pk.gene_row[a:b]
+        cid = ["ctgA", "ctgB"][c]
+        assert col("sequence_id")[k] == (cid if b > a else "") and col("cluster_id")[k] == (cid if b > a else "") + f"_cluster_{number}"
+        assert col("proteins")[k] == ";".join(sorted(order[a:b]))
+        drows = pk.row_order[pk.row_ptr[a]:pk.row_ptr[b]]
+        assert col("domains")[k] == ";".join(sorted(f_dom[r] for r in drows))
+        if b > a:
+            assert cr["start"][k] == starts[rows].min() and cr["end"][k] == ends[rows].max()
+            assert cr["average_p"][k] == statistics.mean(p[a:b].tolist()) and cr["max_p"][k] == p[a:b].max()
+        else:
+            assert np.isnan(cr["average_p"][k]) and np.isnan(cr["max_p"][k])

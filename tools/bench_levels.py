@@ -108,12 +108,18 @@ def main():
         "strand": np.full(nf, "+", dtype=object), "domain": doms, "hmm": np.full(nf, "Pfam", dtype=object),
         "i_evalue": np.full(nf, 1e-10), "pvalue": np.full(nf, 1e-12), "domain_start": rng.integers(1, 300, size=nf),
         "domain_end": np.full(nf, 300)})
-    predict.predict_tables(genes_t, feats_t, crf)  # warm
-    t0 = time.perf_counter()
-    g_out, f_out, c_out = predict.predict_tables(genes_t, feats_t, crf)
-    dt = time.perf_counter() - t0
+    predict.predict_tables(genes_t, feats_t, crf)  # warm: text columns go to Arrow layout once, buffers get sized
+    predict.predict_tables(genes_t, feats_t, crf)
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        g_out, f_out, c_out = predict.predict_tables(genes_t, feats_t, crf)
+        ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]
     out["columnar_tables_api"] = {"genes": ng, "domain_rows": nf, "clusters": len(c_out), "ms": dt * 1e3, "genes_per_s": ng / dt,
-                                  "note": "pack_columns + one-shot ABI (marginals, segmentation) + output columns"}
+                                  "ms_all": [round(t * 1e3, 2) for t in ts],
+                                  "note": "median of 7: native packer (table columns -> CSR in pinned memory) + batch driver "
+                                          "(marginals + refiner on the device) + native cluster rows + output columns"}
     with tempfile.TemporaryDirectory() as tmp:
         gp_, fp_ = os.path.join(tmp, "x.genes.tsv"), os.path.join(tmp, "x.features.tsv")
         genes_t.dump(gp_)
