@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""rocprofv3 PMC passes (rocpd sqlite, one pass per counter group: tools/profile.sh) -> profiles/pmc_traffic.json,
+the per-launch counter figures bench.py quotes next to its live timings.
+usage: pmc_to_json.py <dir-with-pmc*/ dbs> <workload> <tag> [kernel-substring]"""
+import datetime
+import glob
+import json
+import os
+import re
+import sqlite3
+import sys
+
+
+def main():
+    root, workload, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    pat = sys.argv[4] if len(sys.argv) > 4 else "crf_windowed_l2"
+    vals, kernel = {}, None
+    for db in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
+        con = sqlite3.connect(db)
+        try:
+            rows = list(con.execute(
+                "select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                "where kernel_name like ? group by kernel_name, counter_name", (f"%{pat}%",)))
+        except sqlite3.Error:
+            rows = []
+        for k, c, v, n in rows:
+            vals[c] = float(v)
+            mm = re.search(r"(crf_\w+<[^>]*>|crf_\w+|\w+)\(", k.replace("(anonymous namespace)::", ""))
+            kernel = mm.group(1) if mm else k
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        raise SystemExit(f"no FETCH_SIZE / WRITE_SIZE for a kernel matching {pat!r} under {root}")
+    out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    try:
+        doc = json.load(open(out_path))
+    except Exception:
+        doc = {}
+    entry = {
+        # MI355X_MICROARCH.md, HBM / rocprofv3 section: FETCH_SIZE and WRITE_SIZE are in KiB;
+        # gfx950 under-reports the read side by 2x (64-B requests counted as 32 B)
+        "hbm_bytes_per_launch": int(round(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)),
+        "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+        "kernel": kernel,
+        "source": f"profiles/{tag}_pmc.json <- gpurun_out/{tag}/pmc*: rocprofv3 --pmc passes of `bench.py --windowed-only` "
+                  f"({datetime.date.today().isoformat()}), FETCH_SIZE x2 (gfx950 read-side correction) + WRITE_SIZE",
+    }
+    for c in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
+              "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM", "GRBM_GUI_ACTIVE", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+              "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS"):
+        if c in vals:
+            entry[c] = vals[c]
+    doc[workload] = entry
+    json.dump(doc, open(out_path, "w"), indent=1)
+    json.dump({workload: dict(entry, all_counters=vals)}, open(os.path.join(os.path.dirname(out_path), f"{tag}_pmc.json"), "w"), indent=1)
+    print(json.dumps(entry, indent=1))
+
+
+if __name__ == "__main__":
+    main()

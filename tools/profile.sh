@@ -8,10 +8,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
-B="python bench.py --no-cpu-baseline $*"
+B="python bench.py --no-cpu-baseline --no-past-l3 $*"
 # kernel trace of the default bench run (device pre-roll + 100 warmup + 1000 timed steps + 200 kernel timings)
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B > $O/kt.log 2>&1
-S="--steps 3 --warmup 1 --kernel-iters 3 --preroll-ms 0"  # few dispatches: the PMC passes serialise and slow every launch
+S="--steps 3 --warmup 1 --kernel-iters 3 --preroll-ms 0 --windowed-only --no-past-l3"  # few dispatches of ONE kind (plain windowed launches): the PMC passes serialise and slow every launch
 timeout 180 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc1 -o pmc1 -- $B $S > $O/pmc1.log 2>&1
 timeout 180 rocprofv3 --pmc FETCH_SIZE -d $O/pmc2 -o pmc2 -- $B $S > $O/pmc2.log 2>&1
 timeout 180 rocprofv3 --pmc WRITE_SIZE -d $O/pmc3 -o pmc3 -- $B $S > $O/pmc3.log 2>&1
@@ -19,4 +19,5 @@ timeout 180 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE 
 timeout 180 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc5 -o pmc5 -- $B $S > $O/pmc5.log 2>&1
 timeout 180 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $O/pmc6 -o pmc6 -- $B $S > $O/pmc6.log 2>&1
 python tools/prof_summary.py $O crf_ > $O/summary.txt 2>&1
+python tools/pmc_to_json.py $O C3 $TAG > $O/pmc.json 2>&1
 cat $O/summary.txt
