@@ -102,8 +102,10 @@ struct SeqArgs {
     const double2 *state;    // [n_genes]  (s[label 0], s[label 1])
     const double *dstate;    // [n_genes]  s[1] - s[0]: all the difference-form Viterbi needs (8 B/gene)
     const uint8_t *flags;    // [n_genes]  bit0: first gene of a contig, bit1: last gene
-    const int32_t *blk_cs;   // [blocks]   first gene of the contig that the block's first gene belongs to
+    const int32_t *cblk;     // [n_cblocks+1] short contigs only: first gene of every workgroup of WHOLE contigs (<= kSeqBlockGenes genes)
+    int32_t n_cblocks;
     int32_t short_contigs;   // 1: no contig is longer than one scan block (kSeqBlockGenes)
+    const double *smax;      // [n_genes] or null: max(s[0], s[1]) next to dstate (whole-contig marginals with log Z)
     int32_t n_contigs, n_genes;
     double m00, m01, m10, m11;  // exp(trans - mx)
     double t00, t01, t10, t11;  // raw transition weights (Viterbi)
@@ -126,6 +128,8 @@ struct SeqArgs {
 hipError_t launch_seq_state(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_attrs, int n_genes,
                             double2 *state, hipStream_t stream);
 hipError_t launch_seq_marginals(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream);
+hipError_t launch_seq_marginals_short(const SeqArgs &a, const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01,
+                                      int n_attrs, const int32_t *d_contig_ptr, hipStream_t stream);
 hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream);
 // labels only, from a.dstate; needs trans[0][1] - trans[1][1] <= trans[0][0] - trans[1][0]
 hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream);

@@ -569,28 +569,39 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
     int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
     if (rc) return rc;
     const size_t n = size_t(p.n_genes);
-    const size_t nb = (n + kSeqBlockGenes - 1) / kSeqBlockGenes;
-    const size_t o_flags = 0, o_blk = align256p(n + 8), bytes = o_blk + align256p((nb ? nb : 1) * 4);
+    // short contigs (none longer than a scan block): whole contigs are packed into workgroups of <= 2048 genes
+    p.seq_short = true;
+    for (int32_t c = 0; c < p.n_contigs && p.seq_short; ++c)
+        if (p.contig_ptr[c + 1] - p.contig_ptr[c] > kSeqBlockGenes) p.seq_short = false;
+    std::vector<int32_t> &cblk = p.irr_prefix;  // scratch
+    cblk.clear();
+    if (p.seq_short && n) {
+        int32_t start = 0;
+        cblk.push_back(0);
+        for (int32_t c = 0; c < p.n_contigs; ++c) {
+            const int32_t g1 = p.contig_ptr[c + 1];
+            if (g1 - start > kSeqBlockGenes) {  // contig c does not fit any more: close the workgroup before it
+                start = p.contig_ptr[c];
+                cblk.push_back(start);
+            }
+        }
+        cblk.push_back(int32_t(n));
+    }
+    p.n_cblocks = cblk.empty() ? 0 : int32_t(cblk.size()) - 1;
+    const size_t o_flags = 0, o_blk = align256p(n + 8), bytes = o_blk + align256p((cblk.size() + 1) * 4);
     if ((rc = p.seq.reserve(bytes, "contig flags"))) return rc;
     uint8_t *flags = reinterpret_cast<uint8_t *>(p.seq.h + o_flags);
-    int32_t *blk_cs = reinterpret_cast<int32_t *>(p.seq.h + o_blk);
     std::memset(flags, 0, n + 8);
-    for (size_t b = 0; b < (nb ? nb : 1); ++b) blk_cs[b] = 0;
-    // per scan block: where the contig of its first gene starts; and whether every contig fits a block
-    p.seq_short = true;
-    size_t b = 0;
     for (int32_t c = 0; c < p.n_contigs; ++c) {
         const int32_t g0 = p.contig_ptr[c], g1 = p.contig_ptr[c + 1];
         if (g1 > g0) {
             flags[g0] |= 1;
             flags[g1 - 1] |= 2;
         }
-        if (g1 - g0 > kSeqBlockGenes) p.seq_short = false;
-        for (; b < nb && int64_t(b) * kSeqBlockGenes < g1; ++b)
-            if (int64_t(b) * kSeqBlockGenes >= g0) blk_cs[b] = g0;
     }
+    if (!cblk.empty()) std::memcpy(p.seq.h + o_blk, cblk.data(), cblk.size() * 4);
     p.d_seq_flags = reinterpret_cast<uint8_t *>(p.seq.d + o_flags);
-    p.d_seq_blk_cs = reinterpret_cast<int32_t *>(p.seq.d + o_blk);
+    p.d_seq_cblk = reinterpret_cast<int32_t *>(p.seq.d + o_blk);
     // launches that read the tables must be ordered behind this copy: `sync` (any stream may follow), or the
     // caller keeps to `stream` (the batch driver)
     if ((rc = check_hip(hipMemcpyAsync(p.seq.d, p.seq.h, bytes, hipMemcpyHostToDevice, stream), "upload contig flags"))) return rc;
@@ -634,7 +645,8 @@ int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
     a.fLaneSuf = reinterpret_cast<FE *>(w + l.off_flanesuf);
     a.fBlockSuf = reinterpret_cast<FE *>(w + l.off_fblocksuf);
     a.flags = p.d_seq_flags;
-    a.blk_cs = p.d_seq_blk_cs;
+    a.cblk = p.d_seq_cblk;
+    a.n_cblocks = p.n_cblocks;
     a.short_contigs = p.seq_short ? 1 : 0;
     a.n_contigs = p.n_contigs;
     a.n_genes = p.n_genes;
@@ -685,6 +697,11 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
     }
     a.marg = d_marg;
     a.lognorm = d_lognorm;
+    if (p.seq_short) {  // whole contigs per workgroup: 8-byte inputs, one fused kernel (alpha is parked in the state area)
+        a.smax = reinterpret_cast<const double *>(a.alpha);
+        return check_hip(launch_seq_marginals_short(a, d_gene_ptr, d_attr_id, p.tables_model->wtab2[1], p.model->A, p.d_contig_ptr,
+                                                    stream), "marginals launch");
+    }
     // wtab2[1] holds (w[a][0], w[a][1]) = (other, label) pairs for label 1
     if ((rc = check_hip(launch_seq_state(d_gene_ptr, d_attr_id, p.tables_model->wtab2[1], p.model->A, p.n_genes,
                                          const_cast<double2 *>(a.state), stream), "state score launch")))

@@ -63,8 +63,9 @@ struct Plan {
     Arena seq;
     bool seq_ready = false;
     uint8_t *d_seq_flags = nullptr;
-    int32_t *d_seq_blk_cs = nullptr;  // per 2048-gene scan block: first gene of the contig its first gene belongs to
-    bool seq_short = false;           // no contig longer than one scan block: Viterbi looks back by recomputation
+    int32_t *d_seq_cblk = nullptr;    // short contigs: first gene of every workgroup of whole contigs (<= 2048 genes), [n_cblocks+1]
+    int32_t n_cblocks = 0;
+    bool seq_short = false;           // no contig longer than one scan block: whole contigs per workgroup, one launch per decoder
     // workspaces, allocated on first use, grow-only
     char *d_seq_ws = nullptr, *d_gen_ws = nullptr, *d_seg_ws = nullptr;
     double *d_win_scratch = nullptr;

@@ -523,63 +523,42 @@ __global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
     if (slot == 0) A.vBlockMap[blockIdx.x] = total;
 }
 
-// ---- short contigs: fold + replay in one kernel, looking back by RECOMPUTATION --------------------
-// When no contig is longer than one scan block (metagenome assemblies: the headline workload), the
-// value entering a block depends only on the genes between the start of the contig its first gene
-// belongs to (`blk_cs`, host-built) and the block -- at most one block's worth.  The workgroup
-// loads that stretch together with its own genes and folds it itself: no totals of other
-// workgroups, no second launch, no lane-prefix array in HBM.
-__global__ void __launch_bounds__(kT) vd_fused(const SeqArgs A) {
-    __shared__ CE lds[kT / 64];
-    __shared__ uint32_t ldsm[kT / 64];
-    // 2 x 18 KB of transposition space + ~1 KB: four workgroups per CU, so that the ~10^3 workgroups
-    // of a 2 M-gene batch are resident at once
-    __shared__ struct { double st[kT * (kGPL + 1)]; } stg, stgp;
-    __shared__ uint32_t xch[kT];
+// ---- short contigs: ONE launch per decoder --------------------------------------------------------------
+// When no contig is longer than one scan block (metagenome assemblies: the headline workload) the host packs
+// WHOLE contigs into workgroups of at most 2048 genes (`cblk`, plan_ensure_seq): a workgroup then owns
+// complete contigs, so nothing enters from the left, nothing from the right, and fold / scan / replay /
+// back-to-front label pass all happen in this one kernel with the genes read once (8 B + 1 B per gene) and the
+// labels written once (1 B per gene).  (The previous arrangement -- fixed 2048-gene spans, look-back by
+// recomputation, labels in a second launch over three intermediate arrays -- took 12.5 + 5.0 us on C3.)
+struct ShortStage {
+    double st[kT * (kGPL + 1)];
+    uint8_t fl[kT * kGPL];
+    uint8_t yb[kT * kGPL];
+};
+// genes [g0, g0 + n) of the workgroup -> the lanes that own 8 consecutive ones; coalesced global accesses
+// (lane i takes entries i, i + 256, ...), padded LDS rows
+__device__ __forceinline__ void load_short(const double *__restrict__ v, const uint8_t *__restrict__ flags, int g0, int n,
+                                           ShortStage &stg) {
     const int slot = threadIdx.x;
-    const int base = blockIdx.x * kT * kGPL;
-    const int cs = A.blk_cs[blockIdx.x];
-    const bool look = cs < base;  // workgroup-uniform
-    // ---- both stretches are requested before anything is waited for
 #pragma unroll
     for (int j = 0; j < kGPL; ++j) {
         const int idx = j * kT + slot;
-        const int g = base + idx, q = cs + idx;
-        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = g < A.n_genes ? A.dstate[g] : 0.0;
-        if (look) stgp.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = q < base ? A.dstate[q] : 0.0;
+        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = idx < n ? v[g0 + idx] : 0.0;
+        stg.fl[idx] = idx < n ? flags[g0 + idx] : uint8_t(0);
     }
-    auto flag_word = [&](int g0, int limit) {
-        uint64_t w = 0;
-        if (g0 + kGPL <= limit) {
-            w = *reinterpret_cast<const uint64_t *>(A.flags + g0);
-        } else {
-            for (int k = 0; k < kGPL; ++k)
-                if (g0 + k < limit) w |= uint64_t(A.flags[g0 + k]) << (8 * k);
-        }
-        return w;
-    };
-    const int g0 = base + slot * kGPL, q0 = cs + slot * kGPL;
-    const uint64_t wf = flag_word(g0, A.n_genes);
-    const uint64_t wq = look ? flag_word(q0, base) : 0;
     __syncthreads();
-    // ---- the stretch before the block: one ordered reduction to the (constant) map entering the block
-    CE enter = COp::identity();
-    if (look) {
-        const int cntq = min(kGPL, base - q0);
-        CE P = COp::identity();
-#pragma unroll
-        for (int k = 0; k < kGPL; ++k) {
-            if (k < cntq) {
-                const double d = stgp.st[slot * (kGPL + 1) + k];
-                const double c = A.v_k + d;
-                const CE e = ((wq >> (8 * k)) & 1u) ? CE{0.0, d, d} : CE{c, A.v_lo + c, A.v_hi + c};
-                P = COp::combine(P, e);
-            }
-        }
-        (void)block_scan_exclusive<COp, false>(P, lds, &enter);
-    }
-    // ---- own genes: fold, exclusive scan over the workgroup, replay
-    const int cnt = min(kGPL, A.n_genes - g0);
+}
+
+__global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
+    __shared__ CE lds[kT / 64];
+    __shared__ uint32_t ldsm[kT / 64];
+    __shared__ ShortStage stg;
+    __shared__ uint32_t xch[kT];
+    const int slot = threadIdx.x;
+    const int g0 = A.cblk[blockIdx.x], n = A.cblk[blockIdx.x + 1] - g0;
+    load_short(A.dstate, A.flags, g0, n, stg);
+    const int cnt = min(kGPL, n - slot * kGPL);
+    const uint64_t wf = *reinterpret_cast<const uint64_t *>(stg.fl + slot * kGPL);
     double dv[kGPL];
     uint32_t first = 0, last = 0;
     CE P = COp::identity();
@@ -596,8 +575,7 @@ __global__ void __launch_bounds__(kT) vd_fused(const SeqArgs A) {
         }
     }
     CE total;
-    const CE excl = block_scan_exclusive<COp, false>(P, lds, &total);
-    const CE M = COp::combine(enter, excl);
+    const CE M = block_scan_exclusive<COp, false>(P, lds, &total);  // the workgroup starts at a contig start
     double D = M.L;
     uint32_t maps = 0, lane_map = MapOp::identity();
 #pragma unroll
@@ -611,7 +589,8 @@ __global__ void __launch_bounds__(kT) vd_fused(const SeqArgs A) {
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k)
         if (k < cnt) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
-    A.vMaps[blockIdx.x * kT + slot] = maps;
+    // back-to-front scan of the lane maps (mirrored lanes), then the labels: the workgroup ends at a contig end,
+    // so the map entering from its right is irrelevant (the last gene's map is constant)
     xch[kT - 1 - slot] = lane_map;
     __syncthreads();
     const uint32_t mine = xch[slot];
@@ -620,8 +599,22 @@ __global__ void __launch_bounds__(kT) vd_fused(const SeqArgs A) {
     __syncthreads();
     xch[kT - 1 - slot] = mexcl;
     __syncthreads();
-    A.vLaneMap[blockIdx.x * kT + slot] = xch[slot];
-    if (slot == 0) A.vBlockMap[blockIdx.x] = mtotal;
+    uint32_t lab = xch[slot] & 1u;
+    uint64_t packed = 0;
+#pragma unroll
+    for (int k = kGPL - 1; k >= 0; --k) {
+        if (k < cnt) {
+            lab = (maps >> (2 * k + lab)) & 1u;
+            packed |= uint64_t(lab) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint64_t *>(stg.yb + slot * kGPL) = packed;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kGPL; ++j) {
+        const int idx = j * kT + slot;
+        if (idx < n) A.y[g0 + idx] = int8_t(stg.yb[idx]);
+    }
 }
 
 __global__ void __launch_bounds__(kT) v_scores(const SeqArgs A, const int32_t *__restrict__ contig_ptr) {
@@ -771,6 +764,163 @@ __global__ void __launch_bounds__(kT) f_marginals(const SeqArgs A) {
     store_lane_rows(reinterpret_cast<double2 *>(A.marg), A.n_genes, slot, out, stg);
 }
 
+// ---- short contigs: whole-contig marginals in ONE launch on 8-byte inputs --------------------------------
+// Workgroups own whole contigs (`cblk`), so the forward products, alpha, the backward products and the marginals
+// of a gene all stay in the registers of the lane that owns it: per gene 8 B are read (s[1] - s[0]: every
+// marginal depends on the emissions only through that difference; + 8 B of emission maxima when log Z is
+// wanted) and 16 B written.  The general path above reads 16-byte states three times and parks alpha in HBM.
+__device__ __forceinline__ double2 emit_d(const SeqArgs &A, double d) {
+    const double e = exp_neg(fabs(d), A.expc);
+    return d > 0.0 ? make_double2(e, 1.0) : make_double2(1.0, e);
+}
+// one step of the forward / backward products from a gene's emission pair e = exp(s - max s)
+__device__ __forceinline__ FE f_step_e(const SeqArgs &A, double2 e, double m, bool first) {
+    return FE{(first ? 1.0 : A.m00) * e.x, (first ? 1.0 : A.m01) * e.y, (first ? 1.0 : A.m10) * e.x,
+              (first ? 1.0 : A.m11) * e.y, 0.0, m, first ? 1.0 : 0.0};
+}
+
+__global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
+    __shared__ FE lds[kT / 64];
+    __shared__ FE xch[kT];
+    __shared__ struct {
+        double2 st[kT * (kGPL + 1)];  // d (and maxima) in, marginals out
+        uint8_t fl[kT * kGPL];
+    } stg;
+    const int slot = threadIdx.x;
+    const int g0 = A.cblk[blockIdx.x], n = A.cblk[blockIdx.x + 1] - g0;
+    const bool want_z = A.lognorm != nullptr;
+#pragma unroll
+    for (int j = 0; j < kGPL; ++j) {
+        const int idx = j * kT + slot;
+        const bool ok = idx < n;
+        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] =
+            make_double2(ok ? A.dstate[g0 + idx] : 0.0, (ok && want_z) ? A.smax[g0 + idx] : 0.0);
+        stg.fl[idx] = ok ? A.flags[g0 + idx] : uint8_t(0);
+    }
+    __syncthreads();
+    const int cnt = min(kGPL, n - slot * kGPL);
+    const uint64_t wf = *reinterpret_cast<const uint64_t *>(stg.fl + slot * kGPL);
+    // the emission pair of every gene the lane touches (its own 8 and its right neighbour's first): ONE exp per gene,
+    // used by the forward fold, the forward replay, the backward fold and the backward replay
+    double2 E[kGPL + 1];
+    double mx[kGPL];
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        const double2 v = stg.st[slot * (kGPL + 1) + k];
+        E[k] = emit_d(A, v.x);
+        mx[k] = v.y;
+    }
+    E[kGPL] = emit_d(A, slot + 1 < kT ? stg.st[(slot + 1) * (kGPL + 1)].x : 0.0);
+    uint32_t first = 0, last = 0;
+    FE P = FOp::identity();
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        const uint32_t f = uint32_t(wf >> (8 * k)) & 0xffu;
+        first |= (f & 1u) << k;
+        last |= ((f >> 1) & 1u) << k;
+        if (k < cnt) P = FOp::combine(P, f_step_e(A, E[k], mx[k], f & 1u));
+    }
+    FE total;
+    const FE M = block_scan_exclusive<FOp, false>(P, lds, &total);
+    // forward replay: alpha of every gene of the lane (registers), log Z at contig ends; backward matrices folded
+    double a0 = M.a00, a1 = M.a01, ex = M.ex, ms = M.ms;
+    FE Bfold = FOp::identity();
+    double2 al[kGPL];
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) {
+        al[k] = make_double2(0.0, 0.0);
+        if (k < cnt) {
+            double n0, n1;
+            if ((first >> k) & 1u) {
+                n0 = n1 = 1.0;
+                ex = 0.0;
+                ms = 0.0;
+            } else {
+                n0 = fma(a1, A.m10, a0 * A.m00);
+                n1 = fma(a1, A.m11, a0 * A.m01);
+            }
+            a0 = n0 * E[k].x;
+            a1 = n1 * E[k].y;
+            int ee;
+            (void)frexp(fmax(a0, a1), &ee);
+            a0 = ldexp(a0, -ee);
+            a1 = ldexp(a1, -ee);
+            ex += double(ee);
+            ms += mx[k];
+            al[k] = make_double2(a0, a1);
+            const bool lst = (last >> k) & 1u;
+            if (lst && want_z) A.contigTmp[g0 + slot * kGPL + k] = make_double2(ex * 0.6931471805599453 + log(a0 + a1), ms);
+            const FE B = lst ? FE{1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0} : f_step_e(A, E[k + 1], 0.0, false);
+            Bfold = FOpB::combine(Bfold, B);
+        }
+    }
+    __syncthreads();  // every lane has read its neighbour's d: the stage may be overwritten below
+    xch[kT - 1 - slot] = Bfold;
+    __syncthreads();
+    const FE mine = xch[slot];
+    FE btotal;
+    const FE bexcl = block_scan_exclusive<FOpB, true>(mine, lds, &btotal);
+    __syncthreads();
+    xch[kT - 1 - slot] = bexcl;
+    __syncthreads();
+    const FE S = xch[slot];  // product of the backward matrices of the lanes to the right (up to the contig's end)
+    double b0 = S.a00 + S.a01, b1 = S.a10 + S.a11;
+#pragma unroll
+    for (int k = kGPL - 1; k >= 0; --k) {
+        double2 o = make_double2(0.0, 0.0);
+        if (k < cnt) {
+            if ((last >> k) & 1u) {
+                b0 = b1 = 1.0;
+            } else {
+                const double c0 = E[k + 1].x * b0, c1 = E[k + 1].y * b1;
+                b0 = fma(A.m01, c1, A.m00 * c0);
+                b1 = fma(A.m11, c1, A.m10 * c0);
+                int ee;
+                (void)frexp(fmax(b0, b1), &ee);
+                b0 = ldexp(b0, -ee);
+                b1 = ldexp(b1, -ee);
+            }
+            const double x0 = al[k].x * b0, x1 = al[k].y * b1, z = x0 + x1;
+            double r = __builtin_amdgcn_rcp(z);
+            r = fma(fma(-z, r, 1.0), r, r);
+            o = make_double2(x0 * r, x1 * r);
+        }
+        stg.st[slot * (kGPL + 1) + k] = o;
+    }
+    __syncthreads();
+    double2 *out = reinterpret_cast<double2 *>(A.marg);
+#pragma unroll
+    for (int j = 0; j < kGPL; ++j) {
+        const int idx = j * kT + slot;
+        if (idx < n) out[g0 + idx] = stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL];
+    }
+}
+
+// d = s[1] - s[0] per gene (and, optionally, max(s[0], s[1])): all the short-contig kernels need of the state scores
+__global__ void __launch_bounds__(kT) seq_state_dm(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
+                                                    const double2 *__restrict__ wtab01, int n_attrs, int n_genes,
+                                                    double *__restrict__ dstate, double *__restrict__ smax) {
+    const int g = blockIdx.x * kT + threadIdx.x;
+    if (g >= n_genes) return;
+    const int lo = gene_ptr[g], hi = gene_ptr[g + 1];
+    double s0 = 0.0, s1 = 0.0;
+    for (int base = lo; base < hi; base += 4) {
+        int a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = base + u < hi ? attr_id[base + u] : -1;
+        double2 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = unsigned(a[u]) < unsigned(n_attrs) ? wtab01[a[u]] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s0 += w[u].x;
+            s1 += w[u].y;
+        }
+    }
+    dstate[g] = s1 - s0;
+    if (smax) smax[g] = fmax(s0, s1);
+}
+
 // log Z of contig c = log Z' + its emission maxima + (n-1) max(trans)
 __global__ void __launch_bounds__(kT) f_lognorm(const SeqArgs A, const int32_t *__restrict__ contig_ptr) {
     const int c = blockIdx.x * kT + threadIdx.x;
@@ -811,12 +961,12 @@ hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hip
 hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream) {
     if (a.n_contigs <= 0 || a.n_genes <= 0) return hipSuccess;
     const int nb = (a.n_genes + kBlockGenes - 1) / kBlockGenes;
-    if (a.short_contigs) {
-        hipLaunchKernelGGL(vd_fused, dim3(nb), dim3(kT), 0, stream, a);
-    } else {
-        hipLaunchKernelGGL(vd_fold, dim3(nb), dim3(kT), 0, stream, a);
-        hipLaunchKernelGGL(vd_replay, dim3(nb), dim3(kT), 0, stream, a);
+    if (a.short_contigs) {  // whole contigs per workgroup: one launch
+        hipLaunchKernelGGL(vd_short, dim3(a.n_cblocks), dim3(kT), 0, stream, a);
+        return hipGetLastError();
     }
+    hipLaunchKernelGGL(vd_fold, dim3(nb), dim3(kT), 0, stream, a);
+    hipLaunchKernelGGL(vd_replay, dim3(nb), dim3(kT), 0, stream, a);
     hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, a);
     return hipGetLastError();
 }
@@ -825,6 +975,20 @@ hipError_t launch_seq_state_delta(const int32_t *gene_ptr, const int32_t *attr_i
                                   double *dstate, hipStream_t stream) {
     if (n_genes <= 0) return hipSuccess;
     hipLaunchKernelGGL(seq_state_delta, grid_for(n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_attrs, n_genes, dstate);
+    return hipGetLastError();
+}
+
+// short contigs: state differences (+ maxima when log Z is wanted) and the fused kernel; a.dstate / a.smax are
+// workspace arrays filled here
+hipError_t launch_seq_marginals_short(const SeqArgs &a, const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01,
+                                      int n_attrs, const int32_t *d_contig_ptr, hipStream_t stream) {
+    if (a.n_contigs <= 0) return hipSuccess;
+    if (a.n_genes > 0) {
+        hipLaunchKernelGGL(seq_state_dm, grid_for(a.n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_attrs, a.n_genes,
+                           const_cast<double *>(a.dstate), a.lognorm ? const_cast<double *>(a.smax) : nullptr);
+        hipLaunchKernelGGL(f_short, dim3(a.n_cblocks), dim3(kT), 0, stream, a);
+    }
+    if (a.lognorm) hipLaunchKernelGGL(f_lognorm, grid_for(a.n_contigs, kT), dim3(kT), 0, stream, a, d_contig_ptr);
     return hipGetLastError();
 }
 
