@@ -191,6 +191,17 @@ struct GenArgs {
     // outputs
     double *marg, *lognorm, *score;
     int8_t *y;
+    // long contigs (n_chunks > 0): contigs cut into chunks of gen_chunk_genes() genes
+    const int32_t *ch_g0;      // [n_chunks+1] first gene of every chunk (chunks never straddle contigs)
+    const int32_t *ch_contig;  // [n_chunks]
+    const int32_t *cc_ptr;     // [n_contigs+1] chunks of every contig
+    int32_t n_chunks;
+    double *chM;               // [n_chunks*L*L] rows of the chunks' transfer matrices
+    int32_t *chEx;             // [n_chunks*L]   power-of-two exponents of the rows (sum-product)
+    double *chV, *chB;         // [n_chunks*L]   vector entering every chunk / beta of its last gene
+    double *chZ;               // [n_chunks]     partial log-partition
+    uint8_t *chMap;            // [n_chunks*L]   label of the chunk's last gene -> label of the gene before the chunk
+    int8_t *chY;               // [n_chunks]     label of the chunk's last gene
     // windowed path: slot space of the plan
     const int32_t *c_slot, *c_gene, *c_n;
     const uint64_t *start_bits;
@@ -201,6 +212,7 @@ hipError_t launch_gen_state(const GenArgs &a, hipStream_t stream);
 hipError_t launch_gen_windowed(const GenArgs &a, hipStream_t stream);   // p_out must be zeroed first
 hipError_t launch_gen_marginals(const GenArgs &a, hipStream_t stream);
 hipError_t launch_gen_viterbi(const GenArgs &a, hipStream_t stream);
+int gen_chunk_genes();
 
 // weighted domain composition of called clusters (crf_composition.hip); d_tmp: one double per domain row
 hipError_t launch_composition(const int32_t *d_seg, int n_seg, const int32_t *d_dom_ptr, const int32_t *d_dom_col,

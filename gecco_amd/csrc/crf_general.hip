@@ -301,6 +301,363 @@ __global__ void __launch_bounds__(kGT) gl_viterbi_seq(GenArgs a) {
     }
 }
 
+// ==================================================================================================
+// Long contigs, any number of labels ("matrix-product scan for C5").  The kernels
+// above give a whole contig to ONE group of lanes: a 50 000-gene contig is a 50 000-step dependent chain
+// (~50 ms).  Here a contig is cut into chunks of kChunk genes and the recursions become three short
+// stages, each parallel over chunks or short in steps:
+//   rows    one group per (chunk, row i): row i of the chunk's transfer matrix M_c = S_first .. S_last,
+//           i.e. the forward recursion started from the unit vector e_i (sum-product with exact
+//           power-of-two scaling and a per-row exponent; max-plus for Viterbi).  L x the work of the
+//           sequential kernel, spread over n / kChunk groups;
+//   vecs    one group per contig walks its CHUNKS (n / kChunk steps instead of n): v <- v M_c forwards
+//           (alpha / delta entering every chunk), b <- M_c b backwards (beta leaving every chunk: the
+//           backward step matrices are the same S_t);
+//   replay  one group per chunk re-runs CRFsuite's own recursion inside the chunk from its entering
+//           vector: alpha / scale / marginals, or back-pointers and labels.
+// Values entering a chunk come from composed matrices, so they equal the strictly sequential ones
+// whenever the arithmetic is exact (integer weights: ties included) and to rounding otherwise; marginals
+// are normalised by their sum inside the chunk (CRFsuite divides by the scale factor, which is the same
+// number up to rounding).
+constexpr int kChunk = 64;
+
+template <int LP, bool MAXPLUS>
+__global__ void __launch_bounds__(kGT) gl_chunk_rows(GenArgs a) {
+    __shared__ double vecs[kGT];
+    constexpr int G = kGT / LP;
+    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
+    double *vec = vecs + grp * LP;
+    const int L = a.L;
+    const long long q = static_cast<long long>(blockIdx.x) * G + grp;
+    if (q >= static_cast<long long>(a.n_chunks) * L) return;
+    const int ci = int(q / L), i = int(q % L);
+    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int cfirst = a.contig_ptr[a.ch_contig[ci]];  // the contig's first gene has no transition into it
+    const bool on = j < L;
+    const int jj = on ? j : 0;
+    const double ninf = -__builtin_huge_val();
+    double mcol[LP];
+#pragma unroll
+    for (int k = 0; k < LP; ++k) mcol[k] = (k < L && on) ? (MAXPLUS ? a.trans[k * L + j] : a.exp_trans[k * L + j]) : (MAXPLUS ? ninf : 0.0);
+    const double *src = MAXPLUS ? a.state : a.E;
+    double v = MAXPLUS ? (j == i ? 0.0 : ninf) : (j == i ? 1.0 : 0.0);
+    int ex = 0;
+    double e = on ? src[static_cast<size_t>(g0) * L + jj] : (MAXPLUS ? ninf : 0.0);
+    for (int t = g0; t < g1; ++t) {
+        const double e_next = (t + 1 < g1 && on) ? src[static_cast<size_t>(t + 1) * L + jj] : (MAXPLUS ? ninf : 0.0);
+        if (t == cfirst) {
+            v = e;  // every row: the first gene forgets what entered
+        } else {
+            vec[j] = v;
+            __builtin_amdgcn_wave_barrier();
+            double acc = MAXPLUS ? ninf : 0.0;
+#pragma unroll
+            for (int k = 0; k < LP; ++k) {
+                if (MAXPLUS) {
+                    if (k < L) acc = fmax(acc, vec[k] + mcol[k]);
+                } else {
+                    acc = fma(vec[k], mcol[k], acc);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            v = MAXPLUS ? acc + e : acc * e;
+        }
+        if (!MAXPLUS) {  // exact power-of-two scaling of the row, exponent kept
+            const double mx = group_max<LP>(on ? v : 0.0);
+            if (mx > 0.0) {
+                int e2;
+                (void)frexp(mx, &e2);
+                v = ldexp(v, -e2);
+                ex += e2;
+            }
+        }
+        e = e_next;
+    }
+    if (on) a.chM[(static_cast<size_t>(ci) * L + i) * L + j] = v;
+    if (!MAXPLUS && j == 0) a.chEx[static_cast<size_t>(ci) * L + i] = ex;
+}
+
+// forward over the chunks of a contig: the vector entering every chunk (normalised alpha of the gene before
+// it / delta of the gene before it)
+template <int LP, bool MAXPLUS>
+__global__ void __launch_bounds__(kGT) gl_chunk_vecs_fwd(GenArgs a) {
+    __shared__ double vecs[kGT];
+    constexpr int G = kGT / LP;
+    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
+    double *vec = vecs + grp * LP;
+    const int L = a.L;
+    const long long ct = static_cast<long long>(blockIdx.x) * G + grp;
+    if (ct >= a.n_contigs) return;
+    const bool on = j < L;
+    const double ninf = -__builtin_huge_val();
+    const int c0 = a.cc_ptr[ct], c1 = a.cc_ptr[ct + 1];
+    double v = MAXPLUS ? (j == 0 ? 0.0 : ninf) : (j == 0 ? 1.0 : 0.0);
+    for (int c = c0; c < c1; ++c) {
+        if (on) a.chV[static_cast<size_t>(c) * L + j] = v;
+        if (c + 1 == c1) break;
+        const double *M = a.chM + static_cast<size_t>(c) * L * L;
+        double w = v;
+        if (!MAXPLUS) {  // rows carry their own power-of-two exponents
+            const int exj = on ? a.chEx[static_cast<size_t>(c) * L + j] : 0;
+            const double exm = group_max<LP>((on && v > 0.0) ? double(exj) : -1e300);
+            w = (on && v > 0.0) ? ldexp(v, exj - int(exm)) : 0.0;
+        }
+        vec[j] = w;
+        __builtin_amdgcn_wave_barrier();
+        double acc = MAXPLUS ? ninf : 0.0;
+        for (int k = 0; k < L; ++k) {
+            const double mkj = on ? M[static_cast<size_t>(k) * L + j] : (MAXPLUS ? ninf : 0.0);
+            acc = MAXPLUS ? fmax(acc, vec[k] + mkj) : fma(vec[k], mkj, acc);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (MAXPLUS) {
+            v = acc;
+        } else {
+            const double sm = group_sum<LP>(on ? acc : 0.0);
+            v = sm != 0.0 ? acc / sm : acc;
+        }
+    }
+}
+
+// backward over the chunks of a contig (marginals): beta of the last gene of every chunk, up to a factor;
+// also the contig's log-partition from the chunks' partial sums
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_chunk_vecs_bwd(GenArgs a) {
+    __shared__ double vecs[kGT];
+    constexpr int G = kGT / LP;
+    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
+    double *vec = vecs + grp * LP;
+    const int L = a.L;
+    const long long ct = static_cast<long long>(blockIdx.x) * G + grp;
+    if (ct >= a.n_contigs) return;
+    const bool on = j < L;
+    const int c0 = a.cc_ptr[ct], c1 = a.cc_ptr[ct + 1];
+    if (j == 0 && a.lognorm) {
+        double z = 0.0;
+        for (int c = c0; c < c1; ++c) z += a.chZ[c];
+        a.lognorm[ct] = z;
+    }
+    double b = 1.0;
+    for (int c = c1 - 1; c >= c0; --c) {
+        if (on) a.chB[static_cast<size_t>(c) * L + j] = b;
+        if (c == c0) break;
+        // beta of the gene before the chunk = M_c beta: lane j takes row j
+        const double *row = a.chM + (static_cast<size_t>(c) * L + (on ? j : 0)) * L;
+        vec[j] = on ? b : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        double acc = 0.0;
+        for (int k = 0; k < L; ++k) acc = fma(row[k], vec[k], acc);
+        __builtin_amdgcn_wave_barrier();
+        const int exj = on ? a.chEx[static_cast<size_t>(c) * L + j] : 0;
+        const double exm = group_max<LP>((on && acc > 0.0) ? double(exj) : -1e300);
+        acc = (on && acc > 0.0) ? ldexp(acc, exj - int(exm)) : 0.0;
+        const double mx = group_max<LP>(acc);
+        b = mx > 0.0 ? acc / mx : 1.0;
+    }
+}
+
+// CRFsuite's forward recursion inside a chunk, from the vector that enters it
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_chunk_fwd(GenArgs a) {
+    __shared__ double vecs[kGT];
+    constexpr int G = kGT / LP;
+    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
+    double *vec = vecs + grp * LP;
+    const int L = a.L;
+    const long long ci = static_cast<long long>(blockIdx.x) * G + grp;
+    if (ci >= a.n_chunks) return;
+    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int cfirst = a.contig_ptr[a.ch_contig[ci]];
+    const bool on = j < L;
+    const int jj = on ? j : 0;
+    double mcol[LP];
+#pragma unroll
+    for (int k = 0; k < LP; ++k) mcol[k] = (k < L && on) ? a.exp_trans[k * L + j] : 0.0;
+    double v = on ? a.chV[static_cast<size_t>(ci) * L + j] : 0.0, z = 0.0;
+    double e = on ? a.E[static_cast<size_t>(g0) * L + jj] : 0.0;
+    for (int t = g0; t < g1; ++t) {
+        const double e_next = (t + 1 < g1 && on) ? a.E[static_cast<size_t>(t + 1) * L + jj] : 0.0;
+        if (t == cfirst) {
+            v = e;
+        } else {
+            vec[j] = v;
+            __builtin_amdgcn_wave_barrier();
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < LP; ++k) acc = fma(vec[k], mcol[k], acc);
+            __builtin_amdgcn_wave_barrier();
+            v = acc * e;
+        }
+        const double sm = group_sum<LP>(v);
+        const double c = sm != 0.0 ? 1.0 / sm : 1.0;
+        v *= c;
+        if (on) a.alpha[static_cast<size_t>(t) * L + j] = v;
+        if (j == 0) a.scale[t] = c;
+        z += a.smax[t] - log(c);
+        e = e_next;
+    }
+    if (j == 0) a.chZ[ci] = z;
+}
+
+// backward recursion inside a chunk + marginals
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_chunk_bwd(GenArgs a) {
+    __shared__ double vecs[kGT];
+    constexpr int G = kGT / LP;
+    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
+    double *vec = vecs + grp * LP;
+    const int L = a.L;
+    const long long ci = static_cast<long long>(blockIdx.x) * G + grp;
+    if (ci >= a.n_chunks) return;
+    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const bool on = j < L;
+    const int jj = on ? j : 0;
+    double mrow[LP];
+#pragma unroll
+    for (int k = 0; k < LP; ++k) mrow[k] = (k < L && on) ? a.exp_trans[j * L + k] : 0.0;
+    double b = on ? a.chB[static_cast<size_t>(ci) * L + j] : 0.0;
+    for (int t = g1 - 1; t >= g0; --t) {
+        const double al = on ? a.alpha[static_cast<size_t>(t) * L + j] : 0.0;
+        const double x = al * b;
+        const double sm = group_sum<LP>(x);
+        if (on) a.marg[static_cast<size_t>(t) * L + j] = sm != 0.0 ? x / sm : 0.0;
+        if (t > g0) {
+            vec[j] = on ? b * a.E[static_cast<size_t>(t) * L + jj] : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < LP; ++k) acc = fma(mrow[k], vec[k], acc);
+            __builtin_amdgcn_wave_barrier();
+            b = acc * a.scale[t - 1];  // CRFsuite's own scaling keeps beta near 1
+        }
+    }
+}
+
+// Viterbi inside a chunk: back-pointers; the contig's end label and score in its last chunk
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_chunk_vit(GenArgs a) {
+    __shared__ double vecs[kGT];
+    constexpr int G = kGT / LP;
+    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
+    double *vec = vecs + grp * LP;
+    const int L = a.L;
+    const long long ci = static_cast<long long>(blockIdx.x) * G + grp;
+    if (ci >= a.n_chunks) return;
+    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int ct = a.ch_contig[ci];
+    const int cfirst = a.contig_ptr[ct], cend = a.contig_ptr[ct + 1];
+    const bool on = j < L;
+    const int jj = on ? j : 0;
+    double tcol[LP];
+#pragma unroll
+    for (int k = 0; k < LP; ++k) tcol[k] = (k < L && on) ? a.trans[k * L + j] : 0.0;
+    double d = on ? a.chV[static_cast<size_t>(ci) * L + j] : -DBL_MAX;
+    for (int t = g0; t < g1; ++t) {
+        const double s_t = on ? a.state[static_cast<size_t>(t) * L + jj] : 0.0;
+        if (t == cfirst) {
+            d = on ? s_t : -DBL_MAX;
+            continue;
+        }
+        vec[j] = d;
+        __builtin_amdgcn_wave_barrier();
+        double best = -DBL_MAX;
+        int arg = -1;
+#pragma unroll
+        for (int k = 0; k < LP; ++k) {
+            if (k < L) {
+                const double sc = vec[k] + tcol[k];
+                if (best < sc) {
+                    best = sc;
+                    arg = k;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (on) a.back[static_cast<size_t>(t) * L + j] = static_cast<uint8_t>(arg < 0 ? 0 : arg);
+        d = best + s_t;
+    }
+    if (g1 == cend) {  // first arg max of the final scores
+        vec[j] = d;
+        __builtin_amdgcn_wave_barrier();
+        if (j == 0) {
+            double best = -DBL_MAX;
+            int y = 0;
+            for (int k = 0; k < L; ++k)
+                if (best < vec[k]) {
+                    best = vec[k];
+                    y = k;
+                }
+            a.chY[ci] = static_cast<int8_t>(y);
+            if (a.score) a.score[ct] = best;
+        }
+    }
+}
+
+// per chunk: label of its last gene -> label of the gene before the chunk (lane y follows the back-pointers)
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_chunk_maps(GenArgs a) {
+    constexpr int G = kGT / LP;
+    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
+    const int L = a.L;
+    const long long ci = static_cast<long long>(blockIdx.x) * G + grp;
+    if (ci >= a.n_chunks || j >= L) return;
+    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    if (g0 == a.contig_ptr[a.ch_contig[ci]]) return;  // nothing before a contig's first chunk
+    int y = j;
+    for (int t = g1 - 1; t >= g0; --t) y = a.back[static_cast<size_t>(t) * L + y];
+    a.chMap[static_cast<size_t>(ci) * L + j] = static_cast<uint8_t>(y);
+}
+
+// per contig: the label of every chunk's last gene, back to front (n / kChunk dependent steps)
+__global__ void __launch_bounds__(kGT) gl_chunk_ends(GenArgs a) {
+    const long long ct = static_cast<long long>(blockIdx.x) * kGT + threadIdx.x;
+    if (ct >= a.n_contigs) return;
+    const int c0 = a.cc_ptr[ct], c1 = a.cc_ptr[ct + 1];
+    if (c1 <= c0) return;
+    int y = a.chY[c1 - 1];
+    for (int c = c1 - 1; c > c0; --c) {
+        y = a.chMap[static_cast<size_t>(c) * a.L + y];
+        a.chY[c - 1] = static_cast<int8_t>(y);
+    }
+}
+
+// per chunk: labels of its genes from the label of its last one
+__global__ void __launch_bounds__(kGT) gl_chunk_backtrack(GenArgs a) {
+    const long long ci = static_cast<long long>(blockIdx.x) * kGT + threadIdx.x;
+    if (ci >= a.n_chunks) return;
+    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    if (g1 <= g0) return;
+    int y = a.chY[ci];
+    a.y[g1 - 1] = static_cast<int8_t>(y);
+    for (int t = g1 - 1; t > g0; --t) {
+        y = a.back[static_cast<size_t>(t) * a.L + y];
+        a.y[t - 1] = static_cast<int8_t>(y);
+    }
+}
+
+template <int LP>
+hipError_t launch_chunked(int what, const GenArgs &a, hipStream_t stream) {
+    constexpr int G = kGT / LP;
+    auto blocks = [](long long items, int per) { return dim3(unsigned((items + per - 1) / per)); };
+    const long long rows = static_cast<long long>(a.n_chunks) * a.L;
+    if (a.n_chunks <= 0) return hipSuccess;
+    if (what == 2) {
+        hipLaunchKernelGGL((gl_chunk_rows<LP, false>), blocks(rows, G), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL((gl_chunk_vecs_fwd<LP, false>), blocks(a.n_contigs, G), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL(gl_chunk_fwd<LP>, blocks(a.n_chunks, G), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL(gl_chunk_vecs_bwd<LP>, blocks(a.n_contigs, G), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL(gl_chunk_bwd<LP>, blocks(a.n_chunks, G), dim3(kGT), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((gl_chunk_rows<LP, true>), blocks(rows, G), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL((gl_chunk_vecs_fwd<LP, true>), blocks(a.n_contigs, G), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL(gl_chunk_vit<LP>, blocks(a.n_chunks, G), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL(gl_chunk_maps<LP>, blocks(a.n_chunks, G), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL(gl_chunk_ends, blocks(a.n_contigs, kGT), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL(gl_chunk_backtrack, blocks(a.n_chunks, kGT), dim3(kGT), 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
 template <int LP>
 hipError_t launch_lp(int what, const GenArgs &a, hipStream_t stream) {
     constexpr int G = kGT / LP;
@@ -333,6 +690,13 @@ hipError_t launch_lp(int what, const GenArgs &a, hipStream_t stream) {
 
 hipError_t launch_any(int what, const GenArgs &a, hipStream_t stream) {
     if (a.L <= 0 || a.L > kGenMaxL) return hipErrorNotSupported;
+    if ((what == 2 || what == 3) && a.n_chunks > 0) {  // long contigs in the batch: chunked recursions
+        if (a.L <= 2) return launch_chunked<2>(what, a, stream);
+        if (a.L <= 4) return launch_chunked<4>(what, a, stream);
+        if (a.L <= 8) return launch_chunked<8>(what, a, stream);
+        if (a.L <= 16) return launch_chunked<16>(what, a, stream);
+        return launch_chunked<32>(what, a, stream);
+    }
     if (a.L <= 2) return launch_lp<2>(what, a, stream);
     if (a.L <= 4) return launch_lp<4>(what, a, stream);
     if (a.L <= 8) return launch_lp<8>(what, a, stream);
@@ -349,5 +713,6 @@ hipError_t launch_gen_windowed(const GenArgs &a, hipStream_t stream) {
 }
 hipError_t launch_gen_marginals(const GenArgs &a, hipStream_t stream) { return launch_any(2, a, stream); }
 hipError_t launch_gen_viterbi(const GenArgs &a, hipStream_t stream) { return launch_any(3, a, stream); }
+int gen_chunk_genes() { return kChunk; }
 
 }  // namespace gecco

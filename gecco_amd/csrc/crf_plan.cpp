@@ -367,13 +367,41 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
 namespace {
 inline size_t align256g(size_t x) { return (x + 255) & ~size_t(255); }
 
-int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, GenArgs &a) {
+// A contig longer than this sends the whole batch through the chunked whole-contig kernels (crf_general.hip):
+// below it, one group of lanes per contig walking it sequentially is the cheaper arrangement.
+constexpr int32_t kGenLongContig = 2048;
+
+int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, GenArgs &a, bool whole_contig = false,
+                  hipStream_t stream = nullptr) {
     const Model &m = *p.model;
     const size_t n = size_t(p.n_genes), L = size_t(m.L);
     const size_t b_vec = align256g(n * L * 8 + 8), b_one = align256g(n * 8 + 8), b_back = align256g(n * L + 8);
+    // chunk tables of the long-contig path, built on the host (n / 64 entries)
+    std::vector<int32_t> ch_g0, ch_contig, cc_ptr;
+    bool chunked = false;
+    if (whole_contig) {
+        for (int32_t c = 0; c < p.n_contigs && !chunked; ++c) chunked = p.contig_ptr[c + 1] - p.contig_ptr[c] > kGenLongContig;
+        if (const char *env = std::getenv("GECCO_CRF_GENERAL_CHUNKED")) chunked = env[0] == '1';  // tests: force either path
+    }
+    if (chunked) {
+        const int32_t C = gen_chunk_genes();
+        cc_ptr.push_back(0);
+        for (int32_t c = 0; c < p.n_contigs; ++c) {
+            for (int32_t g = p.contig_ptr[c]; g < p.contig_ptr[c + 1]; g += C) {
+                ch_g0.push_back(g);
+                ch_contig.push_back(c);
+            }
+            cc_ptr.push_back(int32_t(ch_g0.size()));
+        }
+        ch_g0.push_back(p.n_genes);
+    }
+    const size_t nch = chunked ? ch_contig.size() : 0;
+    const size_t b_tab = align256g((nch + 1) * 4) + align256g((nch + 1) * 4) + align256g((size_t(p.n_contigs) + 1) * 4);
+    const size_t b_chM = align256g(nch * L * L * 8 + 8), b_chv = align256g(nch * L * 8 + 8), b_chs = align256g(nch * 8 + 8);
+    const size_t b_chunks = chunked ? b_tab + b_chM + 3 * b_chv + 2 * b_chs + 2 * align256g(nch * L + 8) : 0;
     {
         std::lock_guard<std::mutex> lock(p.ws_mutex);
-        int rc = grow_ws(p.d_gen_ws, p.gen_ws_cap, 3 * b_vec + 2 * b_one + b_back, "hipMalloc general-L workspace");
+        int rc = grow_ws(p.d_gen_ws, p.gen_ws_cap, 3 * b_vec + 2 * b_one + b_back + b_chunks, "hipMalloc general-L workspace");
         if (rc) return rc;
     }
     char *w = p.d_gen_ws;
@@ -394,6 +422,36 @@ int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, 
     a.smax = reinterpret_cast<double *>(w + 3 * b_vec);
     a.scale = reinterpret_cast<double *>(w + 3 * b_vec + b_one);
     a.back = reinterpret_cast<uint8_t *>(w + 3 * b_vec + 2 * b_one);
+    if (chunked && nch) {
+        char *q = w + 3 * b_vec + 2 * b_one + b_back;
+        auto put = [&](const std::vector<int32_t> &v) {
+            int32_t *d = reinterpret_cast<int32_t *>(q);
+            q += align256g((v.size() + 1) * 4);
+            return std::make_pair(d, check_hip(hipMemcpyAsync(d, v.data(), v.size() * 4, hipMemcpyHostToDevice, stream), "upload chunk table"));
+        };
+        auto t0 = put(ch_g0), t1 = put(ch_contig), t2 = put(cc_ptr);
+        if (t0.second || t1.second || t2.second) return GECCO_CRF_EHIP;
+        // the tables are host vectors that die with this call: the copies must have left them
+        int rc = check_hip(hipStreamSynchronize(stream), "upload chunk table");
+        if (rc) return rc;
+        a.ch_g0 = t0.first;
+        a.ch_contig = t1.first;
+        a.cc_ptr = t2.first;
+        a.n_chunks = int32_t(nch);
+        a.chM = reinterpret_cast<double *>(q);
+        q += b_chM;
+        a.chV = reinterpret_cast<double *>(q);
+        q += b_chv;
+        a.chB = reinterpret_cast<double *>(q);
+        q += b_chv;
+        a.chEx = reinterpret_cast<int32_t *>(q);
+        q += b_chv;
+        a.chZ = reinterpret_cast<double *>(q);
+        q += 2 * b_chs;
+        a.chMap = reinterpret_cast<uint8_t *>(q);
+        q += align256g(nch * L + 8);
+        a.chY = reinterpret_cast<int8_t *>(q);
+    }
     a.c_slot = p.d_c_slot;
     a.c_gene = p.d_c_gene;
     a.c_n = p.d_c_n;
@@ -688,7 +746,7 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
     }
     if (p.general) {
         GenArgs g;
-        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g))) return rc;
+        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g, true, stream))) return rc;
         g.marg = d_marg;
         g.lognorm = d_lognorm;
         g.state = nullptr;
@@ -721,7 +779,7 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
     }
     if (p.general) {
         GenArgs g;
-        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g))) return rc;
+        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g, true, stream))) return rc;
         g.y = d_y;
         g.score = d_score;
         g.E = nullptr;

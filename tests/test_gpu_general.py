@@ -150,3 +150,65 @@ def test_too_many_labels_is_reported(nat):
     with pytest.raises(nat.NativeError) as ei:
         nat.Model.from_tables(w, trans).windowed_marginals(cptr, gptr, attr, 20, 1, 0, True)
     assert ei.value.code == nat.EUNSUPPORTED
+
+
+# ---- long contigs: the chunked whole-contig kernels ("matrix-product scan for C5") ----
+@pytest.mark.parametrize("L", [1, 2, 3, 5, 8, 17, 32])
+def test_chunked_path_equals_oracle(nat, L, monkeypatch):
+    """GECCO_CRF_GENERAL_CHUNKED=1 sends every batch through the chunked kernels (chunk matrices, vectors over
+    chunks, replay inside chunks): same outputs as the oracle's sequential recursions, short contigs included."""
+    from oracle import crf_oracle as orc
+
+    monkeypatch.setenv("GECCO_CRF_GENERAL_CHUNKED", "1")
+    monkeypatch.setenv("GECCO_CRF_FORCE_GENERAL", "1")
+    w, trans, cptr, gptr, attr = _case(L, 400 + L, extra=10)
+    model = nat.Model.from_tables(w, trans)
+    marg, ln = model.marginals_full(cptr, gptr, attr)
+    emarg, eln = orc.full_marginals(w, trans, cptr, gptr, attr)
+    assert np.abs(marg - emarg).max() <= 1e-12
+    assert np.abs(ln - eln).max() <= 1e-10 * max(1.0, np.abs(eln).max())
+    y, sc = model.viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y.astype(np.int32), ey)
+    assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
+
+
+@pytest.mark.parametrize("L", [3, 5])
+def test_chunked_viterbi_ties_first_argmax(nat, L, monkeypatch):
+    from oracle import crf_oracle as orc
+
+    monkeypatch.setenv("GECCO_CRF_GENERAL_CHUNKED", "1")
+    rng = np.random.default_rng(27 + L)
+    A = 40
+    w = rng.integers(-2, 3, size=(A, L)).astype(np.float64)
+    trans = rng.integers(-1, 2, size=(L, L)).astype(np.float64)
+    cptr, gptr, attr = synth_contigs(rng, [1, 2, 63, 64, 65, 128, 129, 300, 5000], A)
+    y, sc = nat.Model.from_tables(w, trans).viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y.astype(np.int32), ey)
+    assert np.array_equal(sc, esc)
+
+
+@pytest.mark.parametrize("L", [3, 8])
+def test_long_contig_any_label_count(nat, L):
+    """A 50 000-gene contig (the C5 shape) next to short ones: taken by the chunked kernels on its own."""
+    import time
+
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(500 + L)
+    A = 500
+    w, trans = synth_model(A, rng, L=L)
+    cptr, gptr, attr = synth_contigs(rng, [300, 50000, 7, 2049], A)
+    model = nat.Model.from_tables(w, trans)
+    t0 = time.perf_counter()
+    marg, ln = model.marginals_full(cptr, gptr, attr)
+    y, sc = model.viterbi(cptr, gptr, attr)
+    dt = time.perf_counter() - t0
+    emarg, eln = orc.full_marginals(w, trans, cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.abs(marg - emarg).max() <= 1e-12
+    assert np.abs(ln - eln).max() <= 1e-10 * np.abs(eln).max()
+    assert np.array_equal(y.astype(np.int32), ey)
+    assert np.abs(sc - esc).max() <= 1e-9 * np.abs(esc).max()
+    assert dt < 1.0  # the contig-sequential kernels need ~50 ms per pass for the long contig alone; this is a sanity bound

@@ -58,6 +58,29 @@ def main():
             res[name] = {"ms": dt * 1e3, "genes_per_s": n / dt}
         out[f"L={L}" + (" (2-label model forced onto the general kernels)" if L == 2 else "")] = res
     os.environ.pop("GECCO_CRF_FORCE_GENERAL", None)
+    # long contigs: one 50 000-gene contig, contig-sequential kernels (one group of lanes walks it) against the
+    # chunked ones (chunk matrices -> vectors over chunks -> replay inside chunks)
+    lc, lg, la = synth.synth_contigs(rng, [50000], A)
+    d_lg, d_la = torch.from_numpy(lg).to(dev), torch.from_numpy(la).to(dev)
+    for L in (3, 8):
+        w = np.clip(rng.laplace(0.0, 1.7, size=(A, L)), -6.3, 12.7)
+        trans = rng.normal(0, 1.5, size=(L, L))
+        model = nat.Model.from_tables(w, trans)
+        res = {"genes": 50000}
+        for mode in ("0", "1"):
+            os.environ["GECCO_CRF_GENERAL_CHUNKED"] = mode
+            plan = nat.Plan(model, lc, 20, 1, True, device=0)
+            y = torch.zeros(50000, dtype=torch.int8, device=dev)
+            marg = torch.zeros(50000, L, dtype=torch.float64, device=dev)
+            tag = "chunked" if mode == "1" else "contig_sequential"
+            for name, fn in (("viterbi", lambda: plan.run_viterbi(d_lg.data_ptr(), d_la.data_ptr(), y.data_ptr())),
+                             ("marginals_full", lambda: plan.run_marginals_full(d_lg.data_ptr(), d_la.data_ptr(), marg.data_ptr()))):
+                dt = timed(fn, reps=3)
+                res[f"{name}_{tag}"] = {"ms": dt * 1e3, "genes_per_s": 50000 / dt}
+        os.environ.pop("GECCO_CRF_GENERAL_CHUNKED", None)
+        for name in ("viterbi", "marginals_full"):
+            res[f"{name}_speedup"] = res[f"{name}_contig_sequential"]["ms"] / res[f"{name}_chunked"]["ms"]
+        out[f"one 50000-gene contig, L={L}"] = res
     print(json.dumps(out))
 
 
