@@ -118,6 +118,12 @@ SIGNATURES = {
     "gecco_crf_cluster_rows_max_p": (_vp, [_vp]),
     "gecco_crf_cluster_rows_strings": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "gecco_crf_exact_mean": (ctypes.c_double, [_c_f64p, ctypes.c_int64]),
+    "gecco_crf_tsv_format": (
+        ctypes.c_int,
+        [ctypes.c_int64, ctypes.c_int32, _c_i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_char_p, ctypes.POINTER(_vp),
+         ctypes.POINTER(ctypes.c_int64)],
+    ),
+    "gecco_crf_buffer_free": (None, [_vp]),
     "gecco_crf_plan_time_windowed": (
         ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]
     ),
@@ -462,6 +468,50 @@ class PackedTables:
         finally:
             self._lib.gecco_crf_cluster_rows_free(h)
         return out
+
+
+def tsv_format(header: str, columns) -> bytes:
+    """TSV text of `columns` (each a (data uint8, offsets int64) string column, an int64 array or a float64 array)
+    below `header`: floats as Python's repr() writes them, NaN as an empty field (`gecco_crf_tsv_format`)."""
+    lib = load_library()
+    keep, kinds, data, offs = [], [], [], []
+    n_rows = None
+    for col in columns:
+        if isinstance(col, tuple):
+            d = np.ascontiguousarray(col[0], dtype=np.uint8)
+            o = np.ascontiguousarray(col[1], dtype=np.int64)
+            if d.size == 0:
+                d = np.zeros(1, dtype=np.uint8)
+            keep.extend((d, o))
+            kinds.append(0)
+            data.append(d.ctypes.data)
+            offs.append(o.ctypes.data)
+            n = len(o) - 1
+        else:
+            a = np.asarray(col)
+            a = np.ascontiguousarray(a, dtype=np.float64 if a.dtype.kind == "f" else np.int64)
+            if a.size == 0:
+                a = np.zeros(1, dtype=a.dtype)
+            keep.append(a)
+            kinds.append(2 if a.dtype.kind == "f" else 1)
+            data.append(a.ctypes.data)
+            offs.append(None)
+            n = len(np.asarray(col))
+        if n_rows is None:
+            n_rows = n
+        elif n != n_rows:
+            raise ValueError("columns of different lengths")
+    nc = len(kinds)
+    k = np.array(kinds or [0], dtype=np.int32)
+    dp = (_vp * max(nc, 1))(*data)
+    op = (_vp * max(nc, 1))(*offs)
+    out, out_len = _vp(), ctypes.c_int64(0)
+    _check(lib.gecco_crf_tsv_format(n_rows or 0, nc, _ptr(k, _c_i32p), dp, op, header.encode("utf-8"), ctypes.byref(out),
+                                    ctypes.byref(out_len)))
+    try:
+        return ctypes.string_at(out.value, out_len.value)
+    finally:
+        lib.gecco_crf_buffer_free(out)
 
 
 def exact_mean(values) -> float:

@@ -1,5 +1,6 @@
 // extern "C" surface declared in include/gecco_crf.h.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -675,3 +676,19 @@ GECCO_API int gecco_crf_cluster_rows_strings(const gecco_crf_cluster_rows *r, in
     return GECCO_CRF_OK;
 }
 GECCO_API double gecco_crf_exact_mean(const double *v, int64_t n) { return (v && n > 0) ? exact_mean(v, n) : std::nan(""); }
+
+GECCO_API int gecco_crf_tsv_format(int64_t n_rows, int32_t n_cols, const int32_t *kinds, const void *const *data,
+                                   const int64_t *const *offsets, const char *header, uint8_t **out, int64_t *out_len) {
+    if (n_rows < 0 || n_cols < 0 || !out || !out_len || (n_cols > 0 && (!kinds || !data || !offsets))) return GECCO_CRF_EINVAL;
+    *out = nullptr;
+    *out_len = 0;
+    for (int32_t c = 0; c < n_cols; ++c)
+        if (kinds[c] < 0 || kinds[c] > 2 || (n_rows > 0 && !data[c]) || (kinds[c] == 0 && !offsets[c])) {
+            set_error("tsv_format: bad column");
+            return GECCO_CRF_EINVAL;
+        }
+    GECCO_GUARD_BEGIN
+    return format_tsv(n_rows, n_cols, kinds, data, offsets, header, out, out_len);
+    GECCO_GUARD_END
+}
+GECCO_API void gecco_crf_buffer_free(uint8_t *p) { std::free(p); }

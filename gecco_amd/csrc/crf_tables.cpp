@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <charconv>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -914,6 +915,123 @@ int cluster_rows(const Packed &pk, const gecco_crf_table_columns &t, const int64
         }
     }
     ph.lap("cluster rows");
+    return GECCO_CRF_OK;
+}
+
+}  // namespace gecco
+
+// ---- TSV text of a table (gecco/_base.py:133-152 dump rules: tab-separated, NaN as an empty field) ---------
+// Floats are written the way Python's repr() writes them (the reference goes through polars / csv with repr
+// digits; the golden tables are compared byte for byte): the SHORTEST digit string that round-trips
+// (std::to_chars), in positional notation when -4 <= exponent < 16, else d.ddde+XX.
+namespace gecco {
+namespace {
+inline char *put_float_repr(char *p, double v) {
+    if (v != v) return p;  // NaN: empty field
+    if (std::isinf(v)) {
+        const char *s = v > 0 ? "inf" : "-inf";
+        const size_t n = std::strlen(s);
+        std::memcpy(p, s, n);
+        return p + n;
+    }
+    char sci[40];
+    const auto r = std::to_chars(sci, sci + sizeof(sci) - 1, v, std::chars_format::scientific);
+    *r.ptr = 0;  // sci = [-]d[.ddd]e[+-]XX
+    char *q = sci;
+    if (*q == '-') *p++ = *q++;
+    char digits[24];
+    int nd = 0;
+    digits[nd++] = *q++;
+    if (*q == '.') {
+        ++q;
+        while (*q != 'e') digits[nd++] = *q++;
+    }
+    ++q;  // 'e'
+    const int ex = int(std::strtol(q, nullptr, 10));
+    const int decpt = ex + 1;  // position of the decimal point relative to the first digit
+    if (decpt > 16 || decpt < -3) {  // repr: exponential outside 1e-4 <= |v| < 1e16
+        *p++ = digits[0];
+        if (nd > 1) {
+            *p++ = '.';
+            std::memcpy(p, digits + 1, size_t(nd - 1));
+            p += nd - 1;
+        }
+        *p++ = 'e';
+        *p++ = ex < 0 ? '-' : '+';
+        const int ax = ex < 0 ? -ex : ex;
+        if (ax < 10) *p++ = '0';
+        const auto r2 = std::to_chars(p, p + 8, ax);
+        return r2.ptr;
+    }
+    if (decpt <= 0) {  // 0.000ddd
+        *p++ = '0';
+        *p++ = '.';
+        for (int k = 0; k < -decpt; ++k) *p++ = '0';
+        std::memcpy(p, digits, size_t(nd));
+        return p + nd;
+    }
+    if (decpt >= nd) {  // ddd000.0
+        std::memcpy(p, digits, size_t(nd));
+        p += nd;
+        for (int k = nd; k < decpt; ++k) *p++ = '0';
+        *p++ = '.';
+        *p++ = '0';
+        return p;
+    }
+    std::memcpy(p, digits, size_t(decpt));
+    p += decpt;
+    *p++ = '.';
+    std::memcpy(p, digits + decpt, size_t(nd - decpt));
+    return p + (nd - decpt);
+}
+}  // namespace
+
+// kinds: 0 = text (data + offsets), 1 = int64, 2 = float64.  Returns a malloc'ed buffer.
+int format_tsv(int64_t n_rows, int32_t n_cols, const int32_t *kinds, const void *const *data, const int64_t *const *offsets,
+               const char *header, uint8_t **out, int64_t *out_len) {
+    const int workers = worker_count(n_rows * n_cols / 4 + 1);
+    std::vector<std::vector<char>> piece(static_cast<size_t>(workers));
+    parallel_ranges(n_rows, workers, [&](int64_t b, int64_t e, int w) {
+        std::vector<char> &buf = piece[size_t(w)];
+        size_t text = 0;
+        for (int32_t c = 0; c < n_cols; ++c)
+            if (kinds[c] == 0) text += size_t(offsets[c][e] - offsets[c][b]);
+        buf.resize(text + size_t(e - b) * size_t(n_cols) * 26 + 64);
+        char *p = buf.data();
+        for (int64_t i = b; i < e; ++i) {
+            for (int32_t c = 0; c < n_cols; ++c) {
+                if (c) *p++ = '\t';
+                if (kinds[c] == 0) {
+                    const int64_t a0 = offsets[c][i], a1 = offsets[c][i + 1];
+                    std::memcpy(p, static_cast<const uint8_t *>(data[c]) + a0, size_t(a1 - a0));
+                    p += a1 - a0;
+                } else if (kinds[c] == 1) {
+                    p = std::to_chars(p, p + 24, static_cast<const int64_t *>(data[c])[i]).ptr;
+                } else {
+                    p = put_float_repr(p, static_cast<const double *>(data[c])[i]);
+                }
+            }
+            *p++ = '\n';
+        }
+        buf.resize(size_t(p - buf.data()));
+    });
+    const size_t hl = header ? std::strlen(header) : 0;
+    size_t total = hl;
+    for (const auto &b : piece) total += b.size();
+    uint8_t *res = static_cast<uint8_t *>(std::malloc(total ? total : 1));
+    if (!res) {
+        set_error("out of host memory");
+        return GECCO_CRF_ENOMEM;
+    }
+    size_t at = 0;
+    if (hl) std::memcpy(res, header, hl);
+    at = hl;
+    for (const auto &b : piece) {
+        if (!b.empty()) std::memcpy(res + at, b.data(), b.size());
+        at += b.size();
+    }
+    *out = res;
+    *out_len = int64_t(total);
     return GECCO_CRF_OK;
 }
 

@@ -38,5 +38,7 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out);
 int cluster_rows(const Packed &pk, const gecco_crf_table_columns &t, const int64_t *gene_end, const int64_t *feat_end,
                  const int32_t *seg, int32_t n_seg, const double *seg_p, const int64_t *seg_off, ClusterRows &out);
 double exact_mean(const double *v, int64_t n);
+int format_tsv(int64_t n_rows, int32_t n_cols, const int32_t *kinds, const void *const *data, const int64_t *const *offsets,
+               const char *header, uint8_t **out, int64_t *out_len);
 
 }  // namespace gecco

@@ -226,6 +226,31 @@ class _Table:
 
     def dump(self, fh: Union[str, TextIO]) -> None:
         names = self._dump_columns()
+        if len(self) > 64:
+            # bulk tables: formatted natively (gecco_crf_tsv_format: several host threads, floats with repr()
+            # digits, NaN as an empty field) -- the same bytes the row-by-row writer below produces
+            try:
+                from . import _native
+
+                types = {name: typ for name, typ, _ in self.COLUMNS}
+                cols = []
+                for n in names:
+                    col = self.columns[n]
+                    if types.get(n, str) is str or isinstance(col, StringColumn):
+                        sc = as_string_column(col)
+                        cols.append((sc.data, sc.offsets))
+                    else:
+                        cols.append(np.asarray(col, dtype=np.float64 if types[n] is float else np.int64))
+                text = _native.tsv_format("\t".join(names) + "\n", cols)
+            except (ImportError, OSError):
+                text = None
+            if text is not None:
+                if isinstance(fh, str):
+                    with open(fh, "wb") as f:
+                        f.write(text)
+                else:
+                    fh.write(text.decode("utf-8"))
+                return
         if _pd is not None and len(self) > 64:
             # floats are written with repr() digits (shortest round trip), NaN as an empty field
             _pd.DataFrame({n: (self.columns[n].to_objects() if isinstance(self.columns[n], StringColumn) else self.columns[n])

@@ -264,6 +264,13 @@ int gecco_crf_cluster_rows_strings(const gecco_crf_cluster_rows *r, int32_t whic
                                    const int64_t **offsets);
 /* statistics.mean of the non-NaN values: the exact sum divided by the count, rounded once. */
 double gecco_crf_exact_mean(const double *v, int64_t n);
+/* TSV text of a table, the wire format either side of the path (gecco/_base.py:133-152): `header` first, then
+ * n_rows lines of tab-separated cells.  kinds[c]: 0 text (data[c] bytes + offsets[c]), 1 int64, 2 float64; floats
+ * are written with the shortest digits that round-trip, laid out as Python's repr() does, NaN as an empty field.
+ * *out is malloc'ed: release it with gecco_crf_buffer_free. */
+int gecco_crf_tsv_format(int64_t n_rows, int32_t n_cols, const int32_t *kinds, const void *const *data,
+                         const int64_t *const *offsets, const char *header, uint8_t **out, int64_t *out_len);
+void gecco_crf_buffer_free(uint8_t *p);
 
 #ifdef __cplusplus
 }
