@@ -82,13 +82,22 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # GECCO_BENCH_ONE_DEVICE=1 (dry runs of the N > 1 code path on a one-GPU box): every rank on device 0, gloo
+    one_device = os.environ.get("GECCO_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    red_dev = dev
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group(backend="gloo")
+            red_dev = torch.device("cpu")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from gecco_amd import _native as nat
     from gecco_amd import sharding, synth
@@ -134,7 +143,7 @@ def main() -> None:
             barrier()
             elapsed = time.perf_counter() - t0
             if dist is not None:
-                t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 elapsed = float(t.item())
             return elapsed
@@ -142,7 +151,7 @@ def main() -> None:
     def all_sum(v):
         if dist is None:
             return int(v)
-        g = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        g = torch.tensor([int(v)], dtype=torch.int64, device=red_dev)
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         return int(g.item())
 
