@@ -111,6 +111,7 @@ struct SeqArgs {
     double t00, t01, t10, t11;  // raw transition weights (Viterbi)
     double mx;                  // max(trans)
     double v_lo, v_hi, v_k;     // difference-form Viterbi: t01-t11, t00-t10, t11-t00
+    int32_t v_exact;            // 1: decisions within rounding noise of a threshold are re-derived sequentially (GECCO_CRF_VD_EXACT=0: A/B runs)
     double expc[12];            // Taylor coefficients of exp (SGPR-resident), see exp_neg
     // workspaces: one element per lane (n_genes / kSeqGenesPerLane) or per workgroup
     VE *vLane, *vBlock;

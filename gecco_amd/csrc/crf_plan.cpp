@@ -721,6 +721,10 @@ int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
     a.v_lo = a.t01 - a.t11;
     a.v_hi = a.t00 - a.t10;
     a.v_k = a.t11 - a.t00;
+    {
+        const char *env = std::getenv("GECCO_CRF_VD_EXACT");
+        a.v_exact = (env && env[0] == '0') ? 0 : 1;
+    }
     fill_exp_coefficients(a.expc);
     return GECCO_CRF_OK;
 }

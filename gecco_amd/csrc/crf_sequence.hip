@@ -576,16 +576,83 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
     }
     CE total;
     const CE M = block_scan_exclusive<COp, false>(P, lds, &total);  // the workgroup starts at a contig start
-    double D = M.L;
+    // ---- exact entering values.  M comes from COMPOSED maps: its additions are associated differently from the
+    // sequential recursion, so M.L may differ from the sequential Delta in the last bits, and a decision that
+    // lies within that noise of a threshold would depend on how the scan happens to be cut.  The clamp FORGETS:
+    // wherever Delta_t lies beyond [lo, hi] by more than the noise, Delta_{t+1} = bound + c_{t+1} whatever came
+    // before.  So: one approximate pass marks those positions, every lane walks back to the nearest one (or
+    // to its contig's first gene) and re-runs the recursion sequentially from there -- a few genes on
+    // average -- and the decisions below are those of the strictly sequential difference recursion, bit for
+    // bit, independent of lane and workgroup boundaries (oracle_viterbi_delta is that recursion).
+    const double margin = 1e-6 * fmax(1.0, fmax(fabs(A.v_lo), fabs(A.v_hi)));
     uint32_t maps = 0, lane_map = MapOp::identity();
+    bool sensitive = false;  // some decision of this lane lies within the noise of its threshold
+    {
+        double Dq = M.L;
 #pragma unroll
-    for (int k = 0; k < kGPL; ++k) {
-        if (k < cnt) {
-            D = ((first >> k) & 1u) ? dv[k] : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dv[k]);
-            const uint32_t m = ((last >> k) & 1u) ? (D > 0.0 ? 3u : 0u) : ((D > A.v_hi ? 1u : 0u) | (D > A.v_lo ? 2u : 0u));
-            maps |= m << (2 * k);
+        for (int k = 0; k < kGPL; ++k) {
+            if (k < cnt) {
+                Dq = ((first >> k) & 1u) ? dv[k] : fmin(fmax(Dq, A.v_lo), A.v_hi) + (A.v_k + dv[k]);
+                const bool lst = (last >> k) & 1u;
+                const uint32_t m = lst ? (Dq > 0.0 ? 3u : 0u) : ((Dq > A.v_hi ? 1u : 0u) | (Dq > A.v_lo ? 2u : 0u));
+                maps |= m << (2 * k);
+                sensitive |= lst ? fabs(Dq) <= margin : (fabs(Dq - A.v_hi) <= margin || fabs(Dq - A.v_lo) <= margin);
+            }
         }
     }
+    // (one barrier either way: the workgroup learns whether any of its lanes has to look back)
+    if (__syncthreads_or((sensitive && A.v_exact) ? 1 : 0)) {
+        // marks for the walk: per gene 1 = beyond hi, 2 = beyond lo (after this gene), 0 = inside or too close to tell
+        double Dq = M.L;
+        uint64_t sat = 0;
+#pragma unroll
+        for (int k = 0; k < kGPL; ++k) {
+            if (k < cnt) {
+                Dq = ((first >> k) & 1u) ? dv[k] : fmin(fmax(Dq, A.v_lo), A.v_hi) + (A.v_k + dv[k]);
+                const uint64_t c = Dq >= A.v_hi + margin ? 1u : (Dq <= A.v_lo - margin ? 2u : 0u);
+                sat |= c << (8 * k);
+            }
+        }
+        *reinterpret_cast<uint64_t *>(stg.yb + slot * kGPL) = sat;
+        __syncthreads();
+    } else {
+        sensitive = false;
+    }
+    // A lane whose decisions all keep their distance from the thresholds has the sequential decisions already (its
+    // values differ from the sequential ones by less than the margin at every gene: the clamp does not amplify, the
+    // additions are the same).  Any other lane (ties of integer-weight models; otherwise one gene in a million)
+    // rebuilds its entering value sequentially and decides again.
+    if (sensitive && cnt > 0) {
+        double D = 0.0;  // Delta of the gene before the lane's first, rebuilt sequentially
+        if (!(first & 1u)) {
+            // nearest restart at or before gene t0 - 1: a contig's first gene, or a gene whose predecessor is marked
+            const int t0 = slot * kGPL;  // local index of the lane's first gene (> 0 here: gene 0 starts a contig)
+            int p = t0 - 1;
+            auto dval = [&](int t) { return stg.st[(t / kGPL) * (kGPL + 1) + t % kGPL]; };
+            for (;; --p) {
+                if (stg.fl[p] & 1u) {
+                    D = dval(p);
+                    break;
+                }
+                const uint32_t c = stg.yb[p - 1];  // p >= 1: local gene 0 is a contig's first
+                if (c) {
+                    D = (c == 1u ? A.v_hi : A.v_lo) + (A.v_k + dval(p));
+                    break;
+                }
+            }
+            for (int t = p + 1; t < t0; ++t) D = fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dval(t));
+        }
+        maps = 0;
+#pragma unroll
+        for (int k = 0; k < kGPL; ++k) {
+            if (k < cnt) {
+                D = ((first >> k) & 1u) ? dv[k] : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dv[k]);
+                const uint32_t m = ((last >> k) & 1u) ? (D > 0.0 ? 3u : 0u) : ((D > A.v_hi ? 1u : 0u) | (D > A.v_lo ? 2u : 0u));
+                maps |= m << (2 * k);
+            }
+        }
+    }
+    __syncthreads();  // the marks in stg.yb have been read: the label bytes go there below
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k)
         if (k < cnt) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);

@@ -265,6 +265,46 @@ ORACLE_API int oracle_viterbi(const double *w, const double *trans, int A, int L
     return 0;
 }
 
+/* ---- row V, difference form: the SPECIFICATION of the device's 2-label label-only Viterbi kernels
+ * (gecco_amd/csrc/crf_sequence.hip).  With Delta = delta[1] - delta[0] and d = s[1] - s[0], crf1dc_viterbi's
+ * recursion reads  Delta_t = clamp(Delta_{t-1}, lo, hi) + (t11 - t00) + d_t,  lo = t01 - t11, hi = t00 - t10
+ * (requires lo <= hi), back-pointers (Delta_{t-1} > hi, Delta_{t-1} > lo), end label Delta_T > 0 (strict:
+ * the first arg max).  Algebraically identical to oracle_viterbi; numerically it rounds differently (its
+ * quantities stay O(1)), so labels can only differ where a decision lies within rounding noise.  The device
+ * reproduces THIS recursion bit for bit for contigs of up to 2048 genes. */
+ORACLE_API int oracle_viterbi_delta(const double *w, const double *trans, int A, int L,
+                                    const int32_t *contig_ptr, int n_contigs,
+                                    const int32_t *gene_ptr, const int32_t *attr_id, int32_t *labels)
+{
+    (void)A;
+    if (L != 2) return -1;
+    const double t00 = trans[0], t01 = trans[1], t10 = trans[2], t11 = trans[3];
+    const double lo = t01 - t11, hi = t00 - t10, k = t11 - t00;
+    if (!(lo <= hi)) return -2;
+    for (int ci = 0; ci < n_contigs; ++ci) {
+        int g0 = contig_ptr[ci], n = contig_ptr[ci + 1] - g0;
+        if (n == 0) continue;
+        double *state = (double *)malloc(sizeof(double) * (size_t)n * 2);
+        unsigned char *bp = (unsigned char *)malloc((size_t)n);
+        state_scores(w, L, gene_ptr, attr_id, g0, n, 0, n, state);
+        double D = state[1] - state[0];
+        for (int t = 1; t < n; ++t) {
+            bp[t] = (unsigned char)((D > hi ? 1 : 0) | (D > lo ? 2 : 0)); /* bit y: predecessor of label y */
+            double c = D < lo ? lo : D;
+            c = c > hi ? hi : c;
+            D = c + (k + (state[2 * t + 1] - state[2 * t]));
+        }
+        int y = D > 0.0 ? 1 : 0;
+        labels[g0 + n - 1] = y;
+        for (int t = n - 1; t >= 1; --t) {
+            y = (bp[t] >> y) & 1;
+            labels[g0 + t - 1] = y;
+        }
+        free(state); free(bp);
+    }
+    return 0;
+}
+
 /* ---- row R: GeneGrouper + ClusterRefiner, criterion "gecco" ------------------------
  * gecco/refine.py:51-64 (stateful grouper: a gene without probability inherits the
  * previous gene's state; ONE grouper instance spans all contigs of an iter_clusters call, :186),

@@ -198,6 +198,20 @@ def viterbi_seq(state, trans):
     return lab, sc.value
 
 
+def viterbi_delta(w, trans, contig_ptr, gene_ptr, attr_id):
+    """Labels of the 2-label Viterbi recursion in its difference form, evaluated strictly sequentially: the
+    specification the device's label-only kernels reproduce bit for bit (see oracle_viterbi_delta)."""
+    w, trans, contig_ptr, gene_ptr, attr_id = _prep(w, trans, contig_ptr, gene_ptr, attr_id)
+    A, L = w.shape
+    n = int(contig_ptr[-1])
+    labels = np.zeros(max(n, 1), dtype=np.int32)
+    rc = lib().oracle_viterbi_delta(_p(w, _D), _p(trans, _D), A, L, _p(contig_ptr, _I), len(contig_ptr) - 1,
+                                    _p(gene_ptr, _I), _p(attr_id, _I), _p(labels, _I))
+    if rc:
+        raise ValueError("difference form needs 2 labels and trans[0][1] - trans[1][1] <= trans[0][0] - trans[1][0]")
+    return labels[:n]
+
+
 def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, trim=True, carry_state=False):
     p = np.ascontiguousarray(p, dtype=np.float64)
     annotated = np.ascontiguousarray(annotated, dtype=np.uint8)

@@ -237,3 +237,59 @@ def test_empty_inputs(real):
     assert marg.shape == (0, 2) and ln.shape == (0,)
     y, sc = real.viterbi([0, 0, 3], [0, 1, 1, 2], [5, 7])
     assert y.shape == (3,) and sc[0] == 0.0
+
+
+def test_viterbi_short_contigs_reproduce_the_sequential_difference_recursion(nat):
+    """Decisions must not depend on how the scan is cut.  Values entering a lane come from COMPOSED clamp maps,
+    whose additions are associated differently from the sequential recursion; `vd_short` therefore rebuilds
+    every entering value sequentially from the last position where the clamp had forgotten the past.  The
+    contigs below never saturate (transitions +-1000) and end on a score difference of EXACTLY zero in the
+    sequential recursion -- one ulp of re-association noise flips the end label and with it every label of the
+    contig.  Checker: oracle.viterbi_delta, the strictly sequential recursion (and CRFsuite's own form, which
+    sees the same exact tie)."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(77)
+    lengths = [int(x) for x in rng.integers(17, 400, size=600)]
+    n = sum(lengths)
+    trans = np.array([[0.0, -1000.0], [-1000.0, 0.0]])
+    w = np.zeros((n, 2))
+    gptr = np.arange(n + 1, dtype=np.int32)          # gene g carries attribute g alone: d_g = w[g][1]
+    attr = np.arange(n, dtype=np.int32)
+    cptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    sensitive = 0
+    for c, T in enumerate(lengths):
+        d = rng.uniform(-1.0, 1.0, size=T)
+        D = d[0]
+        for t in range(1, T - 1):
+            D = D + (0.0 + d[t])                      # the recursion without saturation, sequentially
+        d[T - 1] = -D                                  # ... ends on exactly 0: label 0 (strict >)
+        w[cptr[c]:cptr[c + 1], 1] = d
+        # would a scan that adds the genes of lanes 1.. first, then the first lane, see it differently?
+        grouped = d[0] + (np.sum(d[8:T - 1]) if T > 9 else 0.0) + np.sum(d[1:8])
+        sensitive += int(grouped + d[T - 1] != 0.0)
+    assert sensitive > 50  # the case is real: re-association changes the last bits for many contigs
+    model = nat.Model.from_tables(w, trans)
+    exp = orc.viterbi_delta(w, trans, cptr, gptr, attr)
+    assert int(exp.sum()) == 0
+    y, _ = model.viterbi(cptr, gptr, attr, want_score=False)
+    np.testing.assert_array_equal(y.astype(np.int32), exp)
+    ey, _ = orc.viterbi(w, trans, cptr, gptr, attr)   # CRFsuite's form: delta[1] accumulates the same sums
+    np.testing.assert_array_equal(ey, exp)
+    # and through the decode path (state differences written by the windowed kernel)
+    ses = nat.Session(model, [0])
+    _, y2 = ses.decode(cptr, gptr, attr, 20)
+    np.testing.assert_array_equal(y2.astype(np.int32), exp)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_viterbi_short_contigs_equal_sequential_recursion_on_random_models(nat, seed):
+    from oracle import crf_oracle as orc
+    from tests.helpers import synth_contigs, synth_model
+
+    rng = np.random.default_rng(900 + seed)
+    A = 500
+    w, trans = synth_model(A, rng)
+    cptr, gptr, attr = synth_contigs(rng, list(rng.integers(1, 2048, size=80)) + [2048, 2047, 1, 9, 8], A)
+    y, _ = nat.Model.from_tables(w, trans).viterbi(cptr, gptr, attr, want_score=False)
+    np.testing.assert_array_equal(y.astype(np.int32), orc.viterbi_delta(w, trans, cptr, gptr, attr))
