@@ -26,6 +26,7 @@ struct WinArgs {
     int32_t K, S, ntiles, W, step, L, label;
     int32_t n_genes, A;        // CSR extent and weight-table rows (buffer descriptors)
     int32_t tiles_per_wg;      // DP phases per workgroup of the fast kernel (plan geometry)
+    int32_t all_regular;       // no padded or skipped contig in the whole batch: slot space = gene space, tile_desc unused
     uint32_t rescale_mask;     // bit k: renormalise the DP vectors after step k
     // transitions in the transformed basis (rows/cols ordered (other, label)):
     //   mu01 = m01*m10/m00^2, mu11 = m11/m00, kappa = m10/m00, rho = mu11/mu01  with m = exp(trans)

@@ -83,8 +83,9 @@ struct WinSmem {
     static constexpr int CAP = TT == 1 ? NT + WMAX - 1 : TT * NT;  // slot capacity of the workgroup
     // a contig occupies at least W slots (shorter ones are padded or not scored at all)
     static constexpr int CMAX = EXACT ? CAP / WMAX + 3 : CAP + 2;  // contigs a workgroup can overlap
-    f64x2 ef[CAP];                  // per slot: (e0, f = mu01*e1) with e = exp(s - max s), "other" first; or, in the
-                                    // ratio form, CAP doubles r = f / e0 = mu01 exp(s[label] - s[other]) in its first half
+    f64x2 ef[2 * CAP];              // first CAP entries, per slot: (e0, f = mu01*e1) with e = exp(s - max s), "other" first; or,
+                                    // in the ratio form, CAP doubles r = f / e0 = mu01 exp(s[label] - s[other]) in its first quarter.
+                                    // Before that, all 2 CAP entries park the weight pairs of the workgroup's attributes (stage 1).
     uint32_t ginfo[CAP];            // per slot: bit 31 = a window may start here; low bits = gene + 1 (0: none)
     f64x2 carry[NT / 64][WMAX];     // running best leaving lane 63 of each wave, per step
     int32_t cslot[CMAX];            // slot offsets of the contigs this workgroup overlaps (irregular tiles)
@@ -155,7 +156,7 @@ __device__ __forceinline__ void state_scores_buf(__amdgpu_buffer_rsrc_t ra, __am
         i32x4 w[kGatherUnroll];
 #pragma unroll
         for (int u = 0; u < kGatherUnroll; ++u) {
-            const uint32_t wo = base + u < cnt ? uint32_t(a[u]) << 4 : 0xFFFFFFF0u;
+            const uint32_t wo = base + u < cnt ? min(uint32_t(a[u]), 0x0FFFFFFFu) << 4 : 0xFFFFFFF0u;
             w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, int(wo), 0, 0);
         }
 #pragma unroll
@@ -198,7 +199,9 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
     // case) maps slots to genes by a constant shift and takes its window-start flags from a
     // host-built bit array, so the CSR loads can leave immediately; otherwise the contig
     // table of its reach goes through LDS and every lane searches it.
-    const int4 td = P.tile_desc[tile];  // (gene - slot shift, first contig, last contig, flags)
+    // (gene - slot shift, first contig, last contig, flags).  A batch without any padded or skipped contig (the
+    // normal case) has slot space = gene space everywhere: no descriptor to wait for, the first CSR load leaves at once
+    const int4 td = P.all_regular ? make_int4(0, 0, 0, 1) : P.tile_desc[tile];
     int gene[JMAX];
     bool start[JMAX];
 #pragma unroll
@@ -247,49 +250,132 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(P.wtab2), 0, uint32_t(P.A) << 4, 0x00020000);
 
-    // ---- stage 1: CSR row bounds -> attribute ids -> weight pairs -> slot constants in LDS.
-    // The row bounds and then the first kGatherUnroll attribute ids of ALL of the lane's slots are
-    // requested before anything is waited for.
-    uint32_t off[JMAX], cnt[JMAX];
+    // ---- stage 1: state scores of the workgroup's slots -> slot constants in LDS.
+    double sc0[JMAX], sc1[JMAX];  // s[other], s[label] of the lane's slots
 #pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-        int lo = 0, hi = 0;
-        if (gene[j] >= 0) {
-            lo = P.gene_ptr[gene[j]];
-            hi = P.gene_ptr[gene[j] + 1];
+    for (int j = 0; j < JMAX; ++j) sc0[j] = sc1[j] = 0.0;
+#ifdef GECCO_EXP_SKIP_GATHER  // experiment: DP alone (no attribute / weight loads)
+    if (false) {
+#else
+    if (td.w & 1) {
+#endif
+        // Regular workgroup (the normal case): its slots are CONSECUTIVE GENES, so their attribute ids are one
+        // contiguous stretch of the CSR.  The stretch is loaded attribute-per-lane -- consecutive lanes take
+        // consecutive ids (coalesced), every id gathers its weight pair once -- parked in LDS (over the area the
+        // slot constants will occupy afterwards), and each slot then adds up its own run from there, in CSR
+        // order (bit-exact with sequential addition).  The first version of this stage gave every SLOT eight
+        // speculative id loads and eight weight gathers whatever its number of domains (1.4 on average): 36
+        // vector memory instructions per lane, of which the 16-byte gathers alone kept the texture path of a CU
+        // busy for ~9 us per launch; the stage took 19.6 us on its own (DP alone: 21.2 us, both: 28.3 us).
+        uint32_t lo[JMAX], hi[JMAX];
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            lo[j] = hi[j] = 0;
+            if (gene[j] >= 0) {
+                lo[j] = uint32_t(P.gene_ptr[gene[j]]);
+                hi[j] = uint32_t(P.gene_ptr[gene[j] + 1]);
+            }
         }
-        off[j] = uint32_t(lo) - lo_tile;
-        cnt[j] = uint32_t(hi - lo);
+        const int q_end = min(q0 + ns, P.S);  // one past the workgroup's last slot
+        const uint32_t hi_tile = uint32_t(P.gene_ptr[q_end + td.x]);
+        const uint32_t n_attr = hi_tile - lo_tile;
+        // parking area: the upper three quarters of `ef` -- the ratio form's slot constants (the lower quarter) never
+        // touch it, so no barrier is needed between the sums and those writes; the max-normalised pairs (lower
+        // half) are only built behind the workgroup-wide vote below
+        constexpr int SBASE = (Smem::CAP + 1) / 2;
+        constexpr int APL = (2 * Smem::CAP - SBASE) / NT;  // attributes per lane and round
+        constexpr int SCAP = APL * NT;                     // weight pairs parked at a time
+        static_assert(APL >= 1, "parking area smaller than one round of the workgroup");
+        f64x2 *park = sm.ef + SBASE;
+#pragma unroll 1
+        for (uint32_t base = 0; base < n_attr; base += SCAP) {
+            int id[APL];
+#pragma unroll
+            for (int a = 0; a < APL; ++a) id[a] = __builtin_amdgcn_raw_buffer_load_b32(ra, int((base + a * NT + tid) << 2), 0, 0);
+            i32x4 w[APL];
+#pragma unroll
+            for (int a = 0; a < APL; ++a) {
+                // ids past the stretch belong to later genes (or read 0 past the array): their pairs are parked
+                // and never used; ids outside the dictionary land outside the table and read (+0.0, +0.0)
+                const uint32_t wo = min(uint32_t(id[a]), 0x0FFFFFFFu) << 4;
+                w[a] = __builtin_amdgcn_raw_buffer_load_b128(rw, int(wo), 0, 0);
+            }
+#pragma unroll
+            for (int a = 0; a < APL; ++a)
+                park[a * NT + tid] = f64x2{__hiloint2double(w[a].y, w[a].x), __hiloint2double(w[a].w, w[a].z)};
+            __syncthreads();
+            const uint32_t c0 = lo_tile + base, c1 = c0 + SCAP;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                uint32_t k = max(lo[j], c0) - c0;
+                const uint32_t e = min(hi[j], c1) - c0;  // (k >= e when the run lies outside this round)
+                for (; k < e && hi[j] > c0; ++k) {
+                    const f64x2 v = park[k];
+                    sc0[j] += v.x;
+                    sc1[j] += v.y;
+                }
+            }
+            if (base + SCAP < n_attr) __syncthreads();  // the parking area is reused by the next round
+        }
+        // kernels without the ratio form write 16-byte slot constants over the whole lower half right away
+        if (!RATIO && n_attr > 0) __syncthreads();
+    } else {
+        // Irregular workgroup (a padded or skipped contig in reach): slots are looked up one by one; every slot
+        // requests its row bounds, then its first kGatherUnroll attribute ids, then their weight pairs, all of
+        // them before anything is waited for.
+        uint32_t off[JMAX], cnt[JMAX];
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            int lo = 0, hi = 0;
+            if (gene[j] >= 0) {
+                lo = P.gene_ptr[gene[j]];
+                hi = P.gene_ptr[gene[j] + 1];
+            }
+            off[j] = uint32_t(lo) - lo_tile;
+            cnt[j] = uint32_t(hi - lo);
+        }
+#ifdef GECCO_EXP_SKIP_GATHER
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) cnt[j] = 0;
+#endif
+        int ids[JMAX][kGatherUnroll];
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j)
+            if (TT > 1 || j == 0 || wave == 0) {
+#pragma unroll
+                for (int u = 0; u < kGatherUnroll; ++u)
+                    ids[j][u] = __builtin_amdgcn_raw_buffer_load_b32(ra, int((off[j] + u) << 2), 0, 0);
+            }
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            if (TT > 1 || j == 0 || wave == 0) {
+                double s0 = 0.0, s1 = 0.0;
+                i32x4 w[kGatherUnroll];
+#pragma unroll
+                for (int u = 0; u < kGatherUnroll; ++u) {
+                    const uint32_t wo = uint32_t(u) < cnt[j] ? min(uint32_t(ids[j][u]), 0x0FFFFFFFu) << 4 : 0xFFFFFFF0u;
+                    w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, int(wo), 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < kGatherUnroll; ++u) {
+                    s0 += __hiloint2double(w[u].y, w[u].x);
+                    s1 += __hiloint2double(w[u].w, w[u].z);
+                }
+                if (cnt[j] > uint32_t(kGatherUnroll))  // rare: a gene with more than 8 domains
+                    state_scores_buf(ra, rw, off[j] + kGatherUnroll, cnt[j] - kGatherUnroll, s0, s1);
+                sc0[j] = s0;
+                sc1[j] = s1;
+            }
+        }
     }
     bool big = false;  // some slot leans so far towards the label that the ratio form could overflow
     double dsl[JMAX];  // s[label] - s[other] of the lane's slots
     double *rr = reinterpret_cast<double *>(sm.ef);  // ratio form: r per slot, in the first half of the (e0, f) array
-    int ids[JMAX][kGatherUnroll];
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j)
-        if (TT > 1 || j == 0 || wave == 0) {
-#pragma unroll
-            for (int u = 0; u < kGatherUnroll; ++u)
-                ids[j][u] = __builtin_amdgcn_raw_buffer_load_b32(ra, int((off[j] + u) << 2), 0, 0);
-        }
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
         if (TT > 1 || j == 0 || wave == 0) {
             const int sl = tid + j * NT;
-            double s0 = 0.0, s1 = 0.0;
-            i32x4 w[kGatherUnroll];
-#pragma unroll
-            for (int u = 0; u < kGatherUnroll; ++u) {
-                const uint32_t wo = uint32_t(u) < cnt[j] ? uint32_t(ids[j][u]) << 4 : 0xFFFFFFF0u;
-                w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, int(wo), 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < kGatherUnroll; ++u) {
-                s0 += __hiloint2double(w[u].y, w[u].x);
-                s1 += __hiloint2double(w[u].w, w[u].z);
-            }
-            if (cnt[j] > uint32_t(kGatherUnroll))  // rare: a gene with more than 8 domains
-                state_scores_buf(ra, rw, off[j] + kGatherUnroll, cnt[j] - kGatherUnroll, s0, s1);
+            const double s0 = sc0[j], s1 = sc1[j];
             // decode = windowed marginals + Viterbi of the same batch: the raw scores of the genes this
             // workgroup owns are handed to the whole-contig kernels instead of being gathered again
             if (sl >= W - 1 && sl < TT * OUT + (W - 1) && gene[j] >= 0) {
@@ -341,6 +427,14 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
 
     const uint32_t rmask = P.rescale_mask;
     const double rho = P.rho;
+#ifdef GECCO_EXP_SKIP_DP  // experiment: stage 1 alone
+    for (int ph = 0; ph < TT; ++ph) {
+        const int sbase = ph * OUT + tid;
+        const int my_gene = int(sm.ginfo[sbase] & 0x7fffffffu) - 1;
+        if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = rr[sbase];
+    }
+    return;
+#endif
 #pragma unroll 1
     for (int ph = 0; ph < TT; ++ph) {
         const int sbase = ph * OUT + tid;  // slot of this lane's window start (and of its output)

@@ -305,6 +305,8 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
         const bool gap_after = k + 1 < p.K && p.c_gene[k + 1] != p.c_gene[k] + p.c_n[k];
         irr_prefix[k + 1] = irr_prefix[k] + ((padded || gap_after) ? 1 : 0);
     }
+    // slot space = gene space everywhere: no contig padded, none skipped (empty contigs take no slots and no genes)
+    p.all_regular = p.skipped.empty() && p.S == p.n_genes && irr_prefix[size_t(p.K)] == 0;
     p.tile_desc.resize(p.ntiles);
     {
         // contigs in reach of a workgroup: both ends of the reach only move forward from tile to tile
@@ -537,6 +539,7 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     a.n_genes = p.n_genes;
     a.A = m.A;
     a.tiles_per_wg = p.tiles_per_wg;
+    a.all_regular = p.all_regular ? 1 : 0;
     a.rescale_mask = p.rescale_mask;
     {
         // exp() of differences only: every constant is a ratio of transition weights

@@ -48,6 +48,7 @@ struct Plan {
     std::vector<int32_t> contig_ptr;
     std::vector<int32_t> irr_prefix;  // scratch of plan_build (kept for its capacity)
     uint32_t rescale_mask = 0;
+    bool all_regular = false;   // no padded or skipped contig: every tile maps slots to genes by the identity
     bool fast_ok = false;       // the register-resident kernel takes this shape
     bool force_generic = false; // GECCO_CRF_FORCE_GENERIC=1 (tests): always use the generic kernel
     bool general = false;       // any-L kernels (crf_general.hip): L != 2, or GECCO_CRF_FORCE_GENERAL=1 (tests)
