@@ -70,6 +70,7 @@ def test_session_windowed_chunks(nat, real_model, oracle_model, chunk, pad, pinn
     st = ses.stats()
     assert st["n_chunks"] == max(1, min(len(cptr) - 1, (int(cptr[-1]) + chunk // 2) // chunk))
     assert st["d2h_bytes"] == 8 * len(exp)
+    assert st["h2d_bytes"] == 4 * (len(gptr) + st["n_chunks"] - 1 + len(attr))
 
 
 def test_session_decode_and_one_shot_agree(nat, real_model, oracle_model):
@@ -169,6 +170,32 @@ def test_plan_run_segment_on_device_arrays(nat, real_model, oracle_model):
         k = int(d_n.item())
         exp = orc.segment(p_exp, ann, cptr, thr, 3, 0, True, carry_state=carry)
         assert d_seg[:k].cpu().numpy().tolist() == exp.tolist()
+
+
+def test_session_pinned_buffers_every_output(nat, real_model, oracle_model, monkeypatch):
+    """GECCO_CRF_ZERO_COPY=all: kernels read the CSR from pinned caller buffers (gecco_crf_host_alloc) and write p /
+    labels into them directly; same numbers as with copies (the default), bit for bit."""
+    monkeypatch.setenv("GECCO_CRF_ZERO_COPY", "all")
+    cptr, gptr, attr = _batch(oracle_model, 17)
+    pc, pg, pa = nat.pinned_copy(cptr), nat.pinned_copy(gptr), nat.pinned_copy(attr)
+    n = int(cptr[-1])
+    ses = nat.Session(real_model, [0])
+    ses.set_chunk_genes(6001)  # chunk starts at odd gene offsets: labels of such chunks go through a device buffer
+    p_z, y_z = ses.decode(pc, pg, pa, 20)
+    assert ses.stats()["h2d_bytes"] == 0
+    out = nat.pinned_empty(n, np.float64)
+    np.testing.assert_array_equal(ses.windowed_marginals(pc, pg, pa, 20, out=out), p_z)
+    assert ses.stats()["d2h_bytes"] == 0 and ses.stats()["h2d_bytes"] == 0
+    ann = (np.diff(gptr) > 0).astype(np.uint8)
+    seg_z = ses.clusters(pc, pg, pa, ann, 20, threshold=_threshold(p_z), p_out=out)
+    monkeypatch.delenv("GECCO_CRF_ZERO_COPY")
+    p_c, y_c = ses.decode(pc, pg, pa, 20)
+    assert ses.stats()["h2d_bytes"] > 0
+    np.testing.assert_array_equal(p_z, p_c)
+    np.testing.assert_array_equal(y_z, y_c)
+    seg_c = ses.clusters(pc, pg, pa, ann, 20, threshold=_threshold(p_z), p_out=out)
+    assert seg_z[0].tolist() == seg_c[0].tolist() and len(seg_z[0]) > 5
+    np.testing.assert_array_equal(seg_z[3], seg_c[3])
 
 
 def test_session_argument_errors(nat, real_model):
