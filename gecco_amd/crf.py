@@ -189,7 +189,7 @@ class ClusterCRF(object):
 
     _FILENAME = pickle_model.MODEL_FILENAME
     #: contigs are scored in launches of at most this many genes, `progress` is called after each
-    _BATCH_GENES = 1 << 22
+    _BATCH_GENES = 1 << 20
 
     # ------------------------------------------------------------------ construction
     @classmethod

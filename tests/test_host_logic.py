@@ -500,3 +500,37 @@ def test_native_cluster_rows_match_python_assembly(monkeypatch, threads):
             assert cr["average_p"][k] == statistics.mean(p[a:b].tolist()) and cr["max_p"][k] == p[a:b].max()
         else:
             assert np.isnan(cr["average_p"][k]) and np.isnan(cr["max_p"][k])
+
+
+def test_native_tsv_writer_is_the_row_by_row_writer(monkeypatch):
+    """`gecco_crf_tsv_format` (bulk tables) must produce the bytes of the reference-faithful row-by-row writer:
+    floats with repr() digits in repr()'s layout, NaN as an empty field (gecco/_base.py:133-152)."""
+    import io
+
+    from gecco_amd import _native as nat
+
+    rng = np.random.default_rng(4)
+    vals = np.concatenate([rng.random(3000), rng.random(3000) * 10.0 ** rng.integers(-330, 300, size=3000), -rng.random(50),
+                           [0.0, -0.0, 1e16, 1e15, 123456789012345680.0, 1e-4, 1e-5, 0.0001234, 5e-324,
+                            1.7976931348623157e308, np.nan, np.inf, -np.inf, 100.0, 1e22, 0.1, 2.0 ** 53, 9999999999999998.0]])
+    got = nat.tsv_format("x\n", [vals]).decode().split("\n")[1:-1]
+    assert got == ["" if v != v else repr(float(v)) for v in vals]
+    # a whole table, several host threads: same bytes as the small-table (row by row) path
+    monkeypatch.setenv("GECCO_CRF_HOST_THREADS", "4")
+    monkeypatch.setenv("GECCO_CRF_HOST_GRAIN", "8")
+    n = 300
+    cols = {"sequence_id": np.array([f"c{i // 50}" for i in range(n)], dtype=object),
+            "protein_id": np.array([f"g{i}_é" for i in range(n)], dtype=object), "start": np.arange(n) * 10 - 5,
+            "end": np.arange(n) * 10 + 9, "strand": np.full(n, "+", dtype=object),
+            "average_p": np.where(rng.random(n) < 0.2, np.nan, rng.random(n)), "max_p": rng.random(n) * 1e-7}
+    t = tables.GeneTable(dict(cols))
+    bulk = io.StringIO()
+    t.dump(bulk)
+    names = t._dump_columns()
+    rows = ["\t".join(names)] + ["\t".join(tables._fmt(np.asarray(t.columns[k], dtype=object)[i] if not isinstance(t.columns[k], np.ndarray)
+                                                          or t.columns[k].dtype == object else t.columns[k][i]) for k in names)
+                                 for i in range(n)]
+    assert bulk.getvalue() == "\n".join(rows) + "\n"
+    back = tables.GeneTable.load(io.BytesIO(bulk.getvalue().encode()))
+    assert list(back.protein_id) == list(cols["protein_id"]) and np.array_equal(np.asarray(back.start), cols["start"])
+    np.testing.assert_array_equal(np.asarray(back.average_p), cols["average_p"])
