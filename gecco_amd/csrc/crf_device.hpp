@@ -104,6 +104,9 @@ struct SeqArgs {
     const double *dstate;    // [n_genes]  s[1] - s[0]: all the difference-form Viterbi needs (8 B/gene)
     const uint8_t *flags;    // [n_genes]  bit0: first gene of a contig, bit1: last gene
     const int32_t *cblk;     // [n_cblocks+1] short contigs only: first gene of every workgroup of WHOLE contigs (<= kSeqBlockGenes genes)
+    const int32_t *cblk_rank;   // [n_cblocks] non-empty contigs before the workgroup's first
+    const int32_t *ne_contig;   // [non-empty contigs] their indices in contig_ptr
+    const int32_t *contig_ptr;  // [n_contigs+1] (device)
     int32_t n_cblocks;
     int32_t short_contigs;   // 1: no contig is longer than one scan block (kSeqBlockGenes)
     const double *smax;      // [n_genes] or null: max(s[0], s[1]) next to dstate (whole-contig marginals with log Z)

@@ -649,7 +649,26 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
         cblk.push_back(int32_t(n));
     }
     p.n_cblocks = cblk.empty() ? 0 : int32_t(cblk.size()) - 1;
-    const size_t o_flags = 0, o_blk = align256p(n + 8), bytes = o_blk + align256p((cblk.size() + 1) * 4);
+    // non-empty contigs: their indices, and how many of them precede every workgroup (log Z is written per contig)
+    std::vector<int32_t> ne, rank;
+    p.n_empty_contigs = 0;
+    if (p.n_cblocks) {
+        size_t b = 0;
+        rank.assign(size_t(p.n_cblocks), 0);
+        for (int32_t c = 0; c < p.n_contigs; ++c) {
+            if (p.contig_ptr[c + 1] == p.contig_ptr[c]) {
+                ++p.n_empty_contigs;
+                continue;
+            }
+            while (b < size_t(p.n_cblocks) && cblk[b] <= p.contig_ptr[c]) {  // workgroups starting at or before this contig
+                if (cblk[b] == p.contig_ptr[c]) rank[b] = int32_t(ne.size());
+                ++b;
+            }
+            ne.push_back(c);
+        }
+    }
+    const size_t o_flags = 0, o_blk = align256p(n + 8), o_rank = o_blk + align256p((cblk.size() + 1) * 4),
+                 o_ne = o_rank + align256p((rank.size() + 1) * 4), bytes = o_ne + align256p((ne.size() + 1) * 4);
     if ((rc = p.seq.reserve(bytes, "contig flags"))) return rc;
     uint8_t *flags = reinterpret_cast<uint8_t *>(p.seq.h + o_flags);
     std::memset(flags, 0, n + 8);
@@ -661,8 +680,12 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
         }
     }
     if (!cblk.empty()) std::memcpy(p.seq.h + o_blk, cblk.data(), cblk.size() * 4);
+    if (!rank.empty()) std::memcpy(p.seq.h + o_rank, rank.data(), rank.size() * 4);
+    if (!ne.empty()) std::memcpy(p.seq.h + o_ne, ne.data(), ne.size() * 4);
     p.d_seq_flags = reinterpret_cast<uint8_t *>(p.seq.d + o_flags);
     p.d_seq_cblk = reinterpret_cast<int32_t *>(p.seq.d + o_blk);
+    p.d_seq_cblk_rank = reinterpret_cast<int32_t *>(p.seq.d + o_rank);
+    p.d_seq_ne_contig = reinterpret_cast<int32_t *>(p.seq.d + o_ne);
     // launches that read the tables must be ordered behind this copy: `sync` (any stream may follow), or the
     // caller keeps to `stream` (the batch driver)
     if ((rc = check_hip(hipMemcpyAsync(p.seq.d, p.seq.h, bytes, hipMemcpyHostToDevice, stream), "upload contig flags"))) return rc;
@@ -708,6 +731,9 @@ int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
     a.flags = p.d_seq_flags;
     a.cblk = p.d_seq_cblk;
     a.n_cblocks = p.n_cblocks;
+    a.cblk_rank = p.d_seq_cblk_rank;
+    a.ne_contig = p.d_seq_ne_contig;
+    a.contig_ptr = p.d_contig_ptr;
     a.short_contigs = p.seq_short ? 1 : 0;
     a.n_contigs = p.n_contigs;
     a.n_genes = p.n_genes;
@@ -764,6 +790,10 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
     a.lognorm = d_lognorm;
     if (p.seq_short) {  // whole contigs per workgroup: 8-byte inputs, one fused kernel (alpha is parked in the state area)
         a.smax = reinterpret_cast<const double *>(a.alpha);
+        // log Z is written by the kernel at every contig's last gene; contigs without genes get their 0 here
+        if (d_lognorm && p.n_empty_contigs &&
+            (rc = check_hip(hipMemsetAsync(d_lognorm, 0, size_t(p.n_contigs) * 8, stream), "memset lognorm")))
+            return rc;
         return check_hip(launch_seq_marginals_short(a, d_gene_ptr, d_attr_id, p.tables_model->wtab2[1], p.model->A, p.d_contig_ptr,
                                                     stream), "marginals launch");
     }

@@ -66,6 +66,8 @@ struct Plan {
     uint8_t *d_seq_flags = nullptr;
     int32_t *d_seq_cblk = nullptr;    // short contigs: first gene of every workgroup of whole contigs (<= 2048 genes), [n_cblocks+1]
     int32_t n_cblocks = 0;
+    int32_t *d_seq_cblk_rank = nullptr, *d_seq_ne_contig = nullptr;  // non-empty contigs before every workgroup; their indices
+    int32_t n_empty_contigs = 0;
     bool seq_short = false;           // no contig longer than one scan block: whole contigs per workgroup, one launch per decoder
     // workspaces, allocated on first use, grow-only
     char *d_seq_ws = nullptr, *d_gen_ws = nullptr, *d_seg_ws = nullptr;

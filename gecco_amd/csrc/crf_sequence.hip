@@ -184,52 +184,80 @@ __device__ __forceinline__ FE lookahead_suffix(const FE *__restrict__ totals, in
 }
 
 // ---------------------------------------------------------------- row S: state scores
-__global__ void __launch_bounds__(kT) seq_state_scores(const int32_t *__restrict__ gene_ptr,
-                                                       const int32_t *__restrict__ attr_id,
-                                                       const double2 *__restrict__ wtab01, int n_attrs, int n_genes,
-                                                       double2 *__restrict__ state) {
-    const int g = blockIdx.x * kT + threadIdx.x;
-    if (g >= n_genes) return;
-    const int lo = gene_ptr[g], hi = gene_ptr[g + 1];
-    double s0 = 0.0, s1 = 0.0;
-    for (int base = lo; base < hi; base += 4) {
-        int a[4];
+// s[y] = sum over the gene's attributes of w[a][y], added in CSR order ([EXT] crf1dt_state_score).  A workgroup
+// takes 512 consecutive genes: their attribute ids are ONE contiguous stretch of the CSR, which is loaded
+// attribute-per-lane (coalesced; every id gathers its 16-byte weight pair once), parked in LDS 1024 pairs at a
+// time, and every gene then adds up its own run from there.  (One lane per gene walking its run through global
+// memory -- the first version -- is a chain of three dependent round trips per gene: 18 us for the 2 M genes of
+// C3; this arrangement is the windowed kernel's stage 1 and takes about half.)
+// MODE 0: d = s[1] - s[0];  1: d and max(s[0], s[1]);  2: the pair (s[0], s[1]).
+constexpr int kStateGenes = 512, kStatePark = 1024;
+template <int MODE>
+__global__ void __launch_bounds__(kT) seq_state_blocks(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
+                                                        const double2 *__restrict__ wtab01, int n_attrs, int n_genes,
+                                                        double *__restrict__ out_d, double *__restrict__ out_m,
+                                                        double2 *__restrict__ out_s) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    __shared__ f64x2 park[kStatePark];
+    constexpr int GPLS = kStateGenes / kT;  // genes per lane, strided by the workgroup size (coalesced row pointers and outputs)
+    constexpr int APL = kStatePark / kT;
+    const int tid = threadIdx.x;
+    const int g_first = blockIdx.x * kStateGenes, g_end = min(g_first + kStateGenes, n_genes);
+    const uint32_t lo_tile = uint32_t(gene_ptr[g_first]), hi_tile = uint32_t(gene_ptr[g_end]);
+    const uint32_t n_run = hi_tile - lo_tile;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(attr_id + lo_tile), 0, n_run << 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(wtab01), 0, uint32_t(n_attrs) << 4, 0x00020000);
+    uint32_t lo[GPLS], hi[GPLS];
+    double s0[GPLS], s1[GPLS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = base + u < hi ? attr_id[base + u] : -1;
-        double2 w[4];
+    for (int k = 0; k < GPLS; ++k) {
+        const int g = g_first + k * kT + tid;
+        lo[k] = hi[k] = 0;
+        if (g < g_end) {
+            lo[k] = uint32_t(gene_ptr[g]);
+            hi[k] = uint32_t(gene_ptr[g + 1]);
+        }
+        s0[k] = s1[k] = 0.0;
+    }
+#pragma unroll 1
+    for (uint32_t base = 0; base < n_run; base += kStatePark) {
+        int id[APL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = unsigned(a[u]) < unsigned(n_attrs) ? wtab01[a[u]] : make_double2(0.0, 0.0);  // unknown ids: no weight
+        for (int a = 0; a < APL; ++a) id[a] = __builtin_amdgcn_raw_buffer_load_b32(ra, int((base + a * kT + tid) << 2), 0, 0);
+        i32x4 w[APL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            s0 += w[u].x;
-            s1 += w[u].y;
+        for (int a = 0; a < APL; ++a)  // ids outside the dictionary land outside the table and read (+0.0, +0.0)
+            w[a] = __builtin_amdgcn_raw_buffer_load_b128(rw, int(min(uint32_t(id[a]), 0x0FFFFFFFu) << 4), 0, 0);
+#pragma unroll
+        for (int a = 0; a < APL; ++a) park[a * kT + tid] = f64x2{__hiloint2double(w[a].y, w[a].x), __hiloint2double(w[a].w, w[a].z)};
+        __syncthreads();
+        const uint32_t c0 = lo_tile + base, c1 = c0 + kStatePark;
+#pragma unroll
+        for (int k = 0; k < GPLS; ++k) {
+            uint32_t q = max(lo[k], c0) - c0;
+            const uint32_t e = min(hi[k], c1) - c0;
+            for (; q < e && hi[k] > c0; ++q) {
+                const f64x2 v = park[q];
+                s0[k] += v.x;
+                s1[k] += v.y;
+            }
+        }
+        if (base + kStatePark < n_run) __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < GPLS; ++k) {
+        const int g = g_first + k * kT + tid;
+        if (g < g_end) {
+            if (MODE == 2) {
+                out_s[g] = make_double2(s0[k], s1[k]);
+            } else {
+                out_d[g] = s1[k] - s0[k];
+                if (MODE == 1) out_m[g] = fmax(s0[k], s1[k]);
+            }
         }
     }
-    state[g] = make_double2(s0, s1);
-}
-
-__global__ void __launch_bounds__(kT) seq_state_delta(const int32_t *__restrict__ gene_ptr,
-                                                       const int32_t *__restrict__ attr_id,
-                                                       const double2 *__restrict__ wtab01, int n_attrs, int n_genes,
-                                                       double *__restrict__ dstate) {
-    const int g = blockIdx.x * kT + threadIdx.x;
-    if (g >= n_genes) return;
-    const int lo = gene_ptr[g], hi = gene_ptr[g + 1];
-    double s0 = 0.0, s1 = 0.0;
-    for (int base = lo; base < hi; base += 4) {
-        int a[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = base + u < hi ? attr_id[base + u] : -1;
-        double2 w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = unsigned(a[u]) < unsigned(n_attrs) ? wtab01[a[u]] : make_double2(0.0, 0.0);  // unknown ids: no weight
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            s0 += w[u].x;
-            s1 += w[u].y;
-        }
-    }
-    dstate[g] = s1 - s0;
 }
 
 // ---------------------------------------------------------------- lane-local loads
@@ -851,8 +879,7 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     __shared__ FE xch[kT];
     __shared__ struct {
         double2 st[kT * (kGPL + 1)];  // d (and maxima) in, marginals out
-        uint8_t fl[kT * kGPL];
-    } stg;
+    } stg;  // 36 KB + 14 KB of exchange: three workgroups per CU (the contig flags are read by their owner lanes directly)
     const int slot = threadIdx.x;
     const int g0 = A.cblk[blockIdx.x], n = A.cblk[blockIdx.x + 1] - g0;
     const bool want_z = A.lognorm != nullptr;
@@ -862,11 +889,13 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
         const bool ok = idx < n;
         stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] =
             make_double2(ok ? A.dstate[g0 + idx] : 0.0, (ok && want_z) ? A.smax[g0 + idx] : 0.0);
-        stg.fl[idx] = ok ? A.flags[g0 + idx] : uint8_t(0);
     }
-    __syncthreads();
     const int cnt = min(kGPL, n - slot * kGPL);
-    const uint64_t wf = *reinterpret_cast<const uint64_t *>(stg.fl + slot * kGPL);
+    uint64_t wf = 0;
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k)
+        if (k < cnt) wf |= uint64_t(A.flags[g0 + slot * kGPL + k]) << (8 * k);
+    __syncthreads();
     // the emission pair of every gene the lane touches (its own 8 and its right neighbour's first): ONE exp per gene,
     // used by the forward fold, the forward replay, the backward fold and the backward replay
     double2 E[kGPL + 1];
@@ -889,6 +918,13 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     }
     FE total;
     const FE M = block_scan_exclusive<FOp, false>(P, lds, &total);
+    // contig ends before this lane (workgroup-wide count): which contig a log Z belongs to
+    uint32_t ends_before = 0;
+    if (want_z) {
+        __shared__ U2 ldsc[kT / 64];
+        U2 ctot;
+        ends_before = block_scan_exclusive<AddOp, false>(U2{uint32_t(__builtin_popcount(last & ((1u << (cnt > 0 ? cnt : 0)) - 1u))), 0u}, ldsc, &ctot).x;
+    }
     // forward replay: alpha of every gene of the lane (registers), log Z at contig ends; backward matrices folded
     double a0 = M.a00, a1 = M.a01, ex = M.ex, ms = M.ms;
     FE Bfold = FOp::identity();
@@ -916,7 +952,12 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
             ms += mx[k];
             al[k] = make_double2(a0, a1);
             const bool lst = (last >> k) & 1u;
-            if (lst && want_z) A.contigTmp[g0 + slot * kGPL + k] = make_double2(ex * 0.6931471805599453 + log(a0 + a1), ms);
+            if (lst && want_z) {
+                // log Z = log Z' (max-normalised emissions and transitions) + the emission maxima + (n - 1) max(trans)
+                const int c = A.ne_contig[A.cblk_rank[blockIdx.x] + int(ends_before) + __builtin_popcount(last & ((1u << k) - 1u))];
+                const int len = A.contig_ptr[c + 1] - A.contig_ptr[c];
+                A.lognorm[c] = (ex * 0.6931471805599453 + log(a0 + a1)) + ms + double(len - 1) * A.mx;
+            }
             const FE B = lst ? FE{1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0} : f_step_e(A, E[k + 1], 0.0, false);
             Bfold = FOpB::combine(Bfold, B);
         }
@@ -963,31 +1004,6 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     }
 }
 
-// d = s[1] - s[0] per gene (and, optionally, max(s[0], s[1])): all the short-contig kernels need of the state scores
-__global__ void __launch_bounds__(kT) seq_state_dm(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
-                                                    const double2 *__restrict__ wtab01, int n_attrs, int n_genes,
-                                                    double *__restrict__ dstate, double *__restrict__ smax) {
-    const int g = blockIdx.x * kT + threadIdx.x;
-    if (g >= n_genes) return;
-    const int lo = gene_ptr[g], hi = gene_ptr[g + 1];
-    double s0 = 0.0, s1 = 0.0;
-    for (int base = lo; base < hi; base += 4) {
-        int a[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = base + u < hi ? attr_id[base + u] : -1;
-        double2 w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = unsigned(a[u]) < unsigned(n_attrs) ? wtab01[a[u]] : make_double2(0.0, 0.0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            s0 += w[u].x;
-            s1 += w[u].y;
-        }
-    }
-    dstate[g] = s1 - s0;
-    if (smax) smax[g] = fmax(s0, s1);
-}
-
 // log Z of contig c = log Z' + its emission maxima + (n-1) max(trans)
 __global__ void __launch_bounds__(kT) f_lognorm(const SeqArgs A, const int32_t *__restrict__ contig_ptr) {
     const int c = blockIdx.x * kT + threadIdx.x;
@@ -1009,7 +1025,8 @@ static inline dim3 grid_for(int n, int per) { return dim3((n + per - 1) / per); 
 hipError_t launch_seq_state(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_attrs, int n_genes,
                             double2 *state, hipStream_t stream) {
     if (n_genes <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seq_state_scores, grid_for(n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_attrs, n_genes, state);
+    hipLaunchKernelGGL(seq_state_blocks<2>, grid_for(n_genes, kStateGenes), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_attrs,
+                       n_genes, (double *)nullptr, (double *)nullptr, state);
     return hipGetLastError();
 }
 
@@ -1041,7 +1058,8 @@ hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream) {
 hipError_t launch_seq_state_delta(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_attrs, int n_genes,
                                   double *dstate, hipStream_t stream) {
     if (n_genes <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seq_state_delta, grid_for(n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_attrs, n_genes, dstate);
+    hipLaunchKernelGGL(seq_state_blocks<0>, grid_for(n_genes, kStateGenes), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_attrs,
+                       n_genes, dstate, (double *)nullptr, (double2 *)nullptr);
     return hipGetLastError();
 }
 
@@ -1051,11 +1069,14 @@ hipError_t launch_seq_marginals_short(const SeqArgs &a, const int32_t *gene_ptr,
                                       int n_attrs, const int32_t *d_contig_ptr, hipStream_t stream) {
     if (a.n_contigs <= 0) return hipSuccess;
     if (a.n_genes > 0) {
-        hipLaunchKernelGGL(seq_state_dm, grid_for(a.n_genes, kT), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01, n_attrs, a.n_genes,
-                           const_cast<double *>(a.dstate), a.lognorm ? const_cast<double *>(a.smax) : nullptr);
-        hipLaunchKernelGGL(f_short, dim3(a.n_cblocks), dim3(kT), 0, stream, a);
+        if (a.lognorm)
+            hipLaunchKernelGGL(seq_state_blocks<1>, grid_for(a.n_genes, kStateGenes), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01,
+                               n_attrs, a.n_genes, const_cast<double *>(a.dstate), const_cast<double *>(a.smax), (double2 *)nullptr);
+        else
+            hipLaunchKernelGGL(seq_state_blocks<0>, grid_for(a.n_genes, kStateGenes), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01,
+                               n_attrs, a.n_genes, const_cast<double *>(a.dstate), (double *)nullptr, (double2 *)nullptr);
+        hipLaunchKernelGGL(f_short, dim3(a.n_cblocks), dim3(kT), 0, stream, a);  // writes log Z itself
     }
-    if (a.lognorm) hipLaunchKernelGGL(f_lognorm, grid_for(a.n_contigs, kT), dim3(kT), 0, stream, a, d_contig_ptr);
     return hipGetLastError();
 }
 
