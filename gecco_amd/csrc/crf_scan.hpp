@@ -46,6 +46,14 @@ __device__ __forceinline__ SegE dpp_elem(const SegE &old, const SegE &s) {
     auto mv = [](uint32_t o, uint32_t v) { return uint32_t(__builtin_amdgcn_update_dpp(int(o), int(v), CTRL, RM, 0xF, false)); };
     return SegE{mv(old.map, s.map), mv(old.ng0, s.ng0), mv(old.ng1, s.ng1), mv(old.ann, s.ann)};
 }
+struct F4 {  // sum-product 2x2 scan element without bookkeeping (marginals only: every scale factor cancels)
+    double a00, a01, a10, a11;
+};
+template <int CTRL, int RM>
+__device__ __forceinline__ F4 dpp_elem(const F4 &old, const F4 &s) {
+    return F4{dpp_f64<CTRL, RM>(old.a00, s.a00), dpp_f64<CTRL, RM>(old.a01, s.a01), dpp_f64<CTRL, RM>(old.a10, s.a10),
+              dpp_f64<CTRL, RM>(old.a11, s.a11)};
+}
 struct U2 {  // pair of counters (plain sums)
     uint32_t x, y;
 };

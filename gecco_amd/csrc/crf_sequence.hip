@@ -20,6 +20,8 @@
 // lane, using CRFsuite's operation order inside the lane.  Values entering a lane come from
 // composed elements, i.e. they equal the strictly sequential values whenever the additions are
 // exact (integer-valued weights: ties and first-argmax included) and to rounding otherwise.
+#include <type_traits>
+
 #include "crf_device.hpp"
 #include "crf_scan.hpp"
 
@@ -78,6 +80,28 @@ struct FOpB {
         return c;
     }
 };
+// Flag-free products for workgroups that own WHOLE contigs and only want marginals (f_short): a contig's first
+// gene contributes the rank-one matrix 1 e^T, so whatever stands before it only scales the product's rows, and
+// its last gene contributes 1 1^T, so whatever follows only scales the columns -- directions are all a marginal
+// needs.  No `rs` test (7 selects per combine), no exponent / maxima sums, 4 doubles through the DPP network.
+struct F4Op {
+    static __device__ __forceinline__ F4 identity() { return F4{1.0, 0.0, 0.0, 1.0}; }
+    static __device__ __forceinline__ F4 combine(const F4 &a, const F4 &b) {  // a earlier
+        F4 c;
+        c.a00 = fma(a.a01, b.a10, a.a00 * b.a00);
+        c.a01 = fma(a.a01, b.a11, a.a00 * b.a01);
+        c.a10 = fma(a.a11, b.a10, a.a10 * b.a00);
+        c.a11 = fma(a.a11, b.a11, a.a10 * b.a01);
+        int e;
+        (void)frexp(fmax(fmax(c.a00, c.a01), fmax(c.a10, c.a11)), &e);
+        c.a00 = ldexp(c.a00, -e);
+        c.a01 = ldexp(c.a01, -e);
+        c.a10 = ldexp(c.a10, -e);
+        c.a11 = ldexp(c.a11, -e);
+        return c;
+    }
+};
+
 // Difference form of the 2-label Viterbi recursion.  With Delta = delta[1] - delta[0] and d = s[1] - s[0],
 //   Delta_t = clamp(Delta_{t-1}, lo, hi) + (t11 - t00) + d_t,   lo = t01 - t11,  hi = t00 - t10  (lo <= hi),
 // the back-pointers of gene t are (Delta_{t-1} > hi, Delta_{t-1} > lo) and the end label is Delta_T > 0
@@ -874,15 +898,20 @@ __device__ __forceinline__ FE f_step_e(const SeqArgs &A, double2 e, double m, bo
               (first ? 1.0 : A.m11) * e.y, 0.0, m, first ? 1.0 : 0.0};
 }
 
+template <bool WANT_Z>
 __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
-    __shared__ FE lds[kT / 64];
-    __shared__ FE xch[kT];
+    // with log Z: elements carry exponents, emission maxima and the contig-start flag; without: bare 2x2 products
+    using E_t = typename std::conditional<WANT_Z, FE, F4>::type;
+    using OpF = typename std::conditional<WANT_Z, FOp, F4Op>::type;
+    using OpB = typename std::conditional<WANT_Z, FOpB, F4Op>::type;
+    __shared__ E_t lds[kT / 64];
+    __shared__ E_t xch[kT];
     __shared__ struct {
         double2 st[kT * (kGPL + 1)];  // d (and maxima) in, marginals out
     } stg;  // 36 KB + 14 KB of exchange: three workgroups per CU (the contig flags are read by their owner lanes directly)
     const int slot = threadIdx.x;
     const int g0 = A.cblk[blockIdx.x], n = A.cblk[blockIdx.x + 1] - g0;
-    const bool want_z = A.lognorm != nullptr;
+    constexpr bool want_z = WANT_Z;
 #pragma unroll
     for (int j = 0; j < kGPL; ++j) {
         const int idx = j * kT + slot;
@@ -908,16 +937,23 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     }
     E[kGPL] = emit_d(A, slot + 1 < kT ? stg.st[(slot + 1) * (kGPL + 1)].x : 0.0);
     uint32_t first = 0, last = 0;
-    FE P = FOp::identity();
+    auto step = [&](double2 e, double m, bool fst) {
+        if constexpr (WANT_Z) {
+            return f_step_e(A, e, m, fst);
+        } else {
+            return F4{(fst ? 1.0 : A.m00) * e.x, (fst ? 1.0 : A.m01) * e.y, (fst ? 1.0 : A.m10) * e.x, (fst ? 1.0 : A.m11) * e.y};
+        }
+    };
+    E_t P = OpF::identity();
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
         const uint32_t f = uint32_t(wf >> (8 * k)) & 0xffu;
         first |= (f & 1u) << k;
         last |= ((f >> 1) & 1u) << k;
-        if (k < cnt) P = FOp::combine(P, f_step_e(A, E[k], mx[k], f & 1u));
+        if (k < cnt) P = OpF::combine(P, step(E[k], mx[k], f & 1u));
     }
-    FE total;
-    const FE M = block_scan_exclusive<FOp, false>(P, lds, &total);
+    E_t total;
+    const E_t M = block_scan_exclusive<OpF, false>(P, lds, &total);
     // contig ends before this lane (workgroup-wide count): which contig a log Z belongs to
     uint32_t ends_before = 0;
     if (want_z) {
@@ -926,8 +962,12 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
         ends_before = block_scan_exclusive<AddOp, false>(U2{uint32_t(__builtin_popcount(last & ((1u << (cnt > 0 ? cnt : 0)) - 1u))), 0u}, ldsc, &ctot).x;
     }
     // forward replay: alpha of every gene of the lane (registers), log Z at contig ends; backward matrices folded
-    double a0 = M.a00, a1 = M.a01, ex = M.ex, ms = M.ms;
-    FE Bfold = FOp::identity();
+    double a0 = M.a00, a1 = M.a01, ex = 0.0, ms = 0.0;
+    if constexpr (WANT_Z) {
+        ex = M.ex;
+        ms = M.ms;
+    }
+    E_t Bfold = OpB::identity();
     double2 al[kGPL];
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
@@ -958,20 +998,26 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
                 const int len = A.contig_ptr[c + 1] - A.contig_ptr[c];
                 A.lognorm[c] = (ex * 0.6931471805599453 + log(a0 + a1)) + ms + double(len - 1) * A.mx;
             }
-            const FE B = lst ? FE{1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0} : f_step_e(A, E[k + 1], 0.0, false);
-            Bfold = FOpB::combine(Bfold, B);
+            E_t B;
+            if constexpr (WANT_Z) {
+                B = lst ? FE{1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0} : f_step_e(A, E[k + 1], 0.0, false);
+            } else {
+                const F4 nx = step(E[k + 1], 0.0, false);
+                B = lst ? F4{1.0, 1.0, 1.0, 1.0} : nx;
+            }
+            Bfold = OpB::combine(Bfold, B);
         }
     }
     __syncthreads();  // every lane has read its neighbour's d: the stage may be overwritten below
     xch[kT - 1 - slot] = Bfold;
     __syncthreads();
-    const FE mine = xch[slot];
-    FE btotal;
-    const FE bexcl = block_scan_exclusive<FOpB, true>(mine, lds, &btotal);
+    const E_t mine = xch[slot];
+    E_t btotal;
+    const E_t bexcl = block_scan_exclusive<OpB, true>(mine, lds, &btotal);
     __syncthreads();
     xch[kT - 1 - slot] = bexcl;
     __syncthreads();
-    const FE S = xch[slot];  // product of the backward matrices of the lanes to the right (up to the contig's end)
+    const E_t S = xch[slot];  // product of the backward matrices of the lanes to the right (up to the contig's end)
     double b0 = S.a00 + S.a01, b1 = S.a10 + S.a11;
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) {
@@ -1075,7 +1121,10 @@ hipError_t launch_seq_marginals_short(const SeqArgs &a, const int32_t *gene_ptr,
         else
             hipLaunchKernelGGL(seq_state_blocks<0>, grid_for(a.n_genes, kStateGenes), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01,
                                n_attrs, a.n_genes, const_cast<double *>(a.dstate), (double *)nullptr, (double2 *)nullptr);
-        hipLaunchKernelGGL(f_short, dim3(a.n_cblocks), dim3(kT), 0, stream, a);  // writes log Z itself
+        if (a.lognorm)
+            hipLaunchKernelGGL(f_short<true>, dim3(a.n_cblocks), dim3(kT), 0, stream, a);  // writes log Z itself
+        else
+            hipLaunchKernelGGL(f_short<false>, dim3(a.n_cblocks), dim3(kT), 0, stream, a);
     }
     return hipGetLastError();
 }

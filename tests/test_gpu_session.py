@@ -4,6 +4,10 @@ batch goes through many chunks and every lane of the ring is reused."""
 import numpy as np
 import pytest
 
+# PyTorch ships its own copy of the HIP runtime: it has to be the one this process loads first (importing torch
+# after libgecco_crf.so has pulled in the system copy leaves torch without a device) -- INTEGRATION.md, section 3
+import torch  # noqa: F401  (used by the device-array test below)
+
 from tests.helpers import synth_contigs
 
 pytestmark = pytest.mark.gpu
@@ -147,8 +151,6 @@ def test_session_clusters_resident(nat, real_model, oracle_model, chunk, pad, n_
 
 def test_plan_run_segment_on_device_arrays(nat, real_model, oracle_model):
     """gecco_crf_plan_run_segment chained behind gecco_crf_plan_run_windowed on one stream: p never leaves the device."""
-    import torch
-
     from oracle import crf_oracle as orc
 
     cptr, gptr, attr = _batch(oracle_model, 15)
