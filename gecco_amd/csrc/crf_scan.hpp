@@ -113,6 +113,31 @@ __device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /
     return comb<Op, REV>(pre, excl);
 }
 
+// Workgroup-wide exclusive scan from the BACK for 32-bit elements: lane l receives e[l+1] (x) e[l+2] (x) ... (x) e[NTH-1]
+// with the element closest to the end acting first (Op::combine(a, b) applies b first); *total = e[0] (x) ... (x) e[NTH-1].
+// Every wave mirrors its lanes through the LDS crossbar (ds_bpermute: no memory, no barrier), scans forward and mirrors
+// back; the waves' totals meet in LDS in reverse order -- one barrier instead of the four of a mirrored exchange
+// through LDS around a forward scan.  `lds_totals` must not be reused before the next barrier of the caller.
+template <class Op, int NTH = kScanThreads>
+__device__ __forceinline__ uint32_t block_scan_exclusive_back(uint32_t mine, uint32_t *lds_totals /* NTH/64 */, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t id = Op::identity();
+    const int mirror = (63 - lane) << 2;
+    const uint32_t m = uint32_t(__builtin_amdgcn_ds_bpermute(mirror, int(mine)));
+    const uint32_t incl = wave_scan_inclusive<Op, true>(m);
+    if (lane == 63) lds_totals[wave] = incl;
+    const uint32_t excl = wave_shift_up(id, incl);
+    __syncthreads();
+    uint32_t pre = id, all = id;
+#pragma unroll
+    for (int w = NTH / 64 - 1; w >= 0; --w) {
+        const uint32_t t = lds_totals[w];
+        if (w > wave) pre = comb<Op, true>(pre, t);
+        all = comb<Op, true>(all, t);
+    }
+    *total = all;
+    return uint32_t(__builtin_amdgcn_ds_bpermute(mirror, int(comb<Op, true>(pre, excl))));
+}
 
 }  // namespace
 }  // namespace gecco

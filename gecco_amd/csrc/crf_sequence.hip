@@ -432,17 +432,9 @@ __global__ void __launch_bounds__(kT) v_replay(const SeqArgs A) {
     for (int k = kGPL - 1; k >= 0; --k)
         if (k < L.cnt) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
     A.vMaps[blockIdx.x * kT + slot] = maps;
-    // back-to-front scan: scan position p = kT-1-slot, so hand the element to the mirrored lane
-    __shared__ uint32_t xch[kT];
-    xch[kT - 1 - slot] = lane_map;
-    __syncthreads();
-    const uint32_t mine = xch[slot];
+    // back-to-front scan of the lane maps
     uint32_t total;
-    const uint32_t excl = block_scan_exclusive<MapOp, true>(mine, lds, &total);
-    __syncthreads();
-    xch[kT - 1 - slot] = excl;  // back to natural lane order
-    __syncthreads();
-    A.vLaneMap[blockIdx.x * kT + slot] = xch[slot];
+    A.vLaneMap[blockIdx.x * kT + slot] = block_scan_exclusive_back<MapOp>(lane_map, lds, &total);
     if (slot == 0) A.vBlockMap[blockIdx.x] = total;
 }
 
@@ -562,16 +554,8 @@ __global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
     for (int k = kGPL - 1; k >= 0; --k)
         if (k < L.cnt) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
     A.vMaps[blockIdx.x * kT + slot] = maps;
-    __shared__ uint32_t xch[kT];
-    xch[kT - 1 - slot] = lane_map;
-    __syncthreads();
-    const uint32_t mine = xch[slot];
     uint32_t total;
-    const uint32_t excl = block_scan_exclusive<MapOp, true>(mine, lds, &total);
-    __syncthreads();
-    xch[kT - 1 - slot] = excl;
-    __syncthreads();
-    A.vLaneMap[blockIdx.x * kT + slot] = xch[slot];
+    A.vLaneMap[blockIdx.x * kT + slot] = block_scan_exclusive_back<MapOp>(lane_map, lds, &total);
     if (slot == 0) A.vBlockMap[blockIdx.x] = total;
 }
 
@@ -605,7 +589,6 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
     __shared__ CE lds[kT / 64];
     __shared__ uint32_t ldsm[kT / 64];
     __shared__ ShortStage stg;
-    __shared__ uint32_t xch[kT];
     const int slot = threadIdx.x;
     const int g0 = A.cblk[blockIdx.x], n = A.cblk[blockIdx.x + 1] - g0;
     load_short(A.dstate, A.flags, g0, n, stg);
@@ -708,17 +691,10 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k)
         if (k < cnt) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
-    // back-to-front scan of the lane maps (mirrored lanes), then the labels: the workgroup ends at a contig end,
+    // back-to-front scan of the lane maps, then the labels: the workgroup ends at a contig end,
     // so the map entering from its right is irrelevant (the last gene's map is constant)
-    xch[kT - 1 - slot] = lane_map;
-    __syncthreads();
-    const uint32_t mine = xch[slot];
     uint32_t mtotal;
-    const uint32_t mexcl = block_scan_exclusive<MapOp, true>(mine, ldsm, &mtotal);
-    __syncthreads();
-    xch[kT - 1 - slot] = mexcl;
-    __syncthreads();
-    uint32_t lab = xch[slot] & 1u;
+    uint32_t lab = block_scan_exclusive_back<MapOp>(lane_map, ldsm, &mtotal) & 1u;
     uint64_t packed = 0;
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) {
