@@ -52,6 +52,9 @@ SIGNATURES = {
         [ctypes.c_int32, _c_f64p, _c_u8p, _c_i32p, ctypes.c_int32, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
          ctypes.c_int32, ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p],
     ),
+    "gecco_crf_segment_ex": (
+        ctypes.c_int, [ctypes.c_int32, _c_f64p, _c_u8p, _c_i32p, ctypes.c_int32, _vp, _c_i32p, ctypes.c_int32, _c_i32p]
+    ),
     "gecco_crf_domain_composition": (
         ctypes.c_int,
         [ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p, ctypes.c_int32, _c_i32p, _c_f64p, ctypes.c_int32, ctypes.c_int32, _c_f64p],
@@ -72,6 +75,7 @@ SIGNATURES = {
         ctypes.c_int,
         [_vp, _vp, _vp, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, _vp, _vp],
     ),
+    "gecco_crf_plan_run_segment_ex": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     "gecco_crf_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "gecco_crf_host_free": (None, [_vp]),
     "gecco_crf_session_create": (ctypes.c_int, [_vp, _c_i32p, ctypes.c_int32, ctypes.POINTER(_vp)]),
@@ -96,6 +100,11 @@ SIGNATURES = {
          ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p, _c_i32p, ctypes.c_int32, _c_i32p, _c_f64p,
          ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)],
     ),
+    "gecco_crf_session_clusters_ex": (
+        ctypes.c_int,
+        [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, _c_u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+         _vp, _c_f64p, _c_i32p, ctypes.c_int32, _c_i32p, _c_f64p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)],
+    ),
     "gecco_crf_pack_columns": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp)]),
     "gecco_crf_packed_free": (None, [_vp]),
     "gecco_crf_packed_info": (
@@ -110,6 +119,8 @@ SIGNATURES = {
     "gecco_crf_packed_row_gene": (_vp, [_vp]),
     "gecco_crf_packed_row_order": (_vp, [_vp]),
     "gecco_crf_packed_row_ptr": (_vp, [_vp]),
+    "gecco_crf_packed_marker_ptr": (_vp, [_vp]),
+    "gecco_crf_packed_marker_id": (_vp, [_vp]),
     "gecco_crf_cluster_rows_build": (ctypes.c_int, [_vp, _vp, _vp, _vp, _c_i32p, ctypes.c_int32, _c_f64p, _vp, ctypes.POINTER(_vp)]),
     "gecco_crf_cluster_rows_free": (None, [_vp]),
     "gecco_crf_cluster_rows_start": (_vp, [_vp]),
@@ -326,11 +337,45 @@ def domain_composition(seg, dom_ptr, dom_col, dom_weight, n_cols, normalize=True
     return out
 
 
+class RefineParams(ctypes.Structure):
+    """``gecco_crf_refine_params``: ClusterRefiner's parameters (gecco/refine.py:75-116)."""
+    _fields_ = [("threshold", ctypes.c_double), ("average_threshold", ctypes.c_double), ("criterion", ctypes.c_int32),
+                ("n_cds", ctypes.c_int32), ("n_biopfams", ctypes.c_int32), ("edge_distance", ctypes.c_int32),
+                ("trim", ctypes.c_int32), ("carry_state", ctypes.c_int32), ("marker_ptr", _vp), ("marker_id", _vp)]
+
+
+CRITERIA = {"gecco": 0, "antismash": 1}
+
+
+def refine_params(criterion="gecco", threshold=0.8, n_cds=5, n_biopfams=5, average_threshold=0.6, edge_distance=0, trim=True,
+                  carry_state=False, marker_ptr=None, marker_id=None, keep=None) -> RefineParams:
+    """The C struct; `marker_ptr` / `marker_id` are host int32 arrays (parked in `keep`) or integer device addresses."""
+    if criterion not in CRITERIA:
+        raise ValueError(f"Unknown cluster filtering criterion: {criterion}")  # refine.py:165
+    q = RefineParams(float(threshold), float(average_threshold), CRITERIA[criterion], int(n_cds), int(n_biopfams),
+                     int(edge_distance), int(bool(trim)), int(bool(carry_state)), None, None)
+    for name, arr in (("marker_ptr", marker_ptr), ("marker_id", marker_id)):
+        if arr is None:
+            continue
+        if isinstance(arr, int):
+            setattr(q, name, arr or None)
+            continue
+        a = _i32(arr)
+        if a.size == 0:
+            a = np.zeros(1, dtype=np.int32)
+        if keep is not None:
+            keep.append(a)
+        setattr(q, name, a.ctypes.data)
+    return q
+
+
 def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, trim=True, device=0,
-            carry_state=False) -> np.ndarray:
+            carry_state=False, criterion="gecco", n_biopfams=5, average_threshold=0.6, marker_ptr=None,
+            marker_id=None) -> np.ndarray:
     """Cluster rows (contig, number, first gene, last gene + 1) of per-gene probabilities.  `carry_state`:
     False = one grouper per contig (the CLI's ``iter_clusters`` call per contig), True = one grouper
-    over all contigs (a single ``iter_clusters`` call)."""
+    over all contigs (a single ``iter_clusters`` call).  `criterion="antismash"` needs the genes' marker domains
+    (`marker_ptr[n_genes+1]`, `marker_id`: indices into the caller's marker list, refine.py:157-163)."""
     lib = load_library()
     p = np.ascontiguousarray(p, dtype=np.float64)
     annotated = np.ascontiguousarray(annotated, dtype=np.uint8)
@@ -338,13 +383,11 @@ def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, t
     cap = max(1, len(p))
     seg = np.zeros((cap, 4), dtype=np.int32)
     n_seg = ctypes.c_int32(0)
-    _check(
-        lib.gecco_crf_segment(
-            device, _ptr(p, _c_f64p), _ptr(annotated, _c_u8p), _ptr(contig_ptr, _c_i32p), len(contig_ptr) - 1,
-            float(threshold), int(n_cds), int(edge_distance), int(bool(trim)), int(bool(carry_state)), _ptr(seg, _c_i32p), cap,
-            ctypes.byref(n_seg),
-        )
-    )
+    keep = []
+    q = refine_params(criterion, threshold, n_cds, n_biopfams, average_threshold, edge_distance, trim, carry_state, marker_ptr,
+                      marker_id, keep)
+    _check(lib.gecco_crf_segment_ex(device, _ptr(p, _c_f64p), _ptr(annotated, _c_u8p), _ptr(contig_ptr, _c_i32p),
+                                    len(contig_ptr) - 1, ctypes.byref(q), _ptr(seg, _c_i32p), cap, ctypes.byref(n_seg)))
     return seg[: n_seg.value].copy()
 
 
@@ -356,7 +399,7 @@ class _Strings(ctypes.Structure):
 class _TableColumns(ctypes.Structure):
     _fields_ = [("n_rows", ctypes.c_int64), ("sequence_id", _Strings), ("protein_id", _Strings), ("domain", _Strings),
                 ("start", _vp), ("domain_start", _vp), ("n_genes", ctypes.c_int64), ("gene_sequence_id", _Strings),
-                ("gene_protein_id", _Strings), ("gene_start", _vp)]
+                ("gene_protein_id", _Strings), ("gene_start", _vp), ("n_markers", ctypes.c_int64), ("markers", _Strings)]
 
 
 def _view(ptr, n, dtype, owner):
@@ -392,7 +435,7 @@ class PackedTables:
     The arrays are views of library-owned memory (pinned when a device is present)."""
 
     def __init__(self, model: "Model", f_sequence_id, f_protein_id, f_start, f_domain, f_domain_start,
-                 g_sequence_id=None, g_protein_id=None, g_start=None):
+                 g_sequence_id=None, g_protein_id=None, g_start=None, markers=None):
         self._lib = load_library()
         keep = []
         t = _TableColumns()
@@ -407,6 +450,9 @@ class PackedTables:
             t.gene_sequence_id = _strings_arg(g_sequence_id, keep)
             t.gene_protein_id = _strings_arg(g_protein_id, keep)
             t.gene_start = _i64_arg(g_start, keep)
+        t.n_markers = 0 if markers is None else len(markers)
+        if t.n_markers:
+            t.markers = _strings_arg(markers, keep)
         self._cols, self._keep = t, keep  # the cluster-row builder reads the same columns again
         h = _vp()
         _check(self._lib.gecco_crf_pack_columns(model._h, ctypes.byref(t), ctypes.byref(h)))
@@ -427,6 +473,12 @@ class PackedTables:
         self.row_gene = _view(L.gecco_crf_packed_row_gene(h), self.n_rows, np.int32, self)
         self.row_order = _view(L.gecco_crf_packed_row_order(h), self.n_rows, np.int64, self)
         self.row_ptr = _view(L.gecco_crf_packed_row_ptr(h), self.n_genes + 1, np.int64, self)
+        self.marker_ptr = self.marker_id = None  # per gene its marker domains (antismash criterion), when asked for
+        if t.n_markers:
+            self.marker_ptr = _view(L.gecco_crf_packed_marker_ptr(h), self.n_genes + 1, np.int32, self)
+            if self.n_genes == 0:
+                self.marker_ptr = np.zeros(1, dtype=np.int32)
+            self.marker_id = _view(L.gecco_crf_packed_marker_id(h), int(self.marker_ptr[-1]), np.int32, self)
         if self.n_contigs == 0:
             self.contig_ptr = np.zeros(1, dtype=np.int32)
         if self.n_genes == 0:
@@ -616,7 +668,8 @@ class Session:
         return p[:n], y[:n]
 
     def clusters(self, contig_ptr, gene_ptr, attr_id, annotated, window, step=1, label=1, pad=True, threshold=0.8, n_cds=3,
-                 edge_distance=0, trim=True, want_p=False, want_seg_p=True, p_out=None):
+                 edge_distance=0, trim=True, want_p=False, want_seg_p=True, p_out=None, criterion="gecco", n_biopfams=5,
+                 average_threshold=0.6, marker_ptr=None, marker_id=None):
         """Windowed marginals + cluster calls in one pass; the probabilities stay on the device unless
         `want_p` / `p_out`.  Returns (seg rows (k, 4), seg_p, seg_off, p or None): `seg_p[seg_off[i]:seg_off[i+1]]`
         are the probabilities of the genes of row i."""
@@ -631,9 +684,12 @@ class Session:
         seg_p = np.empty(max(n, 1), dtype=np.float64) if want_seg_p else None
         seg_off = np.zeros(cap + 1, dtype=np.int64)
         n_seg = ctypes.c_int32(0)
-        _check(self._lib.gecco_crf_session_clusters(
+        keep = []
+        q = refine_params(criterion, threshold, n_cds, n_biopfams, average_threshold, edge_distance, trim, False, marker_ptr,
+                          marker_id, keep)
+        _check(self._lib.gecco_crf_session_clusters_ex(
             self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p), _ptr(attr_id, _c_i32p), _ptr(annotated, _c_u8p),
-            int(window), int(step), int(label), int(bool(pad)), float(threshold), int(n_cds), int(edge_distance), int(bool(trim)),
+            int(window), int(step), int(label), int(bool(pad)), ctypes.byref(q),
             _ptr(p_out, _c_f64p) if p_out is not None else None, _ptr(seg, _c_i32p), cap, ctypes.byref(n_seg),
             _ptr(seg_p, _c_f64p) if want_seg_p else None, max(n, 1), seg_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
         k = n_seg.value
@@ -695,11 +751,14 @@ class Plan:
         _check(self._lib.gecco_crf_plan_run_viterbi(self._h, d_gene_ptr, d_attr_id, d_y, d_score or None, stream or None))
 
     def run_segment(self, d_p: int, d_annotated: int, d_seg: int, max_seg: int, d_n_seg: int, threshold=0.8, n_cds=3,
-                    edge_distance=0, trim=True, carry_state=False, stream: int = 0):
-        """Cluster rows of device-resident probabilities, on the same stream as the marginals (no copies)."""
-        _check(self._lib.gecco_crf_plan_run_segment(self._h, d_p, d_annotated, float(threshold), int(n_cds), int(edge_distance),
-                                                    int(bool(trim)), int(bool(carry_state)), d_seg, int(max_seg), d_n_seg,
-                                                    stream or None))
+                    edge_distance=0, trim=True, carry_state=False, stream: int = 0, criterion="gecco", n_biopfams=5,
+                    average_threshold=0.6, d_marker_ptr: int = 0, d_marker_id: int = 0):
+        """Cluster rows of device-resident probabilities, on the same stream as the marginals (no copies);
+        `d_marker_ptr` / `d_marker_id`: device addresses of the genes' marker domains (antismash criterion)."""
+        q = refine_params(criterion, threshold, n_cds, n_biopfams, average_threshold, edge_distance, trim, carry_state,
+                          int(d_marker_ptr), int(d_marker_id))
+        _check(self._lib.gecco_crf_plan_run_segment_ex(self._h, d_p, d_annotated, ctypes.byref(q), d_seg, int(max_seg), d_n_seg,
+                                                       stream or None))
 
     def time_windowed(self, d_gene_ptr: int, d_attr_id: int, d_p_out: int, label=1, stream: int = 0, warmup=2, iters=10) -> float:
         ms = ctypes.c_float(0)

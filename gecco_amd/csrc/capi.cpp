@@ -89,7 +89,7 @@ int check_device(int32_t device) {
 }  // namespace
 
 GECCO_API const char *gecco_crf_last_error(void) { return last_error(); }
-GECCO_API int gecco_crf_version(void) { return 200; }
+GECCO_API int gecco_crf_version(void) { return 210; }
 
 GECCO_API int gecco_crf_model_load(const uint8_t *lcrf, size_t n_bytes, gecco_crf_model **out) {
     if (!out) return GECCO_CRF_EINVAL;
@@ -356,13 +356,42 @@ GECCO_API int gecco_crf_session_decode(gecco_crf_session *s, const int32_t *cont
     r.y_out = y_out;
     return run_guarded(*s->s, r);
 }
-GECCO_API int gecco_crf_session_clusters(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
-                                         const int32_t *gene_ptr, const int32_t *attr_id, const uint8_t *annotated,
-                                         int32_t window, int32_t step, int32_t label, int32_t pad, double threshold,
-                                         int32_t n_cds, int32_t edge_distance, int32_t trim, double *p_out, int32_t *seg_out,
-                                         int32_t max_seg, int32_t *n_seg, double *seg_p_out, int64_t max_seg_genes,
-                                         int64_t *seg_off_out) {
-    if (!s) return GECCO_CRF_EINVAL;
+namespace {
+SegParams seg_params(const gecco_crf_refine_params &q) {
+    SegParams sp;
+    sp.threshold = q.threshold;
+    sp.average_threshold = q.average_threshold;
+    sp.criterion = q.criterion;
+    sp.n_cds = q.n_cds;
+    sp.n_biopfams = q.n_biopfams;
+    sp.edge_distance = q.edge_distance;
+    sp.trim = q.trim ? 1 : 0;
+    sp.carry = q.carry_state ? 1 : 0;
+    sp.bio_ptr = q.marker_ptr;
+    sp.bio_id = q.marker_id;
+    return sp;
+}
+gecco_crf_refine_params gecco_params(double threshold, int32_t n_cds, int32_t edge_distance, int32_t trim, int32_t carry_state) {
+    gecco_crf_refine_params q{};
+    q.threshold = threshold;
+    q.average_threshold = 0.6;
+    q.criterion = 0;
+    q.n_cds = n_cds;
+    q.n_biopfams = 5;
+    q.edge_distance = edge_distance;
+    q.trim = trim;
+    q.carry_state = carry_state;
+    return q;
+}
+}  // namespace
+
+GECCO_API int gecco_crf_session_clusters_ex(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                            const int32_t *gene_ptr, const int32_t *attr_id, const uint8_t *annotated,
+                                            int32_t window, int32_t step, int32_t label, int32_t pad,
+                                            const gecco_crf_refine_params *params, double *p_out, int32_t *seg_out,
+                                            int32_t max_seg, int32_t *n_seg, double *seg_p_out, int64_t max_seg_genes,
+                                            int64_t *seg_off_out) {
+    if (!s || !params) return GECCO_CRF_EINVAL;
     BatchRequest r = csr_request(contig_ptr, n_contigs, gene_ptr, attr_id);
     r.window = window;
     r.step = step;
@@ -371,10 +400,7 @@ GECCO_API int gecco_crf_session_clusters(gecco_crf_session *s, const int32_t *co
     r.p_out = p_out;
     r.want_segments = true;
     r.annotated = annotated;
-    r.threshold = threshold;
-    r.n_cds = n_cds;
-    r.edge_distance = edge_distance;
-    r.trim = trim;
+    r.seg = seg_params(*params);
     r.seg_out = seg_out;
     r.max_seg = max_seg;
     r.n_seg = n_seg;
@@ -382,6 +408,17 @@ GECCO_API int gecco_crf_session_clusters(gecco_crf_session *s, const int32_t *co
     r.max_seg_genes = max_seg_genes;
     r.seg_off_out = seg_off_out;
     return run_guarded(*s->s, r);
+}
+
+GECCO_API int gecco_crf_session_clusters(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                         const int32_t *gene_ptr, const int32_t *attr_id, const uint8_t *annotated,
+                                         int32_t window, int32_t step, int32_t label, int32_t pad, double threshold,
+                                         int32_t n_cds, int32_t edge_distance, int32_t trim, double *p_out, int32_t *seg_out,
+                                         int32_t max_seg, int32_t *n_seg, double *seg_p_out, int64_t max_seg_genes,
+                                         int64_t *seg_off_out) {
+    const gecco_crf_refine_params q = gecco_params(threshold, n_cds, edge_distance, trim, 0);
+    return gecco_crf_session_clusters_ex(s, contig_ptr, n_contigs, gene_ptr, attr_id, annotated, window, step, label, pad, &q, p_out,
+                                         seg_out, max_seg, n_seg, seg_p_out, max_seg_genes, seg_off_out);
 }
 
 // ---- one-shot host entry points: thin wrappers over the model's own per-device session ------------
@@ -504,14 +541,18 @@ struct Scratch {
 inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 }  // namespace
 
-GECCO_API int gecco_crf_segment(int32_t device, const double *p, const uint8_t *annotated, const int32_t *contig_ptr,
-                                int32_t n_contigs, double threshold, int32_t n_cds, int32_t edge_distance,
-                                int32_t trim, int32_t carry_state, int32_t *seg_out, int32_t max_seg, int32_t *n_seg) {
-    if (!n_seg || n_contigs < 0 || (n_contigs > 0 && !contig_ptr) || max_seg < 0 || (max_seg > 0 && !seg_out)) {
+GECCO_API int gecco_crf_segment_ex(int32_t device, const double *p, const uint8_t *annotated, const int32_t *contig_ptr,
+                                   int32_t n_contigs, const gecco_crf_refine_params *params, int32_t *seg_out, int32_t max_seg,
+                                   int32_t *n_seg) {
+    if (!params || !n_seg || n_contigs < 0 || (n_contigs > 0 && !contig_ptr) || max_seg < 0 || (max_seg > 0 && !seg_out)) {
         set_error("gecco_crf_segment: bad arguments");
         return GECCO_CRF_EINVAL;
     }
     *n_seg = 0;
+    if (params->criterion != 0 && params->criterion != 1) {
+        set_error("Unknown cluster filtering criterion");  // refine.py:165
+        return GECCO_CRF_EINVAL;
+    }
     int rc = check_device(device);
     if (rc) return rc;
     if (n_contigs == 0) return GECCO_CRF_OK;
@@ -526,21 +567,41 @@ GECCO_API int gecco_crf_segment(int32_t device, const double *p, const uint8_t *
         set_error("gecco_crf_segment: bad arguments");
         return GECCO_CRF_EINVAL;
     }
+    SegParams sp = seg_params(*params);
+    size_t nb = 0;
+    if (sp.criterion == 1) {
+        if (!sp.bio_ptr || sp.bio_ptr[0] != 0 || sp.bio_ptr[n] < 0 || (sp.bio_ptr[n] > 0 && !sp.bio_id)) {
+            set_error("the antismash criterion needs the genes' marker domains (marker_ptr[0] = 0)");
+            return GECCO_CRF_EINVAL;
+        }
+        for (size_t g = 0; g < n; ++g)
+            if (sp.bio_ptr[g + 1] < sp.bio_ptr[g]) {
+                set_error("marker_ptr must be non-decreasing");
+                return GECCO_CRF_EINVAL;
+            }
+        nb = size_t(sp.bio_ptr[n]);
+    }
     DeviceGuard guard;
     GECCO_GUARD_BEGIN
     static thread_local Scratch scratch;
     const size_t o_p = 0, o_a = o_p + al256(n * 8), o_c = o_a + al256(n + 8), o_seg = o_c + al256((nc + 1) * 4),
-                 o_tot = o_seg + al256(size_t(max_seg) * 16 + 16), o_ws = o_tot + 256,
-                 bytes = o_ws + segment_workspace_bytes(int(n), n_contigs);
+                 o_tot = o_seg + al256(size_t(max_seg) * 16 + 16), o_bp = o_tot + 256, o_bi = o_bp + al256((n + 1) * 4),
+                 o_ws = o_bi + al256((nb + 4) * 4), bytes = o_ws + segment_workspace_bytes(int(n), n_contigs);
     if ((rc = scratch.reserve(device, bytes))) return rc;
     char *d = scratch.d;
     if ((rc = check_hip(hipMemcpy(d + o_p, p, n * 8, hipMemcpyHostToDevice), "H2D p"))) return rc;
     if ((rc = check_hip(hipMemcpy(d + o_a, annotated, n, hipMemcpyHostToDevice), "H2D annotated"))) return rc;
     if ((rc = check_hip(hipMemcpy(d + o_c, contig_ptr, (nc + 1) * 4, hipMemcpyHostToDevice), "H2D contig_ptr"))) return rc;
+    if (sp.criterion == 1) {
+        if ((rc = check_hip(hipMemcpy(d + o_bp, sp.bio_ptr, (n + 1) * 4, hipMemcpyHostToDevice), "H2D marker_ptr"))) return rc;
+        if (nb && (rc = check_hip(hipMemcpy(d + o_bi, sp.bio_id, nb * 4, hipMemcpyHostToDevice), "H2D marker_id"))) return rc;
+        sp.bio_ptr = reinterpret_cast<const int32_t *>(d + o_bp);
+        sp.bio_id = reinterpret_cast<const int32_t *>(d + o_bi);
+    }
     int32_t *d_seg = reinterpret_cast<int32_t *>(d + o_seg), *d_total = reinterpret_cast<int32_t *>(d + o_tot);
     if ((rc = check_hip(launch_segment(reinterpret_cast<const double *>(d + o_p), reinterpret_cast<const uint8_t *>(d + o_a), nullptr,
-                                       reinterpret_cast<const int32_t *>(d + o_c), int(n), n_contigs, threshold, n_cds, edge_distance,
-                                       trim ? 1 : 0, carry_state ? 1 : 0, d_seg, max_seg, nullptr, d_total, d + o_ws, nullptr),
+                                       reinterpret_cast<const int32_t *>(d + o_c), int(n), n_contigs, sp, d_seg, max_seg, nullptr,
+                                       d_total, d + o_ws, nullptr),
                         "segment launch")))
         return rc;
     int32_t total = 0;
@@ -556,15 +617,29 @@ GECCO_API int gecco_crf_segment(int32_t device, const double *p, const uint8_t *
     GECCO_GUARD_END
 }
 
+GECCO_API int gecco_crf_segment(int32_t device, const double *p, const uint8_t *annotated, const int32_t *contig_ptr,
+                                int32_t n_contigs, double threshold, int32_t n_cds, int32_t edge_distance,
+                                int32_t trim, int32_t carry_state, int32_t *seg_out, int32_t max_seg, int32_t *n_seg) {
+    const gecco_crf_refine_params q = gecco_params(threshold, n_cds, edge_distance, trim, carry_state);
+    return gecco_crf_segment_ex(device, p, annotated, contig_ptr, n_contigs, &q, seg_out, max_seg, n_seg);
+}
+
+GECCO_API int gecco_crf_plan_run_segment_ex(gecco_crf_plan *p, const double *d_p, const uint8_t *d_annotated,
+                                            const gecco_crf_refine_params *params, int32_t *d_seg, int32_t max_seg,
+                                            int32_t *d_n_seg, void *stream) {
+    if (!p || !params) return GECCO_CRF_EINVAL;
+    DeviceGuard guard;
+    GECCO_GUARD_BEGIN
+    return plan_run_segment(p->p, d_p, d_annotated, seg_params(*params), d_seg, max_seg, nullptr, d_n_seg,
+                            static_cast<hipStream_t>(stream));
+    GECCO_GUARD_END
+}
+
 GECCO_API int gecco_crf_plan_run_segment(gecco_crf_plan *p, const double *d_p, const uint8_t *d_annotated, double threshold,
                                          int32_t n_cds, int32_t edge_distance, int32_t trim, int32_t carry_state,
                                          int32_t *d_seg, int32_t max_seg, int32_t *d_n_seg, void *stream) {
-    if (!p) return GECCO_CRF_EINVAL;
-    DeviceGuard guard;
-    GECCO_GUARD_BEGIN
-    return plan_run_segment(p->p, d_p, d_annotated, threshold, n_cds, edge_distance, trim ? 1 : 0, carry_state ? 1 : 0, d_seg, max_seg,
-                            nullptr, d_n_seg, static_cast<hipStream_t>(stream));
-    GECCO_GUARD_END
+    const gecco_crf_refine_params q = gecco_params(threshold, n_cds, edge_distance, trim, carry_state);
+    return gecco_crf_plan_run_segment_ex(p, d_p, d_annotated, &q, d_seg, max_seg, d_n_seg, stream);
 }
 
 GECCO_API int gecco_crf_domain_composition(int32_t device, const int32_t *seg, int32_t n_seg, const int32_t *dom_ptr,
@@ -644,6 +719,8 @@ GECCO_API const int64_t *gecco_crf_packed_gene_row(const gecco_crf_packed *p) { 
 GECCO_API const int32_t *gecco_crf_packed_row_gene(const gecco_crf_packed *p) { return p ? p->p.row_gene.data() : nullptr; }
 GECCO_API const int64_t *gecco_crf_packed_row_order(const gecco_crf_packed *p) { return p ? p->p.row_order.data() : nullptr; }
 GECCO_API const int64_t *gecco_crf_packed_row_ptr(const gecco_crf_packed *p) { return p ? p->p.row_ptr.data() : nullptr; }
+GECCO_API const int32_t *gecco_crf_packed_marker_ptr(const gecco_crf_packed *p) { return p ? p->p.marker_ptr : nullptr; }
+GECCO_API const int32_t *gecco_crf_packed_marker_id(const gecco_crf_packed *p) { return p ? p->p.marker_id : nullptr; }
 
 GECCO_API int gecco_crf_cluster_rows_build(const gecco_crf_packed *p, const gecco_crf_table_columns *t, const int64_t *gene_end,
                                            const int64_t *feature_end, const int32_t *seg, int32_t n_seg, const double *seg_p,

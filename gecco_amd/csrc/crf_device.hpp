@@ -147,6 +147,18 @@ struct SegE {  // what a span of genes does to the grouper, as a function of the
     uint32_t ng0, ng1;  // cluster runs started inside the span when entered in state 0 / 1
     uint32_t ann;       // annotated genes in the span
 };
+// What the refiner is asked for (refine.py:75-116).  criterion 0 = "gecco" (annotated genes and genes away from the
+// contig edges >= n_cds, :142-156), 1 = "antismash" (mean p >= average_threshold, distinct marker domains >=
+// n_biopfams, genes >= n_cds, :157-163).  `bio_ptr` / `bio_id`: per gene the marker domains it carries (CSR over genes,
+// ids in [0, kSegMaxMarkers)), device pointers, antismash only.
+constexpr int kSegMaxMarkers = 256;
+struct SegParams {
+    double threshold = 0.8;
+    int32_t n_cds = 5, edge_distance = 0, trim = 1, carry = 0;
+    int32_t criterion = 0, n_biopfams = 5;
+    double average_threshold = 0.6;
+    const int32_t *bio_ptr = nullptr, *bio_id = nullptr;
+};
 struct SegArgs {
     const double *p;        // [n_genes] probabilities (NaN: none)
     const uint8_t *ann;     // [n_genes] the gene has at least one domain
@@ -155,6 +167,9 @@ struct SegArgs {
     int32_t n_genes, n_contigs;
     double thr;
     int32_t n_cds, edge, trim, carry;
+    int32_t criterion, n_bio;
+    double avg_thr;
+    const int32_t *bio_ptr, *bio_id;
     // workspace
     SegE *lane, *block;     // exclusive prefix per lane inside its workgroup; per workgroup
     int32_t *pre;           // [n_genes+1] annotated genes before gene g
@@ -170,9 +185,8 @@ struct SegArgs {
 };
 size_t segment_workspace_bytes(int n_genes, int n_contigs);
 hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t *d_flags, const int32_t *d_cptr,
-                          int n_genes, int n_contigs, double threshold, int n_cds, int edge_distance, int trim, int carry,
-                          int32_t *d_seg, int max_seg, int32_t *d_seg_off, int32_t *d_total, void *d_work,
-                          hipStream_t stream);
+                          int n_genes, int n_contigs, const SegParams &params, int32_t *d_seg, int max_seg,
+                          int32_t *d_seg_off, int32_t *d_total, void *d_work, hipStream_t stream);
 hipError_t launch_segment_gather(const double *d_p, const int32_t *d_seg, const int32_t *d_seg_off, const int32_t *d_total,
                                  int max_seg, double *d_out, int cap, hipStream_t stream);
 

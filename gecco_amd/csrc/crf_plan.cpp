@@ -872,11 +872,18 @@ int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id
     return check_hip(launch_seq_viterbi(a, p.d_contig_ptr, stream), "viterbi launch");
 }
 
-int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, double threshold, int32_t n_cds,
-                     int32_t edge_distance, int32_t trim, int32_t carry, int32_t *d_seg, int32_t max_seg, int32_t *d_seg_off,
-                     int32_t *d_total, hipStream_t stream) {
+int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, const SegParams &params, int32_t *d_seg,
+                     int32_t max_seg, int32_t *d_seg_off, int32_t *d_total, hipStream_t stream) {
     if (!d_total || max_seg < 0 || (max_seg > 0 && !d_seg)) {
         set_error("plan_run_segment: bad arguments");
+        return GECCO_CRF_EINVAL;
+    }
+    if (params.criterion != 0 && params.criterion != 1) {
+        set_error("Unknown cluster filtering criterion");  // refine.py:165
+        return GECCO_CRF_EINVAL;
+    }
+    if (params.criterion == 1 && p.n_genes > 0 && (!params.bio_ptr || !params.bio_id)) {
+        set_error("the antismash criterion needs the genes' marker domains");
         return GECCO_CRF_EINVAL;
     }
     int rc = plan_ensure_seq(p, stream, !p.async_tables);
@@ -890,8 +897,8 @@ int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, dou
         if ((rc = grow_ws(p.d_seg_ws, p.seg_ws_cap, segment_workspace_bytes(p.n_genes, p.n_contigs), "hipMalloc segment workspace")))
             return rc;
     }
-    return check_hip(launch_segment(d_p, d_annotated, p.d_seq_flags, p.d_contig_ptr, p.n_genes, p.n_contigs, threshold, n_cds,
-                                    edge_distance, trim, carry, d_seg, max_seg, d_seg_off, d_total, p.d_seg_ws, stream),
+    return check_hip(launch_segment(d_p, d_annotated, p.d_seq_flags, p.d_contig_ptr, p.n_genes, p.n_contigs, params, d_seg, max_seg,
+                                    d_seg_off, d_total, p.d_seg_ws, stream),
                      "segment launch");
 }
 

@@ -87,9 +87,8 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
 int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync = true);
 // row R chained behind the marginals on the same stream: d_p and d_annotated are device arrays over the
 // plan's genes; rows go to d_seg (device-accessible memory), their number to d_total
-int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, double threshold, int32_t n_cds,
-                     int32_t edge_distance, int32_t trim, int32_t carry, int32_t *d_seg, int32_t max_seg, int32_t *d_seg_off,
-                     int32_t *d_total, hipStream_t stream);
+int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, const SegParams &params, int32_t *d_seg,
+                     int32_t max_seg, int32_t *d_seg_off, int32_t *d_total, hipStream_t stream);
 int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                       hipStream_t stream);
 // windowed marginals + whole-contig Viterbi of the same batch in one pass over the CSR

@@ -221,16 +221,37 @@ __global__ void __launch_bounds__(kT) seg_validate(const SegArgs A) {
                     b = upper_bound_i32(A.pre, a + 1, e + 1, pre_e - 1);      // one past the last annotated gene
                 }
             }
-            const int pa = A.pre[a], ann = A.pre[b] - pa;
-            int edge = 0;
-            if (A.edge > 0) {
-                const int n_ann = A.pre[g1] - A.pre[g0];
-                const int ra = pa - A.pre[g0], rb = ra + ann;  // ranks of the run's annotated genes
-                const int lo2 = max(A.edge, n_ann - A.edge);   // [0, edge) u [lo2, n_ann)
-                edge = max(0, min(rb, A.edge) - ra) + max(0, rb - max(ra, lo2));
-            }
-            kept = ann >= A.n_cds && (b - a) - edge >= A.n_cds;
             len = b - a;
+            if (A.criterion == 0) {
+                const int pa = A.pre[a], ann = A.pre[b] - pa;
+                int edge = 0;
+                if (A.edge > 0) {
+                    const int n_ann = A.pre[g1] - A.pre[g0];
+                    const int ra = pa - A.pre[g0], rb = ra + ann;  // ranks of the run's annotated genes
+                    const int lo2 = max(A.edge, n_ann - A.edge);   // [0, edge) u [lo2, n_ann)
+                    edge = max(0, min(rb, A.edge) - ra) + max(0, rb - max(ra, lo2));
+                }
+                kept = ann >= A.n_cds && len - edge >= A.n_cds;
+            } else {
+                // "antismash" (refine.py:157-163): mean probability, distinct marker domains, number of genes.  This
+                // one does walk the run (one lane per run; runs are short where this criterion is used).  The mean
+                // is the plain left-to-right sum over the count: numpy.mean's own last bit depends on the SIMD
+                // width numpy was dispatched to, so the reference does not pin it.
+                double sum = 0.0;
+                uint64_t seen[kSegMaxMarkers / 64] = {};
+                for (int g = a; g < b; ++g) {
+                    sum += A.p[g];
+                    for (int k = A.bio_ptr[g]; k < A.bio_ptr[g + 1]; ++k) {
+                        const uint32_t id = uint32_t(A.bio_id[k]);
+                        if (id < uint32_t(kSegMaxMarkers)) seen[id >> 6] |= 1ull << (id & 63u);
+                    }
+                }
+                int markers = 0;
+#pragma unroll
+                for (int w = 0; w < kSegMaxMarkers / 64; ++w) markers += __popcll(seen[w]);
+                // an empty (all trimmed away) run has mean NaN there: rejected like every failed comparison
+                kept = len > 0 && sum / double(len) >= A.avg_thr && markers >= A.n_bio && len >= A.n_cds;
+            }
             A.val[i] = make_int4(kept ? c : -1 - c, number, a, b);
         }
         const int cnt = __syncthreads_count(kept ? 1 : 0);
@@ -319,9 +340,8 @@ size_t segment_workspace_bytes(int n_genes, int n_contigs) {
 // d_seg_off may be null.  d_total receives the number of kept rows (it may exceed max_seg: the rows
 // beyond are not written).
 hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t *d_flags, const int32_t *d_cptr,
-                          int n_genes, int n_contigs, double threshold, int n_cds, int edge_distance, int trim, int carry,
-                          int32_t *d_seg, int max_seg, int32_t *d_seg_off, int32_t *d_total, void *d_work,
-                          hipStream_t stream) {
+                          int n_genes, int n_contigs, const SegParams &params, int32_t *d_seg, int max_seg,
+                          int32_t *d_seg_off, int32_t *d_total, void *d_work, hipStream_t stream) {
     if (n_contigs <= 0 || n_genes <= 0) {
         if (d_seg_off) (void)hipMemsetAsync(d_seg_off, 0, 4, stream);
         return hipMemsetAsync(d_total, 0, 4, stream);
@@ -334,11 +354,16 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
     a.cptr = d_cptr;
     a.n_genes = n_genes;
     a.n_contigs = n_contigs;
-    a.thr = threshold;
-    a.n_cds = n_cds;
-    a.edge = edge_distance;
-    a.trim = trim;
-    a.carry = carry;
+    a.thr = params.threshold;
+    a.n_cds = params.n_cds;
+    a.edge = params.edge_distance;
+    a.trim = params.trim;
+    a.carry = params.carry;
+    a.criterion = params.criterion;
+    a.n_bio = params.n_biopfams;
+    a.avg_thr = params.average_threshold;
+    a.bio_ptr = params.bio_ptr;
+    a.bio_id = params.bio_id;
     a.lane = reinterpret_cast<SegE *>(w);
     w += align256s(nb * kT * sizeof(SegE));
     a.block = reinterpret_cast<SegE *>(w);

@@ -102,7 +102,7 @@ struct Lane {
     hipEvent_t ev_up = nullptr, ev_comp = nullptr, done = nullptr;
     int chunk = -1;  // index of the chunk in flight, -1: idle
     Plan plan;
-    DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm;
+    DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi;
     HostBuf h_seg;  // [total][pad..][seg_off: cap+1][rows: cap*4][p of the rows: n_genes]
     int32_t seg_cap = 0;
     size_t o_off = 0, o_rows = 0, o_p = 0;
@@ -135,7 +135,7 @@ Session::~Session() {
         if (hipSetDevice(d->device) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
         for (Lane &ln : d->lanes) {
-            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm}) b->release();
+            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi}) b->release();
             ln.h_seg.release();
             for (hipEvent_t e : {ln.ev_up, ln.ev_comp, ln.done})
                 if (e) (void)hipEventDestroy(e);
@@ -295,6 +295,7 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
         return GECCO_CRF_EINVAL;
     }
     const size_t nnz = size_t(a1 - a0), L = size_t(m.L);
+    int64_t b0 = 0;  // first marker offset of the chunk (antismash criterion)
     // ---- uploads first: the bulk copies are on their way while the host lays the chunk out
     if (ng) {
         if (!X.z_gene_ptr) {
@@ -314,6 +315,22 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
             if ((rc = check_hip(hipMemcpyAsync(ln.d_ann.p, r.annotated + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D annotated")))
                 return rc;
             S.stats.h2d_bytes += ng;
+            if (r.seg.criterion == 1) {  // the genes' marker domains, offsets kept as the caller's (like gene_ptr)
+                b0 = r.seg.bio_ptr[ck.g0];
+                const int64_t b1 = r.seg.bio_ptr[ck.g1];
+                if (b0 < 0 || b1 < b0) {
+                    set_error("marker_ptr must be non-decreasing and start at a non-negative offset");
+                    return GECCO_CRF_EINVAL;
+                }
+                const size_t nb = size_t(b1 - b0);
+                if ((rc = ln.d_bp.reserve((size_t(ng) + 1) * 4, "hipMalloc marker_ptr"))) return rc;
+                if ((rc = ln.d_bi.reserve((nb + 4) * 4, "hipMalloc marker_id"))) return rc;
+                if ((rc = check_hip(hipMemcpyAsync(ln.d_bp.p, r.seg.bio_ptr + ck.g0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.up), "H2D marker_ptr")))
+                    return rc;
+                if (nb && (rc = check_hip(hipMemcpyAsync(ln.d_bi.p, r.seg.bio_id + b0, nb * 4, hipMemcpyHostToDevice, ln.up), "H2D marker_id")))
+                    return rc;
+                S.stats.h2d_bytes += int64_t((size_t(ng) + 1 + nb) * 4);
+            }
         }
     }
     tm.lap("h2d csr", chunk_index);
@@ -395,8 +412,15 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
         char *dp = ln.h_seg.dp;
         int32_t *d_total = reinterpret_cast<int32_t *>(dp), *d_off = reinterpret_cast<int32_t *>(dp + ln.o_off),
                 *d_rows = reinterpret_cast<int32_t *>(dp + ln.o_rows);
-        if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(ln.d_ann.p), r.threshold, r.n_cds, r.edge_distance,
-                                   r.trim, 0, d_rows, int32_t(cap), d_off, d_total, ln.comp)))
+        SegParams sp = r.seg;
+        sp.carry = 0;
+        sp.bio_ptr = sp.bio_id = nullptr;
+        if (sp.criterion == 1) {
+            sp.bio_ptr = reinterpret_cast<const int32_t *>(ln.d_bp.p);
+            sp.bio_id = reinterpret_cast<const int32_t *>(ln.d_bi.p) - b0;
+        }
+        if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(ln.d_ann.p), sp, d_rows, int32_t(cap), d_off, d_total,
+                                   ln.comp)))
             return rc;
         if (r.seg_p_out &&
             (rc = check_hip(launch_segment_gather(d_p, d_rows, d_off, d_total, int32_t(cap), reinterpret_cast<double *>(dp + ln.o_p), ng,
@@ -493,6 +517,10 @@ int session_run(Session &S, const BatchRequest &r) {
         set_error("segments: bad output arguments");
         return GECCO_CRF_EINVAL;
     }
+    if (r.want_segments && r.seg.criterion != 0 && r.seg.criterion != 1) {
+        set_error("Unknown cluster filtering criterion");  // refine.py:165
+        return GECCO_CRF_EINVAL;
+    }
     if (r.n_seg) *r.n_seg = 0;
     for (int32_t c = 0; c < r.n_contigs; ++c)
         if (r.contig_ptr[c + 1] < r.contig_ptr[c]) {
@@ -502,6 +530,11 @@ int session_run(Session &S, const BatchRequest &r) {
     const int64_t n_genes = r.n_contigs ? r.contig_ptr[r.n_contigs] : 0;
     if (n_genes > 0 && (!r.gene_ptr || (r.want_segments && !r.annotated))) {
         set_error("null buffer");
+        return GECCO_CRF_EINVAL;
+    }
+    if (n_genes > 0 && r.want_segments && r.seg.criterion == 1 &&
+        (!r.seg.bio_ptr || (r.seg.bio_ptr[n_genes] > r.seg.bio_ptr[0] && !r.seg.bio_id))) {
+        set_error("the antismash criterion needs the genes' marker domains");
         return GECCO_CRF_EINVAL;
     }
     if (n_genes > 0 && r.gene_ptr[n_genes] > r.gene_ptr[0] && !r.attr_id) {

@@ -29,8 +29,8 @@ struct BatchRequest {
     // cluster calls (row R) on the windowed marginals, without moving them: rows and their count
     bool want_segments = false;
     const uint8_t *annotated = nullptr;  // [n_genes]
-    double threshold = 0.8;
-    int32_t n_cds = 3, edge_distance = 0, trim = 1;
+    SegParams seg;                       // carry is ignored (one grouper per contig); bio_ptr / bio_id are HOST arrays
+                                         // over the batch's genes here (antismash criterion)
     int32_t *seg_out = nullptr;     // [max_seg][4] (contig, number, first gene, last gene + 1), global indices
     int32_t max_seg = 0;
     int32_t *n_seg = nullptr;

@@ -31,6 +31,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/gecco_crf.h"
@@ -616,14 +617,25 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
     // its own code space; codes only have to tell the names of ONE gene apart, so they are made global by
     // adding the worker's base after the pass.
     std::vector<int32_t> row_dom(static_cast<size_t>(nf));
-    std::vector<int32_t> dom_attr;  // per distinct (worker, name): attribute id or -1
+    std::vector<int32_t> dom_attr;    // per distinct (worker, name): attribute id or -1
+    std::vector<int32_t> dom_marker;  // ... and its index in the caller's marker list or -1 (antismash criterion)
+    const bool want_markers = t.n_markers > 0;
+    if (t.n_markers > 256) {  // kSegMaxMarkers of the segmenter (crf_device.hpp)
+        set_error("at most 256 marker domains");
+        return GECCO_CRF_EINVAL;
+    }
+    std::unordered_map<std::string, int32_t> marker_index;
+    for (int64_t k = 0; k < t.n_markers; ++k) {
+        const Str d = at(t.markers, k);
+        marker_index.emplace(std::string(reinterpret_cast<const char *>(d.p), d.n), int32_t(k));
+    }
     {
-        std::vector<std::vector<int32_t>> attr_of(static_cast<size_t>(wf));
+        std::vector<std::vector<int32_t>> attr_of(static_cast<size_t>(wf)), mark_of(static_cast<size_t>(wf));
         std::vector<std::vector<Str>> name_of(static_cast<size_t>(wf));
         parallel_ranges(nf, wf, [&](int64_t b, int64_t e, int w) {
             Interner doms(4096);
             std::string key;
-            std::vector<int32_t> &attrs = attr_of[size_t(w)];
+            std::vector<int32_t> &attrs = attr_of[size_t(w)], &marks = mark_of[size_t(w)];
             auto code_of = [&](const Str &d) {
                 bool fresh = false;
                 const int32_t code = doms.intern(d, &fresh);
@@ -631,6 +643,10 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
                     key.assign(reinterpret_cast<const char *>(d.p), d.n);
                     auto it = m.attr_index.find(key);
                     attrs.push_back(it == m.attr_index.end() ? -1 : it->second);
+                    if (want_markers) {
+                        auto mk = marker_index.find(key);
+                        marks.push_back(mk == marker_index.end() ? -1 : mk->second);
+                    }
                 }
                 return code;
             };
@@ -670,7 +686,10 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
             for (size_t c = 0; c < name_of[size_t(w)].size(); ++c) {
                 bool fresh = false;
                 const int32_t g = all.intern(name_of[size_t(w)][c], &fresh);
-                if (fresh) dom_attr.push_back(attr_of[size_t(w)][c]);
+                if (fresh) {
+                    dom_attr.push_back(attr_of[size_t(w)][c]);
+                    if (want_markers) dom_marker.push_back(mark_of[size_t(w)][c]);
+                }
                 global[size_t(w)][c] = g;
             }
         }
@@ -685,12 +704,18 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
     {   // one block (a pinned allocation costs ~1 ms whatever its size)
         auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
         const size_t o_c = 0, o_g = o_c + up((cptr.size() + 1) * 4), o_a = o_g + up((size_t(n) + 2) * 4),
-                     o_n = o_a + up((size_t(nf) + 4) * 4), bytes = o_n + up(size_t(n) + 8);
+                     o_n = o_a + up((size_t(nf) + 4) * 4), o_mp = o_n + up(size_t(n) + 8),
+                     o_mi = o_mp + (want_markers ? up((size_t(n) + 2) * 4) : 0),
+                     bytes = o_mi + (want_markers ? up((size_t(nf) + 4) * 4) : 0);
         out.block = static_cast<char *>(alloc_staging(bytes, out.pinned));
         out.contig_ptr = reinterpret_cast<int32_t *>(out.block + o_c);
         out.gene_ptr = reinterpret_cast<int32_t *>(out.block + o_g);
         out.attr_id = reinterpret_cast<int32_t *>(out.block + o_a);
         out.annotated = reinterpret_cast<uint8_t *>(out.block + o_n);
+        if (want_markers) {
+            out.marker_ptr = reinterpret_cast<int32_t *>(out.block + o_mp);
+            out.marker_id = reinterpret_cast<int32_t *>(out.block + o_mi);
+        }
     }
     std::memcpy(out.contig_ptr, cptr.data(), cptr.size() * 4);
     if (cptr.size() == 1) out.contig_ptr[0] = 0;
@@ -732,6 +757,34 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
     });
     out.nnz = n ? out.gene_ptr[n] : 0;
     ph.lap("csr");
+    if (want_markers) {
+        // per gene the distinct marker domains among ALL its rows (refine.py:158: names of every domain of the
+        // member genes, whether the CRF knows them or not); few rows carry one
+        auto gene_markers = [&](int64_t g, int32_t *dst) {
+            int32_t kept = 0;
+            for (int64_t r = out.row_ptr[size_t(g)]; r < out.row_ptr[size_t(g) + 1]; ++r) {
+                const int32_t mk = dom_marker[size_t(row_dom[size_t(out.row_order[size_t(r)])])];
+                if (mk < 0) continue;
+                bool dup = false;
+                for (int64_t q = out.row_ptr[size_t(g)]; q < r && !dup; ++q)
+                    dup = dom_marker[size_t(row_dom[size_t(out.row_order[size_t(q)])])] == mk;
+                if (dup) continue;
+                if (dst) dst[kept] = mk;
+                ++kept;
+            }
+            return kept;
+        };
+        out.marker_ptr[0] = 0;
+        parallel_ranges(n, wc, [&](int64_t gb, int64_t ge, int) {
+            for (int64_t g = gb; g < ge; ++g) out.marker_ptr[g + 1] = gene_markers(g, nullptr);
+        });
+        for (int64_t g = 0; g < n; ++g) out.marker_ptr[g + 1] += out.marker_ptr[g];
+        parallel_ranges(n, wc, [&](int64_t gb, int64_t ge, int) {
+            for (int64_t g = gb; g < ge; ++g)
+                if (out.marker_ptr[g + 1] > out.marker_ptr[g]) (void)gene_markers(g, out.marker_id + out.marker_ptr[g]);
+        });
+        ph.lap("markers");
+    }
     return GECCO_CRF_OK;
 }
 

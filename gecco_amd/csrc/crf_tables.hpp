@@ -17,6 +17,7 @@ struct Packed {
     char *block = nullptr;  // one allocation behind the four arrays
     int32_t *contig_ptr = nullptr, *gene_ptr = nullptr, *attr_id = nullptr;
     uint8_t *annotated = nullptr;
+    int32_t *marker_ptr = nullptr, *marker_id = nullptr;  // [n_genes+1], [..]: marker domains per gene, or null
     std::vector<int64_t> gene_row;   // [n_genes] gene-table row of every gene, or -1 - (its first feature row)
     std::vector<int32_t> row_gene;   // [n_rows]  position (scoring order) of every feature row's gene
     std::vector<int64_t> row_order;  // [n_rows]  feature rows by (gene position, domain_start), stable

@@ -8,7 +8,7 @@ the model's attribute dictionary and silently drops unknown ones.  Here both ste
 once: names -> int32 attribute ids in CSR form.
 """
 from dataclasses import dataclass
-from typing import Any, Dict, List, Sequence
+from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 
@@ -150,19 +150,23 @@ def pack_columns(sequence_id: Sequence[str], protein_id: Sequence[str], start: S
     return PackedColumns(contig_ids, order, contig_ptr, gene_ptr, attr, annotated, row_gene, row_order, row_ptr)
 
 
-def pack_tables(native_model: Any, feats_t: Any, genes_t: Any = None):
+def pack_tables(native_model: Any, feats_t: Any, genes_t: Any = None, markers: Optional[Sequence[str]] = None):
     """Native columnar packer (``gecco_crf_pack_columns``, csrc/crf_tables.cpp): the same result as `pack_columns`
     from tables whose text columns are in Arrow layout (``tables.StringColumn``), without a Python object per
     row -- strings are hashed at most once, orders are checked before anything is sorted, and the CSR lands in
-    pinned memory ready for the batch driver.  Returns a ``_native.PackedTables``."""
+    pinned memory ready for the batch driver.  Returns a ``_native.PackedTables``.  With `markers` (domain names,
+    at most 256: the antismash criterion's biosynthetic Pfams, refine.py:157-163) it also carries, per gene, which
+    of them occur among ALL the gene's domains (`marker_ptr`, `marker_id`)."""
     from . import _native
+    from .tables import StringColumn
 
     g = (None, None, None)
     if genes_t is not None:
         g = (genes_t.string_column("sequence_id"), genes_t.string_column("protein_id"), genes_t.start)
     return _native.PackedTables(
         native_model, feats_t.string_column("sequence_id"), feats_t.string_column("protein_id"), feats_t.start,
-        feats_t.string_column("domain"), feats_t.domain_start, *g)
+        feats_t.string_column("domain"), feats_t.domain_start, *g,
+        markers=StringColumn.from_sequence(list(markers)) if markers else None)
 
 
 def pack_columns_py(sequence_id: Sequence[str], protein_id: Sequence[str], start: Sequence[int], domain: Sequence[str],

@@ -22,6 +22,7 @@ import numpy as np
 
 from . import _native, composition, packing, tables
 from .crf import ClusterCRF
+from .refine import BIO_PFAMS
 
 
 def filter_features(feats_t: tables.FeatureTable, e_filter: Optional[float] = None,
@@ -55,7 +56,8 @@ def _refiner_order_differs(sid_code: np.ndarray, start: np.ndarray, end: np.ndar
 
 def predict_tables(genes_t: tables.GeneTable, feats_t: tables.FeatureTable, crf: ClusterCRF, *, pad: bool = True,
                    threshold: float = 0.8, n_cds: int = 3, edge_distance: int = 0, trim: bool = True,
-                   device: Optional[int] = None, composition_domains: Optional[List[str]] = None):
+                   device: Optional[int] = None, composition_domains: Optional[List[str]] = None,
+                   criterion: str = "gecco", n_biopfams: int = 5, average_threshold: float = 0.6):
     """Returns (GeneTable, FeatureTable, ClusterTable) with probabilities / clusters filled in; with
     `composition_domains` (the type classifier's domain list) also the (n_clusters, n_domains)
     weighted domain composition matrix ``TypeClassifier.predict_types`` feeds its forest with.
@@ -63,12 +65,18 @@ def predict_tables(genes_t: tables.GeneTable, feats_t: tables.FeatureTable, crf:
     Columns in, columns out: the native packer turns the tables into a CSR batch (pinned memory), the batch
     driver runs marginals and refiner on the device (one grouper per contig, like the CLI:
     cli/commands/_common.py:621-623), the probabilities come back once for the gene / feature tables, and
-    the cluster rows are assembled natively from the members' probabilities."""
+    the cluster rows are assembled natively from the members' probabilities.  `criterion` is the CLI's hidden
+    ``--postproc`` (cli/commands/_parser.py:294-301 -> refine.py:142-165); "antismash" runs on the device too: the
+    packer marks, per gene, which of the biosynthetic Pfams (refine.BIO_PFAMS) occur among its domains."""
+    if criterion not in _native.CRITERIA:
+        raise ValueError(f"Unknown cluster filtering criterion: {criterion}")
     if crf.feature_type != "protein":
         raise ValueError("the columnar path supports protein-level features (the shipped model's mode)")
     dev = crf.devices[0] if device is None else device
     native = crf.model.native
-    pk = packing.pack_tables(native, feats_t, genes_t)
+    markers = sorted(BIO_PFAMS) if criterion == "antismash" else None
+    pk = packing.pack_tables(native, feats_t, genes_t, markers)
+    refine_kw = dict(criterion=criterion, n_biopfams=n_biopfams, average_threshold=average_threshold)
     # the reference refuses tables that do not describe the same genes (annotate_genes raises KeyError /
     # ValueError, cli/commands/_common.py): a protein the gene table does not list, a repeated gene id
     if genes_t is not None and len(genes_t):
@@ -113,10 +121,18 @@ def predict_tables(genes_t: tables.GeneTable, feats_t: tables.FeatureTable, crf:
             reorder = np.lexsort((g_end_o, g_start_o, code))
     if reorder is None:
         seg, seg_p, seg_off, p = session.clusters(cptr, pk.gene_ptr, pk.attr_id, pk.annotated, W, crf.window_step, label, pad,
-                                                  threshold, n_cds, edge_distance, trim, want_p=True, want_seg_p=True)
+                                                  threshold, n_cds, edge_distance, trim, want_p=True, want_seg_p=True,
+                                                  marker_ptr=pk.marker_ptr, marker_id=pk.marker_id, **refine_kw)
     else:
         p = session.windowed_marginals(cptr, pk.gene_ptr, pk.attr_id, W, crf.window_step, label, pad)
-        seg = _native.segment(p[reorder], pk.annotated[reorder], cptr, threshold, n_cds, edge_distance, trim, device=dev)
+        mp = mi = None
+        if criterion == "antismash":  # the genes' marker lists in refiner order
+            cnt = np.diff(pk.marker_ptr)[reorder]
+            mp = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+            take = np.repeat(pk.marker_ptr[:-1][reorder] - mp[:-1], cnt) + np.arange(int(mp[-1]))
+            mi = pk.marker_id[take] if len(take) else np.zeros(0, dtype=np.int32)
+        seg = _native.segment(p[reorder], pk.annotated[reorder], cptr, threshold, n_cds, edge_distance, trim, device=dev,
+                              marker_ptr=mp, marker_id=mi, **refine_kw)
     if n == 0:
         p = np.zeros(0)
 
@@ -197,6 +213,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("-m", "--threshold", type=float, default=0.8)
     ap.add_argument("--cds", type=int, default=3)
     ap.add_argument("-E", "--edge-distance", type=int, default=0)
+    ap.add_argument("--postproc", choices=["gecco", "antismash"], default="gecco", help=argparse.SUPPRESS)
     ap.add_argument("--no-trim", action="store_true")
     ap.add_argument("-e", "--e-filter", type=float, default=None,
                     help="e-value cutoff for protein domains to be included (gecco predict -e)")
@@ -215,7 +232,7 @@ def main(argv: Optional[List[str]] = None) -> int:
             comp_domains = [line.strip() for line in fh if line.strip()]
     res = predict_tables(
         genes_t, feats_t, crf, pad=not args.no_pad, threshold=args.threshold, n_cds=args.cds,
-        edge_distance=args.edge_distance, trim=not args.no_trim, composition_domains=comp_domains)
+        edge_distance=args.edge_distance, trim=not args.no_trim, composition_domains=comp_domains, criterion=args.postproc)
     genes_out, feats_out, clusters = res[:3]
     os.makedirs(args.output_dir, exist_ok=True)
     base = os.path.splitext(os.path.basename(args.genes))[0]

@@ -48,7 +48,7 @@ typedef struct gecco_crf_plan gecco_crf_plan;
 
 /* Thread-local description of the last error returned on this thread. */
 const char *gecco_crf_last_error(void);
-/* ABI version: major*10000 + minor*100 + patch. */
+/* ABI version: major*100 + minor*10 + patch (2.1.0 = 210). */
 int gecco_crf_version(void);
 
 /* ---- model (replaces [EXT] pycrfsuite.Tagger.open / labels() / info(); the blob is the
@@ -113,6 +113,29 @@ int gecco_crf_segment(int32_t device, const double *p, const uint8_t *annotated,
                       double threshold, int32_t n_cds, int32_t edge_distance, int32_t trim,
                       int32_t carry_state, int32_t *seg_out, int32_t max_seg, int32_t *n_seg);
 
+/* ClusterRefiner's parameters (gecco/refine.py:75-116) for the *_ex entry points.  criterion 0 = "gecco"
+ * (:142-156: annotated genes, and genes away from the contig edges, >= n_cds); 1 = "antismash" (:157-163: mean
+ * probability of the member genes >= average_threshold, distinct marker domains among ALL their domains >=
+ * n_biopfams, member genes >= n_cds).  The marker domains (the reference's BIO_PFAMS list, refine.py:19-27) come
+ * as a CSR over the batch's genes: marker_ptr[n_genes+1], marker_id[...] in [0, 256) = index of the domain in the
+ * caller's marker list; only read when criterion == 1.  (The mean is the left-to-right sum over the count;
+ * numpy.mean's own last bit depends on the SIMD width numpy dispatches to, so the reference does not pin it.) */
+typedef struct {
+    double threshold;         /* 0.8 */
+    double average_threshold; /* 0.6 */
+    int32_t criterion;        /* 0 */
+    int32_t n_cds;            /* 5 */
+    int32_t n_biopfams;       /* 5 */
+    int32_t edge_distance;    /* 0 */
+    int32_t trim;             /* 1 */
+    int32_t carry_state;      /* see gecco_crf_segment; the batch driver always works per contig */
+    const int32_t *marker_ptr;
+    const int32_t *marker_id;
+} gecco_crf_refine_params;
+int gecco_crf_segment_ex(int32_t device, const double *p, const uint8_t *annotated,
+                         const int32_t *contig_ptr, int32_t n_contigs, const gecco_crf_refine_params *params,
+                         int32_t *seg_out, int32_t max_seg, int32_t *n_seg);
+
 /* Weighted domain composition of called clusters (gecco/model.py:458-503
  * `Cluster.domain_composition(all_possible, normalize)`, assembled per cluster for the type
  * classifier at gecco/types/__init__.py:118).  seg rows as written by gecco_crf_segment
@@ -162,6 +185,10 @@ int gecco_crf_plan_run_segment(gecco_crf_plan *p, const double *d_p, const uint8
                                double threshold, int32_t n_cds, int32_t edge_distance, int32_t trim,
                                int32_t carry_state, int32_t *d_seg, int32_t max_seg, int32_t *d_n_seg,
                                void *stream);
+/* Same with the full parameter set; marker_ptr / marker_id are DEVICE arrays over the plan's genes. */
+int gecco_crf_plan_run_segment_ex(gecco_crf_plan *p, const double *d_p, const uint8_t *d_annotated,
+                                  const gecco_crf_refine_params *params, int32_t *d_seg, int32_t max_seg,
+                                  int32_t *d_n_seg, void *stream);
 /* Average milliseconds per launch of `iters` back-to-back windowed launches, measured with
  * HIP events on `stream` (after `warmup` untimed launches). */
 int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
@@ -209,6 +236,14 @@ int gecco_crf_session_clusters(gecco_crf_session *s, const int32_t *contig_ptr, 
                                int32_t *n_seg, double *seg_p_out /* or NULL */, int64_t max_seg_genes,
                                int64_t *seg_off_out /* max_seg + 1, with seg_p_out */);
 
+/* Same with the full parameter set (host marker arrays over the batch's genes; carry_state is ignored). */
+int gecco_crf_session_clusters_ex(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                  const int32_t *gene_ptr, const int32_t *attr_id, const uint8_t *annotated,
+                                  int32_t window, int32_t step, int32_t label, int32_t pad,
+                                  const gecco_crf_refine_params *params, double *p_out, int32_t *seg_out,
+                                  int32_t max_seg, int32_t *n_seg, double *seg_p_out, int64_t max_seg_genes,
+                                  int64_t *seg_off_out);
+
 /* ---- columnar host side: table columns -> CSR batch, called clusters -> clusters.tsv rows --------
  * Strings travel as Arrow-style columns: one byte buffer + int64 offsets[n+1] per column (what
  * pandas / polars / pyarrow hold them in).  gecco_crf_pack_columns does, on columns, what the reference
@@ -229,6 +264,8 @@ typedef struct {
     int64_t n_genes; /* gene table, may be 0 */
     gecco_crf_strings gene_sequence_id, gene_protein_id;
     const int64_t *gene_start;
+    int64_t n_markers; /* marker domain names for the antismash criterion (<= 256), may be 0 */
+    gecco_crf_strings markers;
 } gecco_crf_table_columns;
 typedef struct gecco_crf_packed gecco_crf_packed;
 typedef struct gecco_crf_cluster_rows gecco_crf_cluster_rows;
@@ -247,6 +284,9 @@ const int64_t *gecco_crf_packed_gene_row(const gecco_crf_packed *p);   /* [n_gen
 const int32_t *gecco_crf_packed_row_gene(const gecco_crf_packed *p);   /* [n_rows] gene position of every feature row */
 const int64_t *gecco_crf_packed_row_order(const gecco_crf_packed *p);  /* [n_rows] rows by (gene position, domain_start) */
 const int64_t *gecco_crf_packed_row_ptr(const gecco_crf_packed *p);    /* [n_genes+1] */
+/* per gene the distinct marker domains among its rows (index into `markers`); NULL without markers */
+const int32_t *gecco_crf_packed_marker_ptr(const gecco_crf_packed *p); /* [n_genes+1] */
+const int32_t *gecco_crf_packed_marker_id(const gecco_crf_packed *p);
 /* Rows of clusters.tsv (gecco/model.py:731-760) for segments as returned by gecco_crf_session_clusters:
  * start / end over the member genes (gene_end: the gene table's `end`, feature_end: the feature table's),
  * average_p = statistics.mean of the members' probabilities, exactly rounded (:442-447), max_p, the sorted

@@ -378,3 +378,67 @@ ORACLE_API int oracle_segment(const double *p, const uint8_t *annotated,
     }
     return kept;
 }
+
+/* The same walk with the "antismash" validation of refine.py:157-163: mean probability of the (trimmed) run's genes
+ * >= average_threshold, distinct marker domains (the reference's BIO_PFAMS) among ALL domains of those genes >=
+ * n_biopfams, number of genes >= n_cds.  marker_ptr / marker_id: CSR over genes of marker indices (< 256).  The mean
+ * is the left-to-right sum over the count (numpy.mean's last bit depends on numpy's SIMD dispatch: not pinned). */
+ORACLE_API int oracle_segment_antismash(const double *p, const uint8_t *annotated, const int32_t *contig_ptr, int n_contigs,
+                                        const int32_t *marker_ptr, const int32_t *marker_id, double threshold, int n_cds,
+                                        int n_biopfams, double average_threshold, int trim, int carry_state,
+                                        int32_t *seg_out, int max_seg)
+{
+    int kept = 0;
+    int in_cluster = 0;
+    for (int ci = 0; ci < n_contigs; ++ci) {
+        int g0 = contig_ptr[ci], g1 = contig_ptr[ci + 1];
+        if (!carry_state) in_cluster = 0;
+        int number = 0;
+        int g = g0;
+        while (g < g1) {
+            if (p[g] == p[g]) in_cluster = p[g] > threshold;
+            int key = in_cluster;
+            int h = g + 1;
+            while (h < g1) {
+                int k2;
+                if (p[h] == p[h]) k2 = p[h] > threshold; else k2 = in_cluster;
+                if (k2 != key) break;
+                in_cluster = k2;
+                ++h;
+            }
+            if (key) {
+                ++number;
+                int a = g, b = h;
+                if (trim) {
+                    while (a < b && !annotated[a]) ++a;
+                    while (b > a && !annotated[b - 1]) --b;
+                }
+                double sum = 0.0;
+                uint8_t seen[256];
+                memset(seen, 0, sizeof seen);
+                int markers = 0;
+                for (int k = a; k < b; ++k) {
+                    sum += p[k];
+                    for (int q = marker_ptr[k]; q < marker_ptr[k + 1]; ++q) {
+                        int id = marker_id[q];
+                        if (id >= 0 && id < 256 && !seen[id]) {
+                            seen[id] = 1;
+                            ++markers;
+                        }
+                    }
+                }
+                /* an empty run has mean NaN in the reference: every comparison fails */
+                if (b > a && sum / (double)(b - a) >= average_threshold && markers >= n_biopfams && b - a >= n_cds) {
+                    if (kept >= max_seg) return -1;
+                    seg_out[4 * kept + 0] = ci;
+                    seg_out[4 * kept + 1] = number;
+                    seg_out[4 * kept + 2] = a;
+                    seg_out[4 * kept + 3] = b;
+                    ++kept;
+                }
+            }
+            g = h;
+        }
+    }
+    return kept;
+}

@@ -227,6 +227,25 @@ def segment(p, annotated, contig_ptr, threshold=0.8, n_cds=3, edge_distance=0, t
     return seg[:k].copy()
 
 
+def segment_antismash(p, annotated, contig_ptr, marker_ptr, marker_id, threshold=0.8, n_cds=5, n_biopfams=5,
+                      average_threshold=0.6, trim=True, carry_state=False):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    annotated = np.ascontiguousarray(annotated, dtype=np.uint8)
+    contig_ptr = np.ascontiguousarray(contig_ptr, dtype=np.int32)
+    marker_ptr = np.ascontiguousarray(marker_ptr, dtype=np.int32)
+    marker_id = np.ascontiguousarray(marker_id if len(marker_id) else np.zeros(1), dtype=np.int32)
+    cap = max(1, len(p))
+    seg = np.zeros((cap, 4), dtype=np.int32)
+    k = lib().oracle_segment_antismash(
+        _p(p, _D), _p(annotated, _B), _p(contig_ptr, _I), len(contig_ptr) - 1, _p(marker_ptr, _I), _p(marker_id, _I),
+        _D(threshold), int(n_cds), int(n_biopfams), _D(average_threshold), int(bool(trim)), int(bool(carry_state)),
+        _p(seg, _I), cap,
+    )
+    if k < 0:
+        raise RuntimeError("oracle_segment_antismash overflow")
+    return seg[:k].copy()
+
+
 # --------------------------------------------------------------------------------------
 # second, independent oracle: brute-force enumeration of all L**T label paths
 # --------------------------------------------------------------------------------------

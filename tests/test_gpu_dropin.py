@@ -243,3 +243,37 @@ def test_filter_features_is_filter_domains():
     assert list(g.domain) == [d for d, k in zip(f.domain, keep) if k]
     h = predict.filter_features(f, 1e-30, None)
     assert len(h) == int((np.asarray(f.i_evalue) < 1e-30).sum())
+
+
+def test_columnar_predict_antismash_equals_object_path(oracle_model):
+    """`--postproc antismash` (cli/commands/_parser.py:294-301) through the columnar path -- markers found by the native
+    packer among ALL domains, criterion evaluated on the device -- against ClusterRefiner(criterion="antismash") on objects."""
+    import itertools
+
+    from gecco_amd import predict, refine, tables
+    from gecco_amd.crf import ClusterCRF
+
+    rng = np.random.default_rng(23)
+    bio = sorted(refine.BIO_PFAMS)
+    known = [a for a in oracle_model["attrs"][:60]]
+    names = known + bio[:40] + ["PF99999", "TIGR00001"]  # model attributes, marker domains (some unknown to the CRF), strangers
+    genes_t, feats_t = _random_tables(rng, 40, names, True)
+    crf = ClusterCRF.trained(GOLDEN)
+    kw = dict(threshold=0.3, n_cds=2, n_biopfams=2, average_threshold=0.45)
+    g_out, f_out, c_out = predict.predict_tables(genes_t, feats_t, crf, criterion="antismash", **kw)
+    by_pid = {g.protein.id: g for g in genes_t.to_genes()}
+    for g in feats_t.to_genes():
+        by_pid[g.protein.id].protein.domains.extend(g.protein.domains)
+    annotated = crf.predict_probabilities(list(by_pid.values()))
+    refiner = refine.ClusterRefiner(criterion="antismash", **kw)
+    clusters = []
+    for _, group in itertools.groupby(annotated, key=lambda g: g.source.id):
+        clusters.extend(refiner.iter_clusters(list(group)))
+    exp_t = tables.ClusterTable.from_clusters(clusters)
+    assert len(exp_t) >= 3
+    n_gecco = len(predict.predict_tables(genes_t, feats_t, crf, threshold=0.3, n_cds=2)[2])
+    assert n_gecco != len(exp_t)  # the criterion matters on this data
+    for name in ("sequence_id", "cluster_id", "start", "end", "average_p", "max_p", "proteins", "domains"):
+        assert list(c_out.columns[name]) == list(exp_t.columns[name]), name
+    with pytest.raises(ValueError, match="Unknown cluster filtering criterion"):
+        predict.predict_tables(genes_t, feats_t, crf, criterion="other")

@@ -232,3 +232,28 @@ def test_session_several_device_entries(nat, real_model, oracle_model):
     thr = _threshold(exp)
     seg = ses.clusters(cptr, gptr, attr, ann, 20, threshold=thr)[0]
     assert seg.tolist() == orc.segment(exp, ann, cptr, thr, 3, 0, True, carry_state=False).tolist()
+
+
+@pytest.mark.parametrize("chunk", [3000, 1 << 19])
+def test_session_clusters_antismash(nat, real_model, oracle_model, chunk):
+    """The batch driver with criterion "antismash": the genes' marker domains travel chunk by chunk with the CSR."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(16)
+    cptr, gptr, attr = _batch(oracle_model, 16)
+    n = int(cptr[-1])
+    ann = (np.diff(gptr) > 0).astype(np.uint8)
+    cnt = np.where(rng.random(n) < 0.4, rng.integers(1, 3, size=n), 0)
+    mptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    mid = rng.integers(0, 20, size=int(mptr[-1])).astype(np.int32)
+    p_exp = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, True)
+    thr = _threshold(p_exp)
+    exp = orc.segment_antismash(p_exp, ann, cptr, mptr, mid, thr, 3, 2, thr + 0.01, True)
+    assert len(exp) > 10
+    ses = nat.Session(real_model, [0])
+    ses.set_chunk_genes(chunk)
+    seg, seg_p, seg_off, _ = ses.clusters(cptr, gptr, attr, ann, 20, 1, 1, True, thr, 3, 0, True, criterion="antismash", n_biopfams=2,
+                                          average_threshold=thr + 0.01, marker_ptr=mptr, marker_id=mid)
+    assert seg.tolist() == exp.tolist()
+    with pytest.raises(Exception, match="marker"):
+        ses.clusters(cptr, gptr, attr, ann, 20, 1, 1, True, thr, 3, 0, True, criterion="antismash")

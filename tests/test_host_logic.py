@@ -330,6 +330,46 @@ def test_refiner_defaults_and_antismash():
         list(refine.ClusterRefiner(criterion="x").iter_clusters(genes))
 
 
+def test_oracle_antismash_segmenter_equals_object_refiner():
+    """oracle_segment_antismash (the checker of the device path) against ClusterRefiner(criterion="antismash") on
+    objects, the mirror of refine.py:118-200."""
+    import itertools
+
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(8)
+    markers = sorted(refine.BIO_PFAMS)
+    genes, p_all, ann, mptr, mid, cptr = [], [], [], [0], [], [0]
+    for c in range(25):
+        n = int(rng.integers(1, 90))
+        base = 0.9 if rng.random() < 0.5 else 0.4
+        for g in range(n):
+            names = [str(rng.choice(markers[:12])) if rng.random() < 0.5 else f"PF9{int(rng.integers(0, 30)):04d}"
+                     for _ in range(int(rng.integers(0, 4)))]
+            p = float(np.clip(rng.normal(base, 0.25), 0, 1))
+            doms = [Domain(nm, i, i + 1, "Pfam", 0.0, 0.0, p) for i, nm in enumerate(names)]
+            genes.append(Gene(Source(f"c{c:02d}"), 10 * g, 10 * g + 9, Strand.Coding, Protein(f"c{c:02d}_{g}", None, doms), _probability=p))
+            p_all.append(p)
+            ann.append(1 if doms else 0)
+            mid.extend(sorted({markers.index(nm) for nm in names if nm in refine.BIO_PFAMS}))
+            mptr.append(len(mid))
+        cptr.append(len(p_all))
+    total = 0
+    for kw in (dict(n_cds=5, n_biopfams=5, average_threshold=0.6), dict(n_cds=2, n_biopfams=2, average_threshold=0.85),
+               dict(n_cds=3, n_biopfams=1, average_threshold=0.5, trim=False), dict(n_cds=1, n_biopfams=0, average_threshold=0.0)):
+        ref = refine.ClusterRefiner(criterion="antismash", threshold=0.8, cluster_type=Cluster, **kw)
+        exp = []
+        for ci, (_, group) in enumerate(itertools.groupby(genes, key=lambda g: g.source.id)):
+            for cl in ref.iter_clusters(list(group)):
+                first = next(i for i in range(cptr[ci], cptr[ci + 1]) if genes[i] is cl.genes[0])
+                exp.append([ci, int(cl.id.rsplit("_", 1)[1]), first, first + len(cl.genes)])
+        got = orc.segment_antismash(p_all, ann, cptr, mptr, mid, 0.8, kw["n_cds"], kw["n_biopfams"], kw["average_threshold"],
+                                    kw.get("trim", True))
+        assert got.tolist() == exp
+        total += len(exp)
+    assert total > 10
+
+
 def test_cluster_average_is_exactly_rounded():
     ps = [float(r["average_p"]) for r in read_tsv(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))]
     c = Cluster("x", [_pgene("c", i, p) for i, p in enumerate(ps)])
@@ -416,8 +456,11 @@ def test_native_column_packer_equals_row_by_row_statement(monkeypatch, threads, 
             args += (sids, pids, starts)
             gargs = (S(sids), S(pids), np.array(starts, dtype=np.int64))
         a = packing.pack_columns_py(*args)
+        # every other table also asks for the genes' marker domains (antismash criterion): names the model knows
+        # ("a3") and names it does not ("unknown13")
+        markers = ["a3", "unknown13", "a0", "nowhere", "unknown14"] if trial % 2 else None
         b = nat.PackedTables(model, S(f_sid), S(f_pid), np.array(f_start, dtype=np.int64), S(f_dom),
-                             np.array(f_ds, dtype=np.int64), *gargs)
+                             np.array(f_ds, dtype=np.int64), *gargs, markers=S(markers) if markers else None)
         n = len(a[1])
         assert b.n_genes == n and b.n_contigs == len(a[0]), trial
         all_pid = (pids if trial % 3 else [])
@@ -430,6 +473,10 @@ def test_native_column_packer_equals_row_by_row_statement(monkeypatch, threads, 
             exp = sorted([r for r in range(nf) if f_pid[r] == names[k]], key=lambda r: f_ds[r])
             assert rows.tolist() == exp, trial
             assert all(b.row_gene[r] == k for r in exp), trial
+            if markers:  # distinct marker domains among ALL rows of the gene, in row order
+                exp_m = list(dict.fromkeys(markers.index(f_dom[r]) for r in exp if f_dom[r] in markers))
+                assert b.marker_id[b.marker_ptr[k]:b.marker_ptr[k + 1]].tolist() == exp_m, trial
+        assert (b.marker_ptr is None) == (markers is None)
         if trial % 3:
             assert b.n_duplicate_gene_ids == (1 if (trial % 7 == 0 and ng > 3) else 0), trial
             assert b.n_unlisted_proteins == (len({p for p in f_pid if p not in set(pids)}) if ng else 0), trial
