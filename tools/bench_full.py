@@ -30,6 +30,7 @@ def main():
         sc = torch.zeros(nc, dtype=torch.float64, device=dev)
         res = {"genes": n}
         for key, fn in (("marginals_full", lambda: plan.run_marginals_full(gp.data_ptr(), at.data_ptr(), marg.data_ptr(), ln.data_ptr())),
+                        ("marginals_full_without_log_z", lambda: plan.run_marginals_full(gp.data_ptr(), at.data_ptr(), marg.data_ptr())),
                         ("viterbi_with_scores", lambda: plan.run_viterbi(gp.data_ptr(), at.data_ptr(), y.data_ptr(), sc.data_ptr())),
                         ("viterbi_labels_only", lambda: plan.run_viterbi(gp.data_ptr(), at.data_ptr(), y.data_ptr()))):
             for _ in range(3):
