@@ -187,8 +187,11 @@ size_t segment_workspace_bytes(int n_genes, int n_contigs);
 hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t *d_flags, const int32_t *d_cptr,
                           int n_genes, int n_contigs, const SegParams &params, int32_t *d_seg, int max_seg,
                           int32_t *d_seg_off, int32_t *d_total, void *d_work, hipStream_t stream);
+// d_out (may be null): the probabilities of the rows' genes; x_*: copies of the rows, their offsets and their number
+// (null: none).  Inputs are read from device memory; the outputs may live in pinned host memory.
 hipError_t launch_segment_gather(const double *d_p, const int32_t *d_seg, const int32_t *d_seg_off, const int32_t *d_total,
-                                 int max_seg, double *d_out, int cap, hipStream_t stream);
+                                 int max_seg, double *d_out, int cap, hipStream_t stream, int32_t *x_seg = nullptr,
+                                 int32_t *x_off = nullptr, int32_t *x_total = nullptr);
 
 // ---- any number of labels (crf_general.hip) -------------------------------------------------
 constexpr int kGenMaxL = 32;  // labels: a group of next-pow2(L) lanes must fit in half a wave

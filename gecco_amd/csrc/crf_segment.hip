@@ -307,12 +307,24 @@ __global__ void __launch_bounds__(kT) seg_compact(const SegArgs A) {
     }
 }
 
-// probabilities of the genes of the kept rows, row after row (what cluster tables need of p)
+// Probabilities of the genes of the kept rows, row after row (what cluster tables need of p), plus -- when the export
+// pointers are given -- the rows, their offsets and their number themselves.  The batch driver points `out` and the
+// export arrays at pinned HOST memory: everything is read from device memory and only written across PCIe (posted
+// writes).  (With the segmenter writing its rows straight into host memory this kernel READ them back from there, three
+// dependent PCIe round trips per row: 62 us per 1 M-gene chunk against 22 us for the window kernel.)
 __global__ void __launch_bounds__(kT) seg_gather(const double *__restrict__ p, const int32_t *__restrict__ seg,
                                                  const int32_t *__restrict__ seg_off, const int32_t *__restrict__ total,
-                                                 int max_seg, double *__restrict__ out, int cap) {
-    const int n = min(*total, max_seg);
+                                                 int max_seg, double *__restrict__ out, int cap, int32_t *__restrict__ x_seg,
+                                                 int32_t *__restrict__ x_off, int32_t *__restrict__ x_total) {
+    const int n_all = *total, n = min(n_all, max_seg);
     const int lane = threadIdx.x & 63, wave = (blockIdx.x * kT + threadIdx.x) >> 6, nwaves = (gridDim.x * kT) >> 6;
+    if (x_total) {
+        const int t = blockIdx.x * kT + threadIdx.x, nt = gridDim.x * kT;
+        if (t == 0) *x_total = n_all;
+        for (int i = t; i < 4 * n; i += nt) x_seg[i] = seg[i];
+        for (int i = t; i <= n; i += nt) x_off[i] = seg_off[i];
+    }
+    if (!out) return;
     for (int r = wave; r < n; r += nwaves) {
         const int a = seg[4 * r + 2], b = seg[4 * r + 3], off = seg_off[r];
         for (int k = lane; k < b - a; k += 64)
@@ -401,8 +413,10 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
 }
 
 hipError_t launch_segment_gather(const double *d_p, const int32_t *d_seg, const int32_t *d_seg_off, const int32_t *d_total,
-                                 int max_seg, double *d_out, int cap, hipStream_t stream) {
-    hipLaunchKernelGGL(seg_gather, dim3(64), dim3(kT), 0, stream, d_p, d_seg, d_seg_off, d_total, max_seg, d_out, cap);
+                                 int max_seg, double *d_out, int cap, hipStream_t stream, int32_t *x_seg, int32_t *x_off,
+                                 int32_t *x_total) {
+    hipLaunchKernelGGL(seg_gather, dim3(64), dim3(kT), 0, stream, d_p, d_seg, d_seg_off, d_total, max_seg, d_out, cap, x_seg, x_off,
+                       x_total);
     return hipGetLastError();
 }
 

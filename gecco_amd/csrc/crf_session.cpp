@@ -102,7 +102,7 @@ struct Lane {
     hipEvent_t ev_up = nullptr, ev_comp = nullptr, done = nullptr;
     int chunk = -1;  // index of the chunk in flight, -1: idle
     Plan plan;
-    DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi;
+    DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg;
     HostBuf h_seg;  // [total][pad..][seg_off: cap+1][rows: cap*4][p of the rows: n_genes]
     int32_t seg_cap = 0;
     size_t o_off = 0, o_rows = 0, o_p = 0;
@@ -135,7 +135,7 @@ Session::~Session() {
         if (hipSetDevice(d->device) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
         for (Lane &ln : d->lanes) {
-            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi}) b->release();
+            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi, &ln.d_seg}) b->release();
             ln.h_seg.release();
             for (hipEvent_t e : {ln.ev_up, ln.ev_comp, ln.done})
                 if (e) (void)hipEventDestroy(e);
@@ -409,6 +409,12 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
         ln.o_p = ln.o_rows + align256(cap * 16);
         const size_t bytes = ln.o_p + (r.seg_p_out ? size_t(ng) * 8 : 0) + 256;
         if ((rc = ln.h_seg.reserve(bytes, "hipHostMalloc segments"))) return rc;
+        // the segmenter works in device memory; one last kernel exports rows, offsets, count and the rows'
+        // probabilities into the pinned block (written across PCIe, never read back across it)
+        const size_t v_off = 256, v_rows = v_off + align256((cap + 1) * 4);
+        if ((rc = ln.d_seg.reserve(v_rows + align256(cap * 16), "hipMalloc segments"))) return rc;
+        int32_t *v_total = reinterpret_cast<int32_t *>(ln.d_seg.p), *v_offp = reinterpret_cast<int32_t *>(ln.d_seg.p + v_off),
+                *v_rowsp = reinterpret_cast<int32_t *>(ln.d_seg.p + v_rows);
         char *dp = ln.h_seg.dp;
         int32_t *d_total = reinterpret_cast<int32_t *>(dp), *d_off = reinterpret_cast<int32_t *>(dp + ln.o_off),
                 *d_rows = reinterpret_cast<int32_t *>(dp + ln.o_rows);
@@ -419,12 +425,12 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
             sp.bio_ptr = reinterpret_cast<const int32_t *>(ln.d_bp.p);
             sp.bio_id = reinterpret_cast<const int32_t *>(ln.d_bi.p) - b0;
         }
-        if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(ln.d_ann.p), sp, d_rows, int32_t(cap), d_off, d_total,
+        if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(ln.d_ann.p), sp, v_rowsp, int32_t(cap), v_offp, v_total,
                                    ln.comp)))
             return rc;
-        if (r.seg_p_out &&
-            (rc = check_hip(launch_segment_gather(d_p, d_rows, d_off, d_total, int32_t(cap), reinterpret_cast<double *>(dp + ln.o_p), ng,
-                                                  ln.comp), "segment gather launch")))
+        if ((rc = check_hip(launch_segment_gather(d_p, v_rowsp, v_offp, v_total, int32_t(cap),
+                                                  r.seg_p_out ? reinterpret_cast<double *>(dp + ln.o_p) : nullptr, ng, ln.comp, d_rows,
+                                                  d_off, d_total), "segment gather launch")))
             return rc;
     }
     tm.lap("launch", chunk_index);
