@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 SIMDS = 256 * 4         # 256 CUs x 4 SIMDs
 SCLK_HZ = 2.4e9         # peak engine clock; an fp64 / DPP / 32-bit VALU instruction occupies a SIMD for 4 cycles per wave
+VALU_SUSTAINED_CYCLES = 4.7  # ... nominally; measured on MI355X under sustained fp64 load: 4.6-4.8 (tools/ubench/valu_rates.hip)
 W, STEP, LABEL = 20, 1, 1
 
 
@@ -228,6 +229,10 @@ def main() -> None:
             # SQ_INSTS_VALU, same profile) x 4 cycles each / (kernel time x 1024 SIMDs x 2.4 GHz)
             "valu_frac": valu_frac,
             "valu_insts_per_launch": valu_insts,
+            # the same against the issue rate this GPU SUSTAINS on fp64 (tools/ubench/valu_rates.hip, four waves per
+            # SIMD of independent chains: 4.6-4.8 "2.4 GHz cycles" per wave instruction for v_add/v_mul/v_fma_f64 and the
+            # DPP moves, i.e. ~2.05 GHz effective under this load) instead of the nominal 4 cycles at 2.4 GHz
+            "valu_frac_at_sustained_rate": (valu_frac * VALU_SUSTAINED_CYCLES / 4.0) if valu_frac else None,
             "ratio_form_fallback_frac": _ratio_form_fallback_fraction(wl, res.plan.num_tiles, 2 * (256 - (W - 1)))
             if args.workload != "Cinf" else None,
         },
