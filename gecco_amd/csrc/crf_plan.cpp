@@ -667,8 +667,10 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
             ne.push_back(c);
         }
     }
+    const size_t n_lane_bits = size_t(p.n_cblocks) * 256;  // short contigs: per lane of every workgroup, which of its 8 genes start / end a contig
     const size_t o_flags = 0, o_blk = align256p(n + 8), o_rank = o_blk + align256p((cblk.size() + 1) * 4),
-                 o_ne = o_rank + align256p((rank.size() + 1) * 4), bytes = o_ne + align256p((ne.size() + 1) * 4);
+                 o_ne = o_rank + align256p((rank.size() + 1) * 4), o_lb = o_ne + align256p((ne.size() + 1) * 4),
+                 bytes = o_lb + align256p(n_lane_bits * 2 + 2);
     if ((rc = p.seq.reserve(bytes, "contig flags"))) return rc;
     uint8_t *flags = reinterpret_cast<uint8_t *>(p.seq.h + o_flags);
     std::memset(flags, 0, n + 8);
@@ -679,6 +681,20 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
             flags[g1 - 1] |= 2;
         }
     }
+    if (n_lane_bits) {
+        // bit k of the low byte: gene k of the lane is the first of its contig; of the high byte: the last
+        uint16_t *lb = reinterpret_cast<uint16_t *>(p.seq.h + o_lb);
+        std::memset(lb, 0, n_lane_bits * 2);
+        size_t b = 0;
+        for (int32_t c = 0; c < p.n_contigs; ++c) {
+            const int32_t g0 = p.contig_ptr[c], g1 = p.contig_ptr[c + 1];
+            if (g1 <= g0) continue;
+            while (cblk[b + 1] <= g0) ++b;  // the workgroup that holds the (whole) contig
+            const int32_t l0 = g0 - cblk[b], l1 = g1 - 1 - cblk[b];
+            lb[b * 256 + size_t(l0 / kSeqGenesPerLane)] |= uint16_t(1u << (l0 % kSeqGenesPerLane));
+            lb[b * 256 + size_t(l1 / kSeqGenesPerLane)] |= uint16_t(0x100u << (l1 % kSeqGenesPerLane));
+        }
+    }
     if (!cblk.empty()) std::memcpy(p.seq.h + o_blk, cblk.data(), cblk.size() * 4);
     if (!rank.empty()) std::memcpy(p.seq.h + o_rank, rank.data(), rank.size() * 4);
     if (!ne.empty()) std::memcpy(p.seq.h + o_ne, ne.data(), ne.size() * 4);
@@ -686,6 +702,7 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
     p.d_seq_cblk = reinterpret_cast<int32_t *>(p.seq.d + o_blk);
     p.d_seq_cblk_rank = reinterpret_cast<int32_t *>(p.seq.d + o_rank);
     p.d_seq_ne_contig = reinterpret_cast<int32_t *>(p.seq.d + o_ne);
+    p.d_seq_lane_bits = reinterpret_cast<const uint16_t *>(p.seq.d + o_lb);
     // launches that read the tables must be ordered behind this copy: `sync` (any stream may follow), or the
     // caller keeps to `stream` (the batch driver)
     if ((rc = check_hip(hipMemcpyAsync(p.seq.d, p.seq.h, bytes, hipMemcpyHostToDevice, stream), "upload contig flags"))) return rc;
@@ -729,6 +746,7 @@ int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
     a.fLaneSuf = reinterpret_cast<FE *>(w + l.off_flanesuf);
     a.fBlockSuf = reinterpret_cast<FE *>(w + l.off_fblocksuf);
     a.flags = p.d_seq_flags;
+    a.lane_bits = p.d_seq_lane_bits;
     a.cblk = p.d_seq_cblk;
     a.n_cblocks = p.n_cblocks;
     a.cblk_rank = p.d_seq_cblk_rank;

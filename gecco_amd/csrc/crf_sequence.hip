@@ -568,19 +568,16 @@ __global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
 // recomputation, labels in a second launch over three intermediate arrays -- took 12.5 + 5.0 us on C3.)
 struct ShortStage {
     double st[kT * (kGPL + 1)];
-    uint8_t fl[kT * kGPL];
     uint8_t yb[kT * kGPL];
 };
 // genes [g0, g0 + n) of the workgroup -> the lanes that own 8 consecutive ones; coalesced global accesses
 // (lane i takes entries i, i + 256, ...), padded LDS rows
-__device__ __forceinline__ void load_short(const double *__restrict__ v, const uint8_t *__restrict__ flags, int g0, int n,
-                                           ShortStage &stg) {
+__device__ __forceinline__ void load_short(const double *__restrict__ v, int g0, int n, ShortStage &stg) {
     const int slot = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < kGPL; ++j) {
         const int idx = j * kT + slot;
         stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = idx < n ? v[g0 + idx] : 0.0;
-        stg.fl[idx] = idx < n ? flags[g0 + idx] : uint8_t(0);
     }
     __syncthreads();
 }
@@ -591,21 +588,22 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
     __shared__ ShortStage stg;
     const int slot = threadIdx.x;
     const int g0 = A.cblk[blockIdx.x], n = A.cblk[blockIdx.x + 1] - g0;
-    load_short(A.dstate, A.flags, g0, n, stg);
+    // which of the lane's genes start / end a contig: two bytes the host packed per lane (the per-gene flag bytes
+    // took eight loads, an LDS round trip and 48 VALU instructions to unpack)
+    const uint32_t bits = A.lane_bits[blockIdx.x * kT + slot];
+    const uint32_t first = bits & 0xffu, last = bits >> 8;
+    load_short(A.dstate, g0, n, stg);
     const int cnt = min(kGPL, n - slot * kGPL);
-    const uint64_t wf = *reinterpret_cast<const uint64_t *>(stg.fl + slot * kGPL);
     double dv[kGPL];
-    uint32_t first = 0, last = 0;
     CE P = COp::identity();
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
         dv[k] = stg.st[slot * (kGPL + 1) + k];
-        const uint32_t f = uint32_t(wf >> (8 * k)) & 0xffu;
-        first |= (f & 1u) << k;
-        last |= ((f >> 1) & 1u) << k;
         if (k < cnt) {
+            // a contig's first gene is the constant map L = H = d (its `a` is never used again: a constant map stays one)
+            const bool fst = (first >> k) & 1u;
             const double c = A.v_k + dv[k];
-            const CE e = (f & 1u) ? CE{0.0, dv[k], dv[k]} : CE{c, A.v_lo + c, A.v_hi + c};
+            const CE e{c, fst ? dv[k] : A.v_lo + c, fst ? dv[k] : A.v_hi + c};
             P = COp::combine(P, e);
         }
     }
@@ -628,10 +626,11 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
         for (int k = 0; k < kGPL; ++k) {
             if (k < cnt) {
                 Dq = ((first >> k) & 1u) ? dv[k] : fmin(fmax(Dq, A.v_lo), A.v_hi) + (A.v_k + dv[k]);
+                // a contig's last gene decides the end label: both of its "thresholds" are 0 (maps 3 / 0)
                 const bool lst = (last >> k) & 1u;
-                const uint32_t m = lst ? (Dq > 0.0 ? 3u : 0u) : ((Dq > A.v_hi ? 1u : 0u) | (Dq > A.v_lo ? 2u : 0u));
-                maps |= m << (2 * k);
-                sensitive |= lst ? fabs(Dq) <= margin : (fabs(Dq - A.v_hi) <= margin || fabs(Dq - A.v_lo) <= margin);
+                const double thi = lst ? 0.0 : A.v_hi, tlo = lst ? 0.0 : A.v_lo;
+                maps |= ((Dq > thi ? 1u : 0u) | (Dq > tlo ? 2u : 0u)) << (2 * k);
+                sensitive |= fabs(Dq - thi) <= margin || fabs(Dq - tlo) <= margin;
             }
         }
     }
@@ -665,7 +664,7 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
             int p = t0 - 1;
             auto dval = [&](int t) { return stg.st[(t / kGPL) * (kGPL + 1) + t % kGPL]; };
             for (;; --p) {
-                if (stg.fl[p] & 1u) {
+                if (A.flags[g0 + p] & 1u) {
                     D = dval(p);
                     break;
                 }
@@ -682,8 +681,8 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
         for (int k = 0; k < kGPL; ++k) {
             if (k < cnt) {
                 D = ((first >> k) & 1u) ? dv[k] : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dv[k]);
-                const uint32_t m = ((last >> k) & 1u) ? (D > 0.0 ? 3u : 0u) : ((D > A.v_hi ? 1u : 0u) | (D > A.v_lo ? 2u : 0u));
-                maps |= m << (2 * k);
+                const bool lst = (last >> k) & 1u;
+                maps |= ((D > (lst ? 0.0 : A.v_hi) ? 1u : 0u) | (D > (lst ? 0.0 : A.v_lo) ? 2u : 0u)) << (2 * k);
             }
         }
     }
@@ -896,10 +895,7 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
             make_double2(ok ? A.dstate[g0 + idx] : 0.0, (ok && want_z) ? A.smax[g0 + idx] : 0.0);
     }
     const int cnt = min(kGPL, n - slot * kGPL);
-    uint64_t wf = 0;
-#pragma unroll
-    for (int k = 0; k < kGPL; ++k)
-        if (k < cnt) wf |= uint64_t(A.flags[g0 + slot * kGPL + k]) << (8 * k);
+    const uint32_t bits = A.lane_bits[blockIdx.x * kT + slot];  // which of the lane's genes start / end a contig (host-packed)
     __syncthreads();
     // the emission pair of every gene the lane touches (its own 8 and its right neighbour's first): ONE exp per gene,
     // used by the forward fold, the forward replay, the backward fold and the backward replay
@@ -912,7 +908,7 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
         mx[k] = v.y;
     }
     E[kGPL] = emit_d(A, slot + 1 < kT ? stg.st[(slot + 1) * (kGPL + 1)].x : 0.0);
-    uint32_t first = 0, last = 0;
+    const uint32_t first = bits & 0xffu, last = bits >> 8;
     auto step = [&](double2 e, double m, bool fst) {
         if constexpr (WANT_Z) {
             return f_step_e(A, e, m, fst);
@@ -922,12 +918,8 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     };
     E_t P = OpF::identity();
 #pragma unroll
-    for (int k = 0; k < kGPL; ++k) {
-        const uint32_t f = uint32_t(wf >> (8 * k)) & 0xffu;
-        first |= (f & 1u) << k;
-        last |= ((f >> 1) & 1u) << k;
-        if (k < cnt) P = OpF::combine(P, step(E[k], mx[k], f & 1u));
-    }
+    for (int k = 0; k < kGPL; ++k)
+        if (k < cnt) P = OpF::combine(P, step(E[k], mx[k], (first >> k) & 1u));
     E_t total;
     const E_t M = block_scan_exclusive<OpF, false>(P, lds, &total);
     // contig ends before this lane (workgroup-wide count): which contig a log Z belongs to
