@@ -694,6 +694,15 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
             lb[b * 256 + size_t(l0 / kSeqGenesPerLane)] |= uint16_t(1u << (l0 % kSeqGenesPerLane));
             lb[b * 256 + size_t(l1 / kSeqGenesPerLane)] |= uint16_t(0x100u << (l1 % kSeqGenesPerLane));
         }
+        // positions past a workgroup's last gene: one-gene contigs (the kernels give them a score difference that decides
+        // nothing), so that the hot loops run over all 8 positions of every lane without testing
+        for (int32_t blk = 0; blk < p.n_cblocks; ++blk) {
+            const int32_t nb = cblk[size_t(blk) + 1] - cblk[size_t(blk)];
+            int32_t l = nb;
+            for (; l < kSeqBlockGenes && l % kSeqGenesPerLane; ++l)
+                lb[size_t(blk) * 256 + size_t(l / kSeqGenesPerLane)] |= uint16_t(0x101u << (l % kSeqGenesPerLane));
+            for (; l < kSeqBlockGenes; l += kSeqGenesPerLane) lb[size_t(blk) * 256 + size_t(l / kSeqGenesPerLane)] = 0xffff;
+        }
     }
     if (!cblk.empty()) std::memcpy(p.seq.h + o_blk, cblk.data(), cblk.size() * 4);
     if (!rank.empty()) std::memcpy(p.seq.h + o_rank, rank.data(), rank.size() * 4);

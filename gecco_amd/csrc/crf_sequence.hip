@@ -572,12 +572,16 @@ struct ShortStage {
 };
 // genes [g0, g0 + n) of the workgroup -> the lanes that own 8 consecutive ones; coalesced global accesses
 // (lane i takes entries i, i + 256, ...), padded LDS rows
+// Positions of a workgroup past its last gene behave as one-gene contigs with a score difference far from every
+// threshold (the host sets their start / end bits in `lane_bits`): they decide nothing, perturb nothing that comes before
+// them, and the hot loops need no "is this gene there" test.
+constexpr double kVdPad = 1e30;
 __device__ __forceinline__ void load_short(const double *__restrict__ v, int g0, int n, ShortStage &stg) {
     const int slot = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < kGPL; ++j) {
         const int idx = j * kT + slot;
-        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = idx < n ? v[g0 + idx] : 0.0;
+        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = idx < n ? v[g0 + idx] : kVdPad;
     }
     __syncthreads();
 }
@@ -599,13 +603,11 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
         dv[k] = stg.st[slot * (kGPL + 1) + k];
-        if (k < cnt) {
-            // a contig's first gene is the constant map L = H = d (its `a` is never used again: a constant map stays one)
-            const bool fst = (first >> k) & 1u;
-            const double c = A.v_k + dv[k];
-            const CE e{c, fst ? dv[k] : A.v_lo + c, fst ? dv[k] : A.v_hi + c};
-            P = COp::combine(P, e);
-        }
+        // a contig's first gene is the constant map L = H = d (its `a` is never used again: a constant map stays one)
+        const bool fst = (first >> k) & 1u;
+        const double c = A.v_k + dv[k];
+        const CE e{c, fst ? dv[k] : A.v_lo + c, fst ? dv[k] : A.v_hi + c};
+        P = COp::combine(P, e);
     }
     CE total;
     const CE M = block_scan_exclusive<COp, false>(P, lds, &total);  // the workgroup starts at a contig start
@@ -624,14 +626,12 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
         double Dq = M.L;
 #pragma unroll
         for (int k = 0; k < kGPL; ++k) {
-            if (k < cnt) {
-                Dq = ((first >> k) & 1u) ? dv[k] : fmin(fmax(Dq, A.v_lo), A.v_hi) + (A.v_k + dv[k]);
-                // a contig's last gene decides the end label: both of its "thresholds" are 0 (maps 3 / 0)
-                const bool lst = (last >> k) & 1u;
-                const double thi = lst ? 0.0 : A.v_hi, tlo = lst ? 0.0 : A.v_lo;
-                maps |= ((Dq > thi ? 1u : 0u) | (Dq > tlo ? 2u : 0u)) << (2 * k);
-                sensitive |= fabs(Dq - thi) <= margin || fabs(Dq - tlo) <= margin;
-            }
+            Dq = ((first >> k) & 1u) ? dv[k] : fmin(fmax(Dq, A.v_lo), A.v_hi) + (A.v_k + dv[k]);
+            // a contig's last gene decides the end label: both of its "thresholds" are 0 (maps 3 / 0)
+            const bool lst = (last >> k) & 1u;
+            const double thi = lst ? 0.0 : A.v_hi, tlo = lst ? 0.0 : A.v_lo;
+            maps |= ((Dq > thi ? 1u : 0u) | (Dq > tlo ? 2u : 0u)) << (2 * k);
+            sensitive |= fabs(Dq - thi) <= margin || fabs(Dq - tlo) <= margin;
         }
     }
     // (one barrier either way: the workgroup learns whether any of its lanes has to look back)
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
     __syncthreads();  // the marks in stg.yb have been read: the label bytes go there below
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k)
-        if (k < cnt) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
+        lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
     // back-to-front scan of the lane maps, then the labels: the workgroup ends at a contig end,
     // so the map entering from its right is irrelevant (the last gene's map is constant)
     uint32_t mtotal;
@@ -697,10 +697,8 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
     uint64_t packed = 0;
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) {
-        if (k < cnt) {
-            lab = (maps >> (2 * k + lab)) & 1u;
-            packed |= uint64_t(lab) << (8 * k);
-        }
+        lab = (maps >> (2 * k + lab)) & 1u;
+        packed |= uint64_t(lab) << (8 * k);
     }
     *reinterpret_cast<uint64_t *>(stg.yb + slot * kGPL) = packed;
     __syncthreads();
