@@ -917,7 +917,7 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     E_t P = OpF::identity();
 #pragma unroll
     for (int k = 0; k < kGPL; ++k)
-        if (k < cnt) P = OpF::combine(P, step(E[k], mx[k], (first >> k) & 1u));
+        P = OpF::combine(P, step(E[k], mx[k], (first >> k) & 1u));  // (positions past the last gene: one-gene contigs, d = 0)
     E_t total;
     const E_t M = block_scan_exclusive<OpF, false>(P, lds, &total);
     // contig ends before this lane (workgroup-wide count): which contig a log Z belongs to
@@ -937,8 +937,7 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     double2 al[kGPL];
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
-        al[k] = make_double2(0.0, 0.0);
-        if (k < cnt) {
+        {
             double n0, n1;
             if ((first >> k) & 1u) {
                 n0 = n1 = 1.0;
@@ -958,7 +957,7 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
             ms += mx[k];
             al[k] = make_double2(a0, a1);
             const bool lst = (last >> k) & 1u;
-            if (lst && want_z) {
+            if (lst && want_z && k < cnt) {
                 // log Z = log Z' (max-normalised emissions and transitions) + the emission maxima + (n - 1) max(trans)
                 const int c = A.ne_contig[A.cblk_rank[blockIdx.x] + int(ends_before) + __builtin_popcount(last & ((1u << k) - 1u))];
                 const int len = A.contig_ptr[c + 1] - A.contig_ptr[c];
@@ -987,8 +986,8 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     double b0 = S.a00 + S.a01, b1 = S.a10 + S.a11;
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) {
-        double2 o = make_double2(0.0, 0.0);
-        if (k < cnt) {
+        double2 o;
+        {
             if ((last >> k) & 1u) {
                 b0 = b1 = 1.0;
             } else {
