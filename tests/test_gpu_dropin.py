@@ -111,6 +111,28 @@ def test_columnar_predict_cli_reproduces_golden_tables(tmp_path):
     assert set(a["domains"].split(";")) == set(b["domains"].split(";"))
 
 
+def test_columnar_predict_cli_postproc_antismash(tmp_path):
+    """`--postproc antismash` on the fixture: the cluster is kept or dropped exactly as ClusterRefiner(criterion=
+    "antismash", n_cds=3) decides on the fixture's objects (refine.py:157-163 with the CLI's defaults)."""
+    from gecco_amd import predict, refine, tables
+
+    rc = predict.main(["--genes", os.path.join(GOLDEN, "BGC0001866.genes.tsv"),
+                       "--features", os.path.join(GOLDEN, "BGC0001866.features.tsv"),
+                       "--model", GOLDEN, "--postproc", "antismash", "-o", str(tmp_path)])
+    assert rc == 0
+    got = read_tsv(str(tmp_path / "BGC0001866.clusters.tsv")) if os.path.exists(tmp_path / "BGC0001866.clusters.tsv") else []
+    feats = tables.FeatureTable.load(os.path.join(GOLDEN, "BGC0001866.features.tsv"))
+    genes_t = tables.GeneTable.load(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))
+    by_pid = {g.protein.id: g for g in genes_t.to_genes()}
+    for g in feats.to_genes():
+        by_pid[g.protein.id].protein.domains.extend(g.protein.domains)
+    exp = list(refine.ClusterRefiner(criterion="antismash", n_cds=3).iter_clusters(list(by_pid.values())))
+    n_markers = len({d.name for g in by_pid.values() for d in g.protein.domains} & refine.BIO_PFAMS)
+    assert len(got) == len(exp) == (1 if n_markers >= 5 else 0)
+    if exp:
+        assert got[0]["cluster_id"] == exp[0].id and len(got[0]["proteins"].split(";")) == len(exp[0].genes)
+
+
 def test_multi_device_sharding_code_path(oracle_model):
     """ClusterCRF.devices with more than one entry shards launches over a thread pool; exercised
     here with the same physical device twice."""
