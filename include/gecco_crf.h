@@ -118,7 +118,8 @@ int gecco_crf_segment(int32_t device, const double *p, const uint8_t *annotated,
  * probability of the member genes >= average_threshold, distinct marker domains among ALL their domains >=
  * n_biopfams, member genes >= n_cds).  The marker domains (the reference's BIO_PFAMS list, refine.py:19-27) come
  * as a CSR over the batch's genes: marker_ptr[n_genes+1], marker_id[...] in [0, 256) = index of the domain in the
- * caller's marker list; only read when criterion == 1.  (The mean is the left-to-right sum over the count;
+ * caller's marker list; only read when criterion == 1 (gecco_crf_segment_ex wants marker_ptr[0] == 0; the batch driver and
+ * the plan take any non-decreasing offsets, like gene_ptr).  (The mean is the left-to-right sum over the count;
  * numpy.mean's own last bit depends on the SIMD width numpy dispatches to, so the reference does not pin it.) */
 typedef struct {
     double threshold;         /* 0.8 */
