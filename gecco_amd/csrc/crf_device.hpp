@@ -103,6 +103,7 @@ struct SeqArgs {
     const double2 *state;    // [n_genes]  (s[label 0], s[label 1])
     const double *dstate;    // [n_genes]  s[1] - s[0]: all the difference-form Viterbi needs (8 B/gene)
     const uint8_t *flags;    // [n_genes]  bit0: first gene of a contig, bit1: last gene
+    const uint16_t *flat_bits;  // [ceil(n_genes / 2048) * 256] the same for the flat layout (lane l owns genes 8 l .. 8 l + 7)
     const uint16_t *lane_bits;  // [n_cblocks * 256] short contigs: low byte = which of the lane's 8 genes start a contig, high byte = end one
     const int32_t *cblk;     // [n_cblocks+1] short contigs only: first gene of every workgroup of WHOLE contigs (<= kSeqBlockGenes genes)
     const int32_t *cblk_rank;   // [n_cblocks] non-empty contigs before the workgroup's first

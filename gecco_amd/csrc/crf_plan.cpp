@@ -670,7 +670,8 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
     const size_t n_lane_bits = size_t(p.n_cblocks) * 256;  // short contigs: per lane of every workgroup, which of its 8 genes start / end a contig
     const size_t o_flags = 0, o_blk = align256p(n + 8), o_rank = o_blk + align256p((cblk.size() + 1) * 4),
                  o_ne = o_rank + align256p((rank.size() + 1) * 4), o_lb = o_ne + align256p((ne.size() + 1) * 4),
-                 bytes = o_lb + align256p(n_lane_bits * 2 + 2);
+                 o_fb = o_lb + align256p(n_lane_bits * 2 + 2), n_flat_bits = ((n + kSeqBlockGenes - 1) / kSeqBlockGenes) * 256,
+                 bytes = o_fb + align256p(n_flat_bits * 2 + 2);
     if ((rc = p.seq.reserve(bytes, "contig flags"))) return rc;
     uint8_t *flags = reinterpret_cast<uint8_t *>(p.seq.h + o_flags);
     std::memset(flags, 0, n + 8);
@@ -680,6 +681,21 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
             flags[g0] |= 1;
             flags[g1 - 1] |= 2;
         }
+    }
+    if (n_flat_bits) {
+        // the flat layout (long contigs): lane l of the batch owns genes 8 l .. 8 l + 7
+        uint16_t *fb = reinterpret_cast<uint16_t *>(p.seq.h + o_fb);
+        std::memset(fb, 0, n_flat_bits * 2);
+        for (int32_t c = 0; c < p.n_contigs; ++c) {
+            const int32_t g0 = p.contig_ptr[c], g1 = p.contig_ptr[c + 1];
+            if (g1 <= g0) continue;
+            fb[size_t(g0 / kSeqGenesPerLane)] |= uint16_t(1u << (g0 % kSeqGenesPerLane));
+            fb[size_t((g1 - 1) / kSeqGenesPerLane)] |= uint16_t(0x100u << ((g1 - 1) % kSeqGenesPerLane));
+        }
+        size_t l = n;  // positions past the last gene: one-gene contigs
+        for (; l < n_flat_bits * kSeqGenesPerLane && l % kSeqGenesPerLane; ++l)
+            fb[l / kSeqGenesPerLane] |= uint16_t(0x101u << (l % kSeqGenesPerLane));
+        for (; l < n_flat_bits * kSeqGenesPerLane; l += kSeqGenesPerLane) fb[l / kSeqGenesPerLane] = 0xffff;
     }
     if (n_lane_bits) {
         // bit k of the low byte: gene k of the lane is the first of its contig; of the high byte: the last
@@ -712,6 +728,7 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
     p.d_seq_cblk_rank = reinterpret_cast<int32_t *>(p.seq.d + o_rank);
     p.d_seq_ne_contig = reinterpret_cast<int32_t *>(p.seq.d + o_ne);
     p.d_seq_lane_bits = reinterpret_cast<const uint16_t *>(p.seq.d + o_lb);
+    p.d_seq_flat_bits = reinterpret_cast<const uint16_t *>(p.seq.d + o_fb);
     // launches that read the tables must be ordered behind this copy: `sync` (any stream may follow), or the
     // caller keeps to `stream` (the batch driver)
     if ((rc = check_hip(hipMemcpyAsync(p.seq.d, p.seq.h, bytes, hipMemcpyHostToDevice, stream), "upload contig flags"))) return rc;
@@ -756,6 +773,7 @@ int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
     a.fBlockSuf = reinterpret_cast<FE *>(w + l.off_fblocksuf);
     a.flags = p.d_seq_flags;
     a.lane_bits = p.d_seq_lane_bits;
+    a.flat_bits = p.d_seq_flat_bits;
     a.cblk = p.d_seq_cblk;
     a.n_cblocks = p.n_cblocks;
     a.cblk_rank = p.d_seq_cblk_rank;

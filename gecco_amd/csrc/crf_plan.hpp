@@ -64,6 +64,7 @@ struct Plan {
     Arena seq;
     bool seq_ready = false;
     uint8_t *d_seq_flags = nullptr;
+    const uint16_t *d_seq_flat_bits = nullptr;  // [ceil(n / 2048) * 256] the same bits for the flat layout (lane l owns genes 8 l ..)
     const uint16_t *d_seq_lane_bits = nullptr;  // [n_cblocks * 256] contig start / end bits of the 8 genes of every lane (short contigs)
     int32_t *d_seq_cblk = nullptr;    // short contigs: first gene of every workgroup of whole contigs (<= 2048 genes), [n_cblocks+1]
     int32_t n_cblocks = 0;

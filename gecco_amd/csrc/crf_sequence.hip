@@ -465,9 +465,12 @@ __global__ void __launch_bounds__(kT) v_labels(const SeqArgs A) {
 }
 
 // ---- difference form: fold / replay on 8-byte inputs ------------------------------------------
+// Positions of a workgroup past its last gene behave as one-gene contigs with a score difference far from every
+// threshold (the host sets their start / end bits in `lane_bits`): they decide nothing, perturb nothing that comes before
+// them, and the hot loops need no "is this gene there" test.
+constexpr double kVdPad = 1e30;
 struct LaneStageD {
     double st[kT * (kGPL + 1)];
-    uint8_t fl[kT * kGPL];
 };
 struct LaneGenesD {
     double d[kGPL];
@@ -476,35 +479,22 @@ struct LaneGenesD {
 };
 __device__ __forceinline__ LaneGenesD load_lane_d(const SeqArgs &A, int slot, LaneStageD &stg) {
     const int base = blockIdx.x * kT * kGPL;
+    // which of the lane's genes start / end a contig: two bytes per lane, packed by the host (positions past the last
+    // gene of the batch count as one-gene contigs)
+    const uint32_t bits = A.flat_bits[blockIdx.x * kT + slot];
 #pragma unroll
     for (int j = 0; j < kGPL; ++j) {  // coalesced 8-B loads, transposed through padded LDS rows
         const int idx = j * kT + slot, g = base + idx;
-        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = g < A.n_genes ? A.dstate[g] : 0.0;
-    }
-    {
-        const int g0 = base + slot * kGPL;
-        uint64_t w = 0;
-        if (g0 + kGPL <= A.n_genes) {
-            w = *reinterpret_cast<const uint64_t *>(A.flags + g0);
-        } else {
-            for (int k = 0; k < kGPL; ++k)
-                if (g0 + k < A.n_genes) w |= uint64_t(A.flags[g0 + k]) << (8 * k);
-        }
-        *reinterpret_cast<uint64_t *>(stg.fl + slot * kGPL) = w;
+        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = g < A.n_genes ? A.dstate[g] : kVdPad;
     }
     __syncthreads();
     LaneGenesD L;
     L.g0 = base + slot * kGPL;
     L.cnt = min(kGPL, A.n_genes - L.g0);
-    L.first = L.last = 0;
-    const uint64_t w = *reinterpret_cast<const uint64_t *>(stg.fl + slot * kGPL);
+    L.first = bits & 0xffu;
+    L.last = bits >> 8;
 #pragma unroll
-    for (int k = 0; k < kGPL; ++k) {
-        L.d[k] = stg.st[slot * (kGPL + 1) + k];
-        const uint32_t f = uint32_t(w >> (8 * k)) & 0xffu;
-        L.first |= (f & 1u) << k;
-        L.last |= ((f >> 1) & 1u) << k;
-    }
+    for (int k = 0; k < kGPL; ++k) L.d[k] = stg.st[slot * (kGPL + 1) + k];
     __syncthreads();
     return L;
 }
@@ -516,11 +506,10 @@ __global__ void __launch_bounds__(kT) vd_fold(const SeqArgs A) {
     CE P = COp::identity();
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
-        if (k < L.cnt) {
-            const double c = A.v_k + L.d[k];
-            const CE e = ((L.first >> k) & 1u) ? CE{0.0, L.d[k], L.d[k]} : CE{c, A.v_lo + c, A.v_hi + c};
-            P = COp::combine(P, e);
-        }
+        // a contig's first gene is the constant map L = H = d (its `a` is never used again: a constant map stays one)
+        const bool fst = (L.first >> k) & 1u;
+        const double c = A.v_k + L.d[k];
+        P = COp::combine(P, CE{c, fst ? L.d[k] : A.v_lo + c, fst ? L.d[k] : A.v_hi + c});
     }
     CE total;
     const CE excl = block_scan_exclusive<COp, false>(P, lds, &total);
@@ -539,20 +528,14 @@ __global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
     uint32_t maps = 0, lane_map = MapOp::identity();
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
-        if (k < L.cnt) {
-            D = ((L.first >> k) & 1u) ? L.d[k] : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + L.d[k]);
-            uint32_t m;
-            if ((L.last >> k) & 1u) {
-                m = D > 0.0 ? 3u : 0u;  // end label: first arg max
-            } else {
-                m = (D > A.v_hi ? 1u : 0u) | (D > A.v_lo ? 2u : 0u);  // back-pointers the next gene will take
-            }
-            maps |= m << (2 * k);
-        }
+        D = ((L.first >> k) & 1u) ? L.d[k] : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + L.d[k]);
+        // back-pointers the next gene will take; a contig's last gene decides the end label (first arg max): both of
+        // its "thresholds" are 0
+        const bool lst = (L.last >> k) & 1u;
+        maps |= ((D > (lst ? 0.0 : A.v_hi) ? 1u : 0u) | (D > (lst ? 0.0 : A.v_lo) ? 2u : 0u)) << (2 * k);
     }
 #pragma unroll
-    for (int k = kGPL - 1; k >= 0; --k)
-        if (k < L.cnt) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
+    for (int k = kGPL - 1; k >= 0; --k) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
     A.vMaps[blockIdx.x * kT + slot] = maps;
     uint32_t total;
     A.vLaneMap[blockIdx.x * kT + slot] = block_scan_exclusive_back<MapOp>(lane_map, lds, &total);
@@ -572,10 +555,6 @@ struct ShortStage {
 };
 // genes [g0, g0 + n) of the workgroup -> the lanes that own 8 consecutive ones; coalesced global accesses
 // (lane i takes entries i, i + 256, ...), padded LDS rows
-// Positions of a workgroup past its last gene behave as one-gene contigs with a score difference far from every
-// threshold (the host sets their start / end bits in `lane_bits`): they decide nothing, perturb nothing that comes before
-// them, and the hot loops need no "is this gene there" test.
-constexpr double kVdPad = 1e30;
 __device__ __forceinline__ void load_short(const double *__restrict__ v, int g0, int n, ShortStage &stg) {
     const int slot = threadIdx.x;
 #pragma unroll
