@@ -581,3 +581,30 @@ def test_native_tsv_writer_is_the_row_by_row_writer(monkeypatch):
     back = tables.GeneTable.load(io.BytesIO(bulk.getvalue().encode()))
     assert list(back.protein_id) == list(cols["protein_id"]) and np.array_equal(np.asarray(back.start), cols["start"])
     np.testing.assert_array_equal(np.asarray(back.average_p), cols["average_p"])
+
+
+def test_gecco_hip_entry_point(monkeypatch, capsys):
+    """`gecco-hip` = gecco.cli.main(crf_type=gecco_amd.crf.ClusterCRF) (cli/commands/__init__.py:127-137); without GECCO
+    installed it says what it needs instead of a traceback."""
+    import sys
+    import types
+
+    from gecco_amd import cli
+    from gecco_amd.crf import ClusterCRF
+
+    monkeypatch.setitem(sys.modules, "gecco", None)  # import gecco -> ImportError
+    assert cli.main(["run", "--help"]) == 2
+    assert "needs GECCO itself" in capsys.readouterr().err
+    seen = {}
+    fake = types.ModuleType("gecco")
+    fake.cli = types.ModuleType("gecco.cli")
+
+    def fake_main(argv=None, console=None, *, crf_type=None, **kw):
+        seen.update(argv=argv, crf_type=crf_type)
+        return 0
+
+    fake.cli.main = fake_main
+    monkeypatch.setitem(sys.modules, "gecco", fake)
+    monkeypatch.setitem(sys.modules, "gecco.cli", fake.cli)
+    assert cli.main(["predict", "-o", "x"]) == 0
+    assert seen == {"argv": ["predict", "-o", "x"], "crf_type": ClusterCRF}
