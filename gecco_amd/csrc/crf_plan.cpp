@@ -343,6 +343,11 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
                  o_skip = take(p.skipped.size() * sizeof(int2)), o_cptr = take(p.contig_ptr.size() * 4);
     if ((rc = p.tables.reserve(off, "plan tables"))) return rc;
     char *h = p.tables.h, *d = p.tables.d;
+    if (p.tables_in_host_memory) {
+        void *dv = nullptr;
+        if ((rc = check_hip(hipHostGetDevicePointer(&dv, h, 0), "hipHostGetDevicePointer"))) return rc;
+        d = static_cast<char *>(dv);
+    }
     auto put = [&](size_t o, const void *src, size_t bytes) {
         if (bytes) std::memcpy(h + o, src, bytes);
     };
@@ -360,6 +365,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     p.d_start_bits = reinterpret_cast<uint64_t *>(d + o_bits);
     p.d_skipped = reinterpret_cast<int2 *>(d + o_skip);
     p.d_contig_ptr = reinterpret_cast<int32_t *>(d + o_cptr);
+    if (p.tables_in_host_memory) return GECCO_CRF_OK;
     if ((rc = check_hip(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, upload_stream), "upload plan tables"))) return rc;
     if (sync && (rc = check_hip(hipStreamSynchronize(upload_stream), "upload plan tables"))) return rc;
     return GECCO_CRF_OK;

@@ -76,6 +76,8 @@ struct Plan {
     double *d_win_scratch = nullptr;
     size_t seq_ws_cap = 0, gen_ws_cap = 0, seg_ws_cap = 0, win_scratch_cap = 0;
     bool async_tables = false;  // the owner launches everything on ONE stream (batch driver): table uploads are not waited for
+    bool tables_in_host_memory = false;  // the window kernel reads the plan tables from the pinned block itself (batch driver:
+                                         // one copy and one inter-copy gap less per chunk; they are ~0.1 MB, read once)
     std::mutex ws_mutex;  // guards the lazy workspace / table creation: launches of one plan may come from several threads
     ~Plan();
 };

@@ -335,6 +335,16 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
     }
     tm.lap("h2d csr", chunk_index);
     const double t0 = now_s();
+    {
+        // marginals (and labels) only: the window kernel reads the plan tables (~0.1 MB per chunk, each word once) from the
+        // plan's pinned block itself -- one copy and one ~10 us gap between copies less per chunk.  The refiner and the
+        // whole-contig marginals search the contig table many times: for them it is copied.  GECCO_CRF_TABLES_COPY=1: always copy
+        static const bool always_copy = [] {
+            const char *env = std::getenv("GECCO_CRF_TABLES_COPY");
+            return env && env[0] == '1';
+        }();
+        ln.plan.tables_in_host_memory = !always_copy && !r.want_segments && !X.full && !r.score_out;
+    }
     if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.up, false))) return rc;
     if ((X.viterbi || X.full || r.want_segments) && (rc = plan_ensure_seq(ln.plan, ln.up, false))) return rc;
     S.stats.host_plan_seconds += now_s() - t0;
