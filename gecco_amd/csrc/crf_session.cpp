@@ -567,7 +567,9 @@ int session_run(Session &S, const BatchRequest &r) {
     if (hipGetDevice(&prev_device) != hipSuccess) prev_device = -1;
 
     std::vector<Chunk> chunks;
-    cut_chunks(r, S.chunk_genes, int(S.devs.size()), chunks);
+    // cluster calls launch eight more (short) kernels per chunk and download next to nothing: twice the chunk size
+    cut_chunks(r, r.want_segments ? int32_t(std::min<int64_t>(2 * int64_t(S.chunk_genes), 1 << 28)) : S.chunk_genes, int(S.devs.size()),
+               chunks);
     deal_chunks(chunks, int(S.devs.size()));
     S.stats.n_chunks = int32_t(chunks.size());
     RunCtx X{S, r, chunks, windowed, viterbi, full, windowed ? r.window : 1, windowed ? r.step : 1, windowed ? r.pad : 1};
