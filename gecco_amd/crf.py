@@ -197,6 +197,13 @@ def _annotate_all(genes: List[Any], probs: List[float], w1: Dict[str, float]) ->
     if dom_cls is not None and (not _IS_DATACLASS.setdefault(dom_cls, __import__("dataclasses").is_dataclass(dom_cls))
                                 or hasattr(dom_cls, "__post_init__") or hasattr(dom_cls, "__slots__")):
         return None
+    # ... with GECCO's field names (gecco/model.py:274-290,321-375): anything else goes through its own with_* methods
+    if not {"protein", "qualifiers", "_probability"} <= g0.__dict__.keys() or "domains" not in g0.protein.__dict__:
+        return None
+    if dom_cls is not None:
+        d0 = next(g for g in genes if g.protein.domains).protein.domains[0]
+        if not hasattr(d0, "__dict__") or not {"name", "probability", "cluster_weight", "qualifiers"} <= d0.__dict__.keys():
+            return None
     wget = w1.get  # domain name -> weight of its ('name', '1') state feature
     new = object.__new__
     out = []
