@@ -42,7 +42,7 @@ def oracle_engine(monkeypatch, oracle_model):
             return fake(None, contig_ptr, gene_ptr, attr_id, window, step, label, pad)
 
         def clusters(self, contig_ptr, gene_ptr, attr_id, annotated, window, step=1, label=1, pad=True, threshold=0.8,
-                     n_cds=3, edge_distance=0, trim=True, want_p=False, want_seg_p=True, p_out=None):
+                     n_cds=3, edge_distance=0, trim=True, want_p=False, want_seg_p=True, p_out=None, **_refine_kw):
             p = self.windowed_marginals(contig_ptr, gene_ptr, attr_id, window, step, label, pad)
             seg = orc.segment(p, annotated, contig_ptr, threshold, n_cds, edge_distance, trim, carry_state=False)
             off = np.concatenate([[0], np.cumsum(seg[:, 3] - seg[:, 2])]).astype(np.int64) if len(seg) else np.zeros(1, np.int64)
@@ -608,3 +608,48 @@ def test_gecco_hip_entry_point(monkeypatch, capsys):
     monkeypatch.setitem(sys.modules, "gecco.cli", fake.cli)
     assert cli.main(["predict", "-o", "x"]) == 0
     assert seen == {"argv": ["predict", "-o", "x"], "crf_type": ClusterCRF}
+
+
+def test_duck_typed_models_go_through_their_own_with_methods(trained, oracle_engine):
+    """Genes that are not GECCO-style dataclasses (slots, other field names) are annotated through the with_* methods
+    the reference itself calls (model.py:364-375, crf/__init__.py:261-269); same probabilities and weights as the
+    dataclass fast path."""
+    class D:
+        __slots__ = ("name", "start", "end", "probability", "cluster_weight")
+
+        def __init__(self, name, start, end, probability=None, cluster_weight=None):
+            self.name, self.start, self.end, self.probability, self.cluster_weight = name, start, end, probability, cluster_weight
+
+        def with_probability(self, p):
+            return D(self.name, self.start, self.end, p, self.cluster_weight)
+
+        def with_cluster_weight(self, w):
+            return D(self.name, self.start, self.end, self.probability, w)
+
+    class P:
+        def __init__(self, id, domains):
+            self.id, self.domains = id, list(domains)
+
+        def with_domains(self, domains):
+            return P(self.id, domains)
+
+    class G:
+        def __init__(self, source, start, end, protein, p=None):
+            self.source, self.start, self.end, self.protein, self.p = source, start, end, protein, p
+
+        def with_probability(self, p):
+            return G(self.source, self.start, self.end, self.protein.with_domains([d.with_probability(p) for d in self.protein.domains]), p)
+
+        def with_protein(self, protein):
+            return G(self.source, self.start, self.end, protein, self.p)
+
+    ref = _golden_genes()
+    duck = [G(g.source, g.start, g.end, P(g.protein.id, [D(d.name, d.start, d.end) for d in g.protein.domains])) for g in ref]
+    a = trained.predict_probabilities(ref)
+    b = trained.predict_probabilities(duck)
+    assert [g.protein.id for g in a] == [g.protein.id for g in b]
+    assert [g.average_probability for g in a] == [g.p for g in b]
+    for ga, gb in zip(a, b):
+        assert [(d.name, d.probability, d.cluster_weight) for d in ga.protein.domains] == \
+            [(d.name, d.probability, d.cluster_weight) for d in gb.protein.domains]
+    assert all(type(g) is G and type(g.protein) is P for g in b)
