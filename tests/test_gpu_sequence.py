@@ -293,3 +293,17 @@ def test_viterbi_short_contigs_equal_sequential_recursion_on_random_models(nat, 
     cptr, gptr, attr = synth_contigs(rng, list(rng.integers(1, 2048, size=80)) + [2048, 2047, 1, 9, 8], A)
     y, _ = nat.Model.from_tables(w, trans).viterbi(cptr, gptr, attr, want_score=False)
     np.testing.assert_array_equal(y.astype(np.int32), orc.viterbi_delta(w, trans, cptr, gptr, attr))
+
+
+def test_random_shapes_against_the_oracle(monkeypatch, capsys):
+    """tools/stress_sequence.py: 80 random batches whose workgroups of whole contigs end at, just before and just after
+    2048 genes, partial last lanes, one-gene contigs, a long contig among short ones -- labels equal, marginals and log Z
+    within 1e-12 of the oracle."""
+    import os
+    import runpy
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_sequence.py")
+    monkeypatch.setattr(sys, "argv", [tool, "80", "7"])
+    runpy.run_path(tool, run_name="__main__")
+    assert "ok 80 batches" in capsys.readouterr().out
