@@ -452,9 +452,12 @@ class ClusterCRF(object):
         """The batch driver bound to ``self.devices`` (``gecco_crf_session_*``): created on first use, kept
         for the life of the object so that streams, plans and device buffers are reused from call to call."""
         devices = tuple(self.devices or [0])
+        native = self.model.native
         ses = getattr(self, "_ses", None)
-        if ses is None or ses[0] != devices:
-            ses = (devices, _native.Session(self.model.native, devices))
+        # the session is bound to ONE native model: `fit`, `crf.model = ...` or a copy followed by a model swap must
+        # not keep scoring with the previous model's weights
+        if ses is None or ses[0] != devices or ses[1].model is not native:
+            ses = (devices, _native.Session(native, devices))
             self._ses = ses
         return ses[1]
 
@@ -507,6 +510,7 @@ class ClusterCRF(object):
         with tempfile.TemporaryDirectory() as tmp:
             ref.save(tmp)
             fitted = type(self).trained(tmp)
+        self.__dict__.pop("_ses", None)  # bound to the previous model
         self.__dict__.update(fitted.__dict__)
 
     def save(self, model_path: Union[str, os.PathLike]) -> None:

@@ -19,7 +19,7 @@ struct WinArgs {
     const int32_t *c_gene;     // [K]          first gene of every scored contig
     const int32_t *c_n;        // [K]          number of genes of every scored contig
     const int4 *tile_desc;     // [ntiles]     (gene-slot shift, first contig, last contig, flags: 1 = regular)
-    const uint64_t *start_bits;// [S/64+1]     bit q: a window may start at slot q
+    const uint64_t *start_bits;// [S/64+2]     bit q: a window may start at slot q; zero words in front (1) and behind (24)
     double *p_out;             // [n_genes]
     double2 *state_out;        // [n_genes] or null: raw state scores (s[0], s[1]) as a by-product (fast L == 2 kernel)
     double *dstate_out;        // [n_genes] or null: s[1] - s[0] as a by-product
@@ -37,6 +37,7 @@ struct WinArgs {
     int32_t generic;            // 1: dispatch to the generic window kernel
     const double *exp_trans;   // [L*L] exp(trans) for the generic kernel
     double *scratch;           // generic kernel workspace
+    const double *rtab;        // [32] mu01 * 2^(j/32): exp table of the streaming kernel (crf_stream.hip)
 };
 
 // Geometry of the fast L==2 kernel.
@@ -73,6 +74,25 @@ __device__ __forceinline__ double exp_signed(double x, const double (&kExpC)[12]
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return ldexp(p, int(n));
+}
+// mu exp(x) = 2^e (mu 2^(j/32)) exp(r),  n = rint(x 32 / ln 2) = 32 e + j,  r = x - n ln2 / 32 in two pieces
+// (|r| <= ln2 / 64), degree-6 Taylor polynomial (truncation 3e-18 relative), the factor mu 2^(j/32) from a 32-entry
+// table (`rtab`, built by the host in extended precision; cache-resident, requested before the polynomial),
+// v_ldexp_f64 for 2^e (overflows to +inf / flushes to 0 by itself).  17 VALU instructions and five coefficients,
+// against 28 and twelve for exp_signed followed by the multiplication.
+__device__ __forceinline__ double mu_exp_tab(double x, const double *__restrict__ rtab, const double (&kExpC)[12]) {
+    const double n = rint(x * 46.166241308446828384);  // 32 / ln 2
+    const int ni = int(n);
+    const double t = rtab[ni & 31];
+    double r = fma(-n, 0.02166084939249829, x);          // ln2 / 32, high part
+    r = fma(-n, 7.247021293269686e-19, r);                // low part
+    double p = fma(kExpC[7], r, kExpC[8]);                 // 1/6!, 1/5!
+    p = fma(p, r, kExpC[9]);
+    p = fma(p, r, kExpC[10]);
+    p = fma(p, r, kExpC[11]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p * t, ni >> 5);
 }
 inline void fill_exp_coefficients(double (&c)[12]) {
     double f = 1.0;  // k!
@@ -247,6 +267,10 @@ const char *windowed_kernel_name(int W, int L, bool fast);
 // tile_out = output slots per workgroup for the kernel that (W, L) dispatches to.
 int windowed_tile_out(int W, int L, int tiles_per_wg);
 hipError_t launch_windowed(const WinArgs &a, hipStream_t stream);
+// streaming form (crf_stream.hip): L == 2, W == 20, no rescaling, batches without padded / skipped contigs
+constexpr int kWinStreamPhases = 0;  // phases of kWinThreads window starts per workgroup; 0 = the tiled kernel (default: measured faster); GECCO_CRF_STREAM=2|3|4 selects the streaming one
+int windowed_stream_tile_out(int W, int phases);
+hipError_t launch_windowed_stream(const WinArgs &a, int phases, hipStream_t stream);
 hipError_t launch_fill_nan(double *p, const int2 *ranges, int n_ranges, hipStream_t stream);
 
 }  // namespace gecco

@@ -91,6 +91,7 @@ struct WinSmem {
     int32_t cslot[CMAX];            // slot offsets of the contigs this workgroup overlaps (irregular tiles)
     int32_t cgene[CMAX];
     int32_t cn[CMAX];
+    int32_t flag;                   // ratio-form kernels: some slot leans too far towards the label (the workgroup's vote)
 };
 
 struct SlotInfo {
@@ -250,6 +251,10 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(P.wtab2), 0, uint32_t(P.A) << 4, 0x00020000);
 
+    // the vote's flag (a barrier of stage 1 lies between this and the vote).  NOT any earlier: a store in front of the
+    // wave-uniform loads above turns them into vector loads, and every buffer load then grows a readfirstlane
+    // ("waterfall") loop for its descriptor
+    if (RATIO && tid == 0) sm.flag = 0;
     // ---- stage 1: state scores of the workgroup's slots -> slot constants in LDS.
     double sc0[JMAX], sc1[JMAX];  // s[other], s[label] of the lane's slots
 #pragma unroll
@@ -307,18 +312,20 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
             const uint32_t c0 = lo_tile + base, c1 = c0 + SCAP;
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
-                uint32_t k = max(lo[j], c0) - c0;
-                const uint32_t e = min(hi[j], c1) - c0;  // (k >= e when the run lies outside this round)
+                // the run [lo, hi) cut to this round, as addresses in the parking area (one add and one compare per pair)
+                const f64x2 *k = park + (max(lo[j], c0) - c0);
+                const f64x2 *const e = park + (min(hi[j], c1) - c0);  // (k >= e when the run lies outside this round)
                 for (; k < e && hi[j] > c0; ++k) {
-                    const f64x2 v = park[k];
+                    const f64x2 v = *k;
                     sc0[j] += v.x;
                     sc1[j] += v.y;
                 }
             }
             if (base + SCAP < n_attr) __syncthreads();  // the parking area is reused by the next round
         }
-        // kernels without the ratio form write 16-byte slot constants over the whole lower half right away
-        if (!RATIO && n_attr > 0) __syncthreads();
+        // kernels without the ratio form write 16-byte slot constants over the whole lower half right away; a ratio-form
+        // workgroup without any attribute has not passed a barrier yet (the vote's flag was cleared above)
+        if (RATIO ? n_attr == 0 : n_attr > 0) __syncthreads();
     } else {
         // Irregular workgroup (a padded or skipped contig in reach): slots are looked up one by one; every slot
         // requests its row bounds, then its first kGatherUnroll attribute ids, then their weight pairs, all of
@@ -369,10 +376,11 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
         }
     }
     bool big = false;  // some slot leans so far towards the label that the ratio form could overflow
-    double dsl[JMAX];  // s[label] - s[other] of the lane's slots
+    double rv[JMAX];   // ratio form: the slot constants of the lane's slots (kept for the rare max-normalised rebuild)
     double *rr = reinterpret_cast<double *>(sm.ef);  // ratio form: r per slot, in the first half of the (e0, f) array
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
+        rv[j] = 0.0;
         if (TT > 1 || j == 0 || wave == 0) {
             const int sl = tid + j * NT;
             const double s0 = sc0[j], s1 = sc1[j];
@@ -382,19 +390,23 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                 if (P.state_out) reinterpret_cast<f64x2 *>(P.state_out)[gene[j]] = P.label ? f64x2{s0, s1} : f64x2{s1, s0};
                 if (P.dstate_out) P.dstate_out[gene[j]] = P.label ? s1 - s0 : s0 - s1;
             }
-            dsl[j] = s1 - s0;
+            const double d = s1 - s0;
             if (sl < ns) {
-                const double d = dsl[j];
                 if (RATIO) {
-                    // r = mu01 exp(d); the max-normalised pair is only built if the workgroup needs it
-                    rr[sl] = P.mu01 * exp_signed(d, P.expc);
+                    // r = mu01 exp(d), with "a window may start here" in its sign bit (r > 0: the DP reads |r|); the
+                    // max-normalised pair is only built if the workgroup needs it.  A regular tile maps slots to genes
+                    // by a constant shift, so only irregular ones park their genes.
+                    const double r = mu_exp_tab(d, P.rtab, P.expc);
+                    rv[j] = __hiloint2double(__double2hiint(r) | (start[j] ? int(0x80000000u) : 0), __double2loint(r));
+                    rr[sl] = rv[j];
                     big |= d > P.ratio_dmax;
+                    if (!(td.w & 1)) sm.ginfo[sl] = uint32_t(gene[j] + 1);
                 } else {
                     const double e = exp_neg(fabs(d), P.expc);
                     const double e1 = d > 0.0 ? 1.0 : e;
                     sm.ef[sl] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
+                    sm.ginfo[sl] = (start[j] ? 0x80000000u : 0u) | uint32_t(gene[j] + 1);
                 }
-                sm.ginfo[sl] = (start[j] ? 0x80000000u : 0u) | uint32_t(gene[j] + 1);
             }
         }
     }
@@ -407,16 +419,21 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
     // (a run of strongly label-leaning genes: rare) it uses the max-normalised form below.
     bool ratio_ok = false;
     if (RATIO) {
-        ratio_ok = !__syncthreads_or(big ? 1 : 0);
-        if (!ratio_ok) {  // rare: build (e0, f) over the r values (same LDS), from the differences still in registers
+        // the vote: one ballot per wave, one LDS word, one barrier (`__syncthreads_or` takes three)
+        if (__builtin_amdgcn_ballot_w64(big) != 0 && lane == 0) sm.flag = 1;
+        __syncthreads();
+        ratio_ok = __builtin_amdgcn_readfirstlane(sm.flag) == 0;
+        if (!ratio_ok) {
+            // rare: (e0, f) over the r values (same LDS), rebuilt from r itself: r > mu01 <=> d > 0, where
+            // (e0, f) = (exp(-d), mu01) = (mu01 / r, mu01); else (1, mu01 exp(d)) = (1, r).  The start flag moves to the
+            // sign of f.
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
                 const int sl = tid + j * NT;
                 if ((TT > 1 || j == 0 || wave == 0) && sl < ns) {
-                    const double d = dsl[j];
-                    const double e = exp_neg(fabs(d), P.expc);
-                    const double e1 = d > 0.0 ? 1.0 : e;
-                    sm.ef[sl] = f64x2{d > 0.0 ? e : 1.0, P.mu01 * e1};
+                    const double r = fabs(rv[j]);
+                    const double f = r > P.mu01 ? P.mu01 : r;
+                    sm.ef[sl] = f64x2{r > P.mu01 ? P.mu01 / r : 1.0, rv[j] < 0.0 ? -f : f};
                 }
             }
             __syncthreads();
@@ -430,7 +447,8 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
 #ifdef GECCO_EXP_SKIP_DP  // experiment: stage 1 alone
     for (int ph = 0; ph < TT; ++ph) {
         const int sbase = ph * OUT + tid;
-        const int my_gene = int(sm.ginfo[sbase] & 0x7fffffffu) - 1;
+        const int q = q0 + sbase;
+        const int my_gene = (td.w & 1) ? ((q >= 0 && q < P.S) ? q + td.x : -1) : int(sm.ginfo[sbase] & 0x7fffffffu) - 1;
         if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = rr[sbase];
     }
     return;
@@ -438,19 +456,30 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
 #pragma unroll 1
     for (int ph = 0; ph < TT; ++ph) {
         const int sbase = ph * OUT + tid;  // slot of this lane's window start (and of its output)
-        const uint32_t gi = sm.ginfo[sbase];
-        const bool my_start = gi >> 31;
-        const int my_gene = int(gi & 0x7fffffffu) - 1;
+        // the lane's output gene and whether a window may start at its slot: ratio-form kernels carry the start flag in
+        // the sign bit of the slot constant and compute the gene of a regular tile from the slot; the others read both
+        // from the slot table
+        bool my_start = false;
+        int my_gene;
+        if (RATIO) {
+            const int q = q0 + sbase;
+            my_gene = (td.w & 1) ? ((q >= 0 && q < P.S) ? q + td.x : -1) : int(sm.ginfo[sbase]) - 1;
+        } else {
+            const uint32_t gi = sm.ginfo[sbase];
+            my_start = gi >> 31;
+            my_gene = int(gi & 0x7fffffffu) - 1;
+        }
         const f64x2 *ef = sm.ef + sbase;
         if (RATIO && ratio_ok) {
             const double *rrs = rr + sbase;
             double A1[WMAX];
-            double a0 = 1.0, a1 = rrs[0] * P.kappa_over_mu01;
+            const double r0 = rrs[0];
+            double a0 = 1.0, a1 = fabs(r0) * P.kappa_over_mu01;
             A1[0] = a1;
 #pragma unroll
             for (int k = 1; k < WMAX; ++k) {
                 if (EXACT || k < W) {
-                    const double r = rrs[k];
+                    const double r = fabs(rrs[k]);
                     const double t = a0 + a1;
                     a1 = fma(a1, rho, a0) * r;
                     a0 = t;
@@ -463,7 +492,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                 const double z = fma(a1, P.inv_kappa, a0);
                 double r = __builtin_amdgcn_rcp(z);
                 r = fma(fma(-z, r, 1.0), r, r);
-                b0 = my_start ? r : 0.0;
+                b0 = r0 < 0.0 ? r : 0.0;  // (the sign bit: a window may start here)
                 b1 = b0 * P.inv_kappa;
             }
             double R = 0.0;
@@ -478,7 +507,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                     }
                     R = max_nocanon(R, cand);
                     if (k > 0) {
-                        const double u = rrs[k] * b1;
+                        const double u = fabs(rrs[k]) * b1;
                         b1 = fma(u, rho, b0);
                         b0 = b0 + u;
                     }
@@ -498,8 +527,9 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
             double a0, a1;
             {
                 const f64x2 c = ef[0];
+                if (RATIO) my_start = c.y < 0.0;  // (ratio-form kernels: the start flag travels in the sign of f)
                 a0 = c.x;
-                a1 = c.y * P.kappa_over_mu01;  // kappa * e1
+                a1 = fabs(c.y) * P.kappa_over_mu01;  // kappa * e1
             }
             A1[0] = a1;
 #pragma unroll
@@ -507,7 +537,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                 if (EXACT || k < W) {
                     const f64x2 c = ef[k];
                     const double t = a0 + a1;
-                    a1 = fma(a1, rho, a0) * c.y;
+                    a1 = fma(a1, rho, a0) * fabs(c.y);
                     a0 = t * c.x;
                     A1[k] = a1;
                 }
@@ -541,7 +571,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                     R = max_nocanon(R, cand);
                     if (k > 0) {
                         const f64x2 c = ef[k];
-                        const double cc = c.x * b0, u = c.y * b1;
+                        const double cc = c.x * b0, u = fabs(c.y) * b1;
                         b0 = cc + u;
                         b1 = fma(u, rho, cc);
                     }

@@ -41,6 +41,8 @@ Model::~Model() {
             (void)hipFree(t->wtab2[1]);
             (void)hipFree(t->exp_trans);
             (void)hipFree(t->trans);
+            (void)hipFree(t->rtab[0]);
+            (void)hipFree(t->rtab[1]);
             (void)hipSetDevice(prev);
         }
         delete t;  // without a usable device the allocations die with the context
@@ -53,6 +55,8 @@ static void free_device_tables(DeviceTables *t) {
     (void)hipFree(t->wtab2[1]);
     (void)hipFree(t->exp_trans);
     (void)hipFree(t->trans);
+    (void)hipFree(t->rtab[0]);
+    (void)hipFree(t->rtab[1]);
     delete t;
 }
 
@@ -78,6 +82,16 @@ int get_device_tables(const Model &m, int device, const DeviceTables **out) {
         for (int label = 0; label < 2 && !rc; ++label) {
             for (size_t a = 0; a < A; ++a) w2[a] = make_double2(m.state[a * 2 + (1 - label)], m.state[a * 2 + label]);
             rc = upload(&t->wtab2[label], w2.data(), A, "upload state weight pairs");
+        }
+        // r = mu01 exp(d) in the streaming window kernel: exp(d) = 2^e 2^(j/32) exp(r'), |r'| <= ln2/64; the table holds
+        // mu01 2^(j/32), rounded once from extended precision
+        for (int label = 0; label < 2 && !rc; ++label) {
+            const int o = 1 - label;
+            auto T = [&](int i, int j) { return (long double)m.trans[size_t(i) * 2 + j]; };
+            const long double lmu = T(o, label) + T(label, o) - 2.0L * T(o, o);
+            double tab[32];
+            for (int j = 0; j < 32; ++j) tab[j] = double(expl(lmu + (long double)j * 0.693147180559945309417232121458L / 32.0L));
+            rc = upload(&t->rtab[label], tab, 32, "upload exp table");
         }
     }
     if (rc) {
@@ -279,26 +293,27 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
         p.force_generic = env && env[0] == '1';
     }
     if (p.force_generic) p.fast_ok = false;
-    p.kernel_name = p.general ? "gl_windowed" : windowed_kernel_name(W, m.L, p.fast_ok);
     {
         const char *env = std::getenv("GECCO_CRF_TILES_PER_WG");
         p.tiles_per_wg = (env && env[0] >= '1' && env[0] <= '3' && !env[1]) ? env[0] - '0' : kWinTilesPerWg;
     }
-    p.tile_out = windowed_tile_out(W, m.L, p.tiles_per_wg);
-    p.ntiles = p.S > 0 ? (p.S + p.tile_out - 1) / p.tile_out : 0;
     // window-start flags per slot (_meta.py:131: starts at 0, step, 2*step, ... <= n' - W)
-    p.start_bits.assign(size_t(p.S) / 64 + 2, 0);
+    // one zero word in front (slots -64 .. -1: the lead-in of the first workgroup) and kStartBitsTail behind (the reach of
+    // the last one): the window kernels index the array with any slot of their reach, unclamped
+    constexpr size_t kStartBitsTail = 24;
+    p.start_bits.assign(1 + size_t(p.S) / 64 + 2 + kStartBitsTail, 0);
+    uint64_t *const start_bits = p.start_bits.data() + 1;  // word of slot 0
     // irregular[k]: contig k is padded, or a skipped contig lies between it and contig k+1
     std::vector<int32_t> &irr_prefix = p.irr_prefix;
     irr_prefix.assign(size_t(p.K) + 1, 0);
     for (int32_t k = 0; k < p.K; ++k) {
         const int32_t s0 = p.c_slot[k], np = p.c_slot[k + 1] - s0;
         if (step == 1) {
-            set_bit_range(p.start_bits.data(), s0, int64_t(s0) + np - W + 1);
+            set_bit_range(start_bits, s0, int64_t(s0) + np - W + 1);
         } else {
             for (int32_t pos = 0; pos + W <= np; pos += step) {
                 const int64_t q = int64_t(s0) + pos;
-                p.start_bits[size_t(q >> 6)] |= 1ull << (q & 63);
+                start_bits[size_t(q >> 6)] |= 1ull << (q & 63);
             }
         }
         const bool padded = np != p.c_n[k];
@@ -307,6 +322,25 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     }
     // slot space = gene space everywhere: no contig padded, none skipped (empty contigs take no slots and no genes)
     p.all_regular = p.skipped.empty() && p.S == p.n_genes && irr_prefix[size_t(p.K)] == 0;
+    // kernel and geometry: the streaming kernel (crf_stream.hip) takes the headline shape -- two labels, W = 20, no
+    // rescaling --, the tiled one (crf_kernels.hip) everything else
+    {
+        const char *env = std::getenv("GECCO_CRF_STREAM");  // 0: tiled kernel; 2, 3, 4: phases per workgroup
+        int ph = kWinStreamPhases;
+        if (env && env[0] >= '0' && env[0] <= '9' && !env[1]) ph = env[0] - '0';
+        if (ph != 0 && ph != 2 && ph != 3 && ph != 4) ph = kWinStreamPhases;
+        // (its buffer offsets into the CSR arrays are 32-bit byte offsets: batches of 2^28 genes and more -- up to 2^30
+        // attribute ids -- stay with the tiled kernel, which addresses them relative to the workgroup)
+        p.stream_phases = (p.fast_ok && W == 20 && p.rescale_mask == 0 && p.n_genes < (1 << 28)) ? ph : 0;
+    }
+    if (p.stream_phases) {
+        p.kernel_name = "crf_windowed_stream_l2<20>";
+        p.tile_out = windowed_stream_tile_out(W, p.stream_phases);
+    } else {
+        p.kernel_name = p.general ? "gl_windowed" : windowed_kernel_name(W, m.L, p.fast_ok);
+        p.tile_out = windowed_tile_out(W, m.L, p.tiles_per_wg);
+    }
+    p.ntiles = p.S > 0 ? (p.S + p.tile_out - 1) / p.tile_out : 0;
     p.tile_desc.resize(p.ntiles);
     {
         // contigs in reach of a workgroup: both ends of the reach only move forward from tile to tile
@@ -362,7 +396,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     p.d_c_gene = reinterpret_cast<int32_t *>(d + o_gene);
     p.d_c_n = reinterpret_cast<int32_t *>(d + o_n);
     p.d_tile_desc = reinterpret_cast<int4 *>(d + o_tile);
-    p.d_start_bits = reinterpret_cast<uint64_t *>(d + o_bits);
+    p.d_start_bits = reinterpret_cast<uint64_t *>(d + o_bits) + 1;  // (the word of slot 0)
     p.d_skipped = reinterpret_cast<int2 *>(d + o_skip);
     p.d_contig_ptr = reinterpret_cast<int32_t *>(d + o_cptr);
     if (p.tables_in_host_memory) return GECCO_CRF_OK;
@@ -527,6 +561,7 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     a.wtab = p.tables_model->wtab;
     a.wtab2 = p.tables_model->wtab2[label];
     a.exp_trans = p.tables_model->exp_trans;
+    a.rtab = p.tables_model->rtab[label];
     a.c_slot = p.d_c_slot;
     a.c_gene = p.d_c_gene;
     a.c_n = p.d_c_n;
@@ -585,6 +620,12 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     if (!p.skipped.empty())
         if ((rc = check_hip(launch_fill_nan(d_p_out, p.d_skipped, int(p.skipped.size()), stream), "fill_nan launch")))
             return rc;
+    if (p.stream_phases && !a.state_out) return check_hip(launch_windowed_stream(a, p.stream_phases, stream), "windowed launch");
+    if (p.stream_phases) {
+        // 16-byte state scores as a by-product (matrix-form Viterbi, path scores): not a stream-kernel shape
+        set_error("internal: the streaming plan cannot emit 16-byte state scores");
+        return GECCO_CRF_EUNSUPPORTED;
+    }
     return check_hip(launch_windowed(a, stream), "windowed launch");
 }
 
@@ -917,6 +958,10 @@ int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id
         if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, const_cast<double *>(a.dstate), stream)))
             return rc;
         return check_hip(launch_seq_viterbi_delta(a, stream), "viterbi launch");
+    }
+    if (p.stream_phases) {  // the streaming window kernel hands over score differences only: two passes over the CSR
+        if ((rc = plan_run_windowed(p, d_gene_ptr, d_attr_id, label, d_p_out, stream))) return rc;
+        return plan_run_viterbi(p, d_gene_ptr, d_attr_id, d_y, d_score, stream);
     }
     if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, const_cast<double2 *>(a.state), nullptr, stream)))
         return rc;

@@ -21,6 +21,7 @@ struct DeviceTables {
     double2 *wtab2[2] = {nullptr, nullptr};  // L == 2: [A] (other, label) for label = 0 / 1
     double *exp_trans = nullptr;  // [L*L]
     double *trans = nullptr;      // [L*L] raw weights (general-L Viterbi)
+    double *rtab[2] = {nullptr, nullptr};  // L == 2: [32] mu01(label) * 2^(j/32), the exp table of the streaming window kernel
 };
 
 // A pinned host block mirrored by a device block: plan tables are written on the host side and reach
@@ -41,6 +42,7 @@ struct Plan {
     int64_t n_windows = 0;
     // slot-space layout (host)
     int32_t K = 0, S = 0, ntiles = 0, tile_out = 0, tiles_per_wg = 1;
+    int32_t stream_phases = 0;  // > 0: the streaming window kernel (crf_stream.hip) with this many phases per workgroup
     std::vector<int32_t> c_slot, c_gene, c_n;
     std::vector<int4> tile_desc;
     std::vector<uint64_t> start_bits;

@@ -788,16 +788,17 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
     return GECCO_CRF_OK;
 }
 
-// ---- exactly rounded mean of doubles in [0, 2^63): what statistics.mean returns ------------------------
-// Every double is an integer multiple of 2^-1074; the sum is accumulated exactly in a fixed-point integer
-// with that unit, divided by the count (long division, remainder kept) and rounded to nearest-even once.
+// ---- exactly rounded mean of doubles: what statistics.mean returns -------------------------------------
+// Every finite double is an integer multiple of 2^-1074; positive and negative values are accumulated exactly in
+// two fixed-point integers with that unit (2^-1074 .. 2^1024 and 64 bits of carry room), their difference is divided
+// by the count (long division, remainder kept) and rounded to nearest-even once.  Infinities follow float
+// arithmetic (inf, -inf, or NaN when both signs occur), as statistics.mean does.
 namespace {
 struct ExactSum {
-    static constexpr int kLimbs = 20;  // 2^-1074 .. 2^205
+    static constexpr int kLimbs = 34;  // bits 0 .. 2175 in units of 2^-1074: |v| < 2^1024 needs 2098, the rest is carry room
     uint64_t limb[kLimbs];
     ExactSum() { std::memset(limb, 0, sizeof(limb)); }
-    void add(double v) {  // v >= 0, finite
-        if (v == 0.0) return;
+    void add(double v) {  // v > 0, finite
         int e;
         const double f = std::frexp(v, &e);                  // v = f 2^e, f in [0.5, 1)
         uint64_t mant = uint64_t(std::ldexp(f, 53));       // 53-bit integer
@@ -807,6 +808,7 @@ struct ExactSum {
             pos = 0;
         }
         const int li = int(pos >> 6), sh = int(pos & 63);
+        if (li + 1 >= kLimbs) return;  // unreachable for finite doubles (li <= 32); keeps the writes in bounds regardless
         unsigned __int128 x = (unsigned __int128)mant << sh;
         uint64_t lo = uint64_t(x), hi = uint64_t(x >> 64);
         unsigned __int128 c = (unsigned __int128)limb[li] + lo;
@@ -818,6 +820,19 @@ struct ExactSum {
             c = (unsigned __int128)limb[k] + carry;
             limb[k] = uint64_t(c);
             carry = uint64_t(c >> 64);
+        }
+    }
+    int compare(const ExactSum &o) const {
+        for (int k = kLimbs - 1; k >= 0; --k)
+            if (limb[k] != o.limb[k]) return limb[k] < o.limb[k] ? -1 : 1;
+        return 0;
+    }
+    void subtract(const ExactSum &o) {  // *this >= o
+        uint64_t borrow = 0;
+        for (int k = 0; k < kLimbs; ++k) {
+            const unsigned __int128 d = (unsigned __int128)limb[k] - o.limb[k] - borrow;
+            limb[k] = uint64_t(d);
+            borrow = uint64_t(d >> 64) & 1u;
         }
     }
     double mean(uint64_t count) const {
@@ -846,20 +861,39 @@ struct ExactSum {
         bool sticky = rem != 0;
         for (int b = drop - 2; b >= 0 && !sticky; --b) sticky = bit(b);
         if (round_bit && (sticky || (mnt & 1))) ++mnt;
-        return std::ldexp(double(mnt), drop - 1074);
+        return std::ldexp(double(mnt), drop - 1074);  // overflows to +inf by itself
     }
 };
 }  // namespace
 
 double exact_mean(const double *v, int64_t n) {
-    ExactSum s;
+    ExactSum pos, neg;
     uint64_t cnt = 0;
-    for (int64_t i = 0; i < n; ++i)
-        if (v[i] == v[i]) {
-            s.add(v[i]);
-            ++cnt;
+    double inf_sum = 0.0;  // float sum of the infinite values: +inf, -inf, or NaN when both occur
+    bool any_inf = false;
+    for (int64_t i = 0; i < n; ++i) {
+        const double x = v[i];
+        if (x != x) continue;
+        ++cnt;
+        if (std::isinf(x)) {
+            inf_sum += x;
+            any_inf = true;
+        } else if (x > 0.0) {
+            pos.add(x);
+        } else if (x < 0.0) {
+            neg.add(-x);
         }
-    return cnt ? s.mean(cnt) : std::nan("");
+    }
+    if (!cnt) return std::nan("");
+    if (any_inf) return inf_sum;
+    const int c = pos.compare(neg);
+    if (c == 0) return 0.0;
+    if (c > 0) {
+        pos.subtract(neg);
+        return pos.mean(cnt);
+    }
+    neg.subtract(pos);
+    return -neg.mean(cnt);
 }
 
 // Rows of clusters.tsv (gecco/model.py:731-760) for the called clusters, columnar.

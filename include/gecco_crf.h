@@ -303,7 +303,8 @@ const double *gecco_crf_cluster_rows_max_p(const gecco_crf_cluster_rows *r);
 /* which: 0 sequence_id, 1 cluster_id, 2 proteins, 3 domains */
 int gecco_crf_cluster_rows_strings(const gecco_crf_cluster_rows *r, int32_t which, const uint8_t **data,
                                    const int64_t **offsets);
-/* statistics.mean of the non-NaN values: the exact sum divided by the count, rounded once. */
+/* statistics.mean of the non-NaN values: the exact sum divided by the count, rounded once.  Any finite doubles of either
+ * sign; infinite values follow float arithmetic (inf, -inf, NaN for both signs); NaN when there is no value. */
 double gecco_crf_exact_mean(const double *v, int64_t n);
 /* TSV text of a table, the wire format either side of the path (gecco/_base.py:133-152): `header` first, then
  * n_rows lines of tab-separated cells.  kinds[c]: 0 text (data[c] bytes + offsets[c]), 1 int64, 2 float64; floats
