@@ -117,7 +117,13 @@ def main() -> None:
             self.d_at = torch.from_numpy(np.ascontiguousarray(attr) if len(attr) else np.zeros(1, np.int32)).to(dev)
             self.d_p = torch.zeros(max(self.n_genes, 1), dtype=torch.float64, device=dev)
             self.d_y = torch.zeros(max(self.n_genes, 1), dtype=torch.int8, device=dev)
-            self.stream = torch.cuda.current_stream(dev).cuda_stream
+            # a stream of its own, not the legacy default one: the decode step is replayed as a HIP graph, and streams
+            # are captured into graphs everywhere but there
+            if os.environ.get("GECCO_BENCH_OWN_STREAM", "1") == "1":
+                self.torch_stream = torch.cuda.Stream(dev)
+                self.stream = self.torch_stream.cuda_stream
+            else:
+                self.stream = torch.cuda.current_stream(dev).cuda_stream
 
         def step(self):
             if args.windowed_only:

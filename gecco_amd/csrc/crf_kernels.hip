@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
             const int sl = tid + j * NT, q = q0 + sl;
             if (sl < ns && q >= 0 && q < P.S) {
                 gene[j] = q + td.x;
-                start[j] = (P.start_bits[q >> 6] >> (q & 63)) & 1ull;
+                start[j] = (reinterpret_cast<const uint32_t *>(P.start_bits)[q >> 5] >> (q & 31)) & 1u;  // (one v_bfe_u32)
             }
         }
     } else {
@@ -388,9 +388,11 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
             // workgroup owns are handed to the whole-contig kernels instead of being gathered again
             if (sl >= W - 1 && sl < TT * OUT + (W - 1) && gene[j] >= 0) {
                 if (P.state_out) reinterpret_cast<f64x2 *>(P.state_out)[gene[j]] = P.label ? f64x2{s0, s1} : f64x2{s1, s0};
-                if (P.dstate_out) P.dstate_out[gene[j]] = P.label ? s1 - s0 : s0 - s1;
             }
             const double d = s1 - s0;
+            // (s[1] - s[0] = d or -d: one XOR on the sign word)
+            if (sl >= W - 1 && sl < TT * OUT + (W - 1) && gene[j] >= 0 && P.dstate_out)
+                P.dstate_out[gene[j]] = __hiloint2double(__double2hiint(d) ^ (P.label ? 0 : int(0x80000000u)), __double2loint(d));
             if (sl < ns) {
                 if (RATIO) {
                     // r = mu01 exp(d), with "a window may start here" in its sign bit (r > 0: the DP reads |r|); the

@@ -125,10 +125,21 @@ void Arena::release() {
     cap = 0;
 }
 
+void Plan::DecodeGraph::reset() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    exec = nullptr;
+    graph = nullptr;
+    seen = 0;
+    label = -1;
+    for (auto &k : key) k = nullptr;
+}
+
 Plan::~Plan() {
     if (device >= 0) {
         int prev = 0;
         if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess) {
+            decode_graph.reset();
             tables.release();
             seq.release();
             (void)hipFree(d_seq_ws);
@@ -224,6 +235,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
         set_error("a plan cannot move to another device");
         return GECCO_CRF_EINVAL;
     }
+    p.decode_graph.reset();  // (device pointers of the previous layout are baked into it)
     p.model = &m;
     p.device = device;
     p.W = W;
@@ -931,8 +943,69 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
 }
 
 
+static int run_decode_launches(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                               int8_t *d_y, double *d_score, hipStream_t stream);
+
 int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                     int8_t *d_y, double *d_score, hipStream_t stream) {
+    // A resident batch decoded again and again with the same buffers (a service scoring with several models, the
+    // benchmark's steps, a shard of a strong-scaling run where the launches themselves dominate): replay the launches
+    // as a graph.  The first call runs plainly (it may allocate workspaces and upload tables: not capturable), the
+    // second one captures, from the third on one hipGraphLaunch.  Not on the legacy default stream (no capture there).
+    Plan::DecodeGraph &g = p.decode_graph;
+    static const bool enabled = [] {
+        const char *env = std::getenv("GECCO_CRF_GRAPH");  // opt-in: measured SLOWER than the two plain launches
+        return env && env[0] == '1';
+    }();
+    const void *key[5] = {d_gene_ptr, d_attr_id, d_p_out, d_y, d_score};
+    const bool same = g.label == label && g.stream == stream && std::equal(key, key + 5, g.key);
+    if (!enabled || !stream || p.device < 0) return run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
+    if (same && g.exec) {
+        int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
+        if (rc) return rc;
+        return check_hip(hipGraphLaunch(g.exec, stream), "decode graph launch");
+    }
+    if (same && g.seen < 0) return run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);  // (cannot capture)
+    if (!same || g.seen == 0) {
+        g.reset();
+        std::copy(key, key + 5, g.key);
+        g.label = label;
+        g.stream = stream;
+        int rc = run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
+        if (!rc) g.seen = 1;
+        return rc;
+    }
+    // second identical call: capture
+    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
+    if (rc) return rc;
+    if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        g.seen = -1;  // this stream cannot capture: plain launches from now on
+        return run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
+    }
+    rc = run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(stream, &graph);
+    if (rc || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        g.seen = -1;
+        return rc ? rc : run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
+        (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        g.seen = -1;
+        return run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
+    }
+    g.graph = graph;
+    g.exec = exec;
+    return check_hip(hipGraphLaunch(g.exec, stream), "decode graph launch");
+}
+
+static int run_decode_launches(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                               int8_t *d_y, double *d_score, hipStream_t stream) {
     // the fused hand-over needs the register-resident 2-label kernel and every gene in slot space
     const bool share = !p.general && p.fast_ok && p.skipped.empty() && p.device >= 0;
     if (!share) {

@@ -81,6 +81,17 @@ struct Plan {
     bool tables_in_host_memory = false;  // the window kernel reads the plan tables from the pinned block itself (batch driver:
                                          // one copy and one inter-copy gap less per chunk; they are ~0.1 MB, read once)
     std::mutex ws_mutex;  // guards the lazy workspace / table creation: launches of one plan may come from several threads
+    // The decode step (window kernel + whole-contig Viterbi) as a HIP graph, opt-in (GECCO_CRF_GRAPH=1; measured slower than
+    // the two plain launches on this stack): the second call with the arguments of the first captures the launches,
+    // later ones replay them with one hipGraphLaunch.  Rebuilding the plan drops it.
+    struct DecodeGraph {
+        const void *key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        int32_t label = -1, seen = 0;
+        hipStream_t stream = nullptr;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        void reset();
+    } decode_graph;
     ~Plan();
 };
 
