@@ -72,6 +72,10 @@ def main() -> None:
                     help="steps are plain windowed launches (for PMC passes: one kind of dispatch)")
     ap.add_argument("--preroll-ms", type=float, default=30.0,
                     help="untimed device pre-roll before the warmup steps: the GPU needs ~10 ms of sustained work to reach steady clocks")
+    ap.add_argument("--synth", default="genome", choices=["genome", "8d"],
+                    help="weight law of the synthetic model: 'genome' (default, most genes lean to label 0) or SURVEY.md 8d to the letter")
+    ap.add_argument("--no-levels", action="store_true", help="skip the host-buffer / tables / object API levels (SURVEY.md 8d)")
+    ap.add_argument("--no-8d", action="store_true", help="skip the second roofline point on the 8d-exact weight law")
     args = ap.parse_args()
 
     import torch
@@ -91,14 +95,30 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
     dist = None
     red_dev = dev
+    backend = None
     if world > 1:
         import torch.distributed as dist
 
-        if one_device:
+        # RCCL ("nccl") over xGMI when it comes up; gloo otherwise (the collectives here are a barrier and two scalar
+        # reductions around the timed region: the data path has none)
+        backend = "gloo" if one_device else os.environ.get("GECCO_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            try:
+                dist.init_process_group(backend="nccl", device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(dev)
+            except Exception as err:  # every rank fails the same way (no RCCL transport): fall back together
+                print(f"[bench rank {rank}] nccl unavailable ({type(err).__name__}: {err}); falling back to gloo", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                backend = "gloo"
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        if backend == "gloo":
             dist.init_process_group(backend="gloo")
             red_dev = torch.device("cpu")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
 
     from gecco_amd import _native as nat
     from gecco_amd import sharding, synth
@@ -163,7 +183,7 @@ def main() -> None:
         return int(g.item())
 
     # ---- workload: every rank generates its own batch (same model, different contigs) for the weak-scaling value
-    wl = synth.workload(args.workload, seed=synth.SEED)
+    wl = synth.workload(args.workload, seed=synth.SEED, law=args.synth)
     base = dict(wl)  # rank 0's batch = the batch BASELINE.json names; C4 partitions THIS one
     if rank > 0:
         rng = np.random.default_rng(synth.SEED + rank)
@@ -188,10 +208,20 @@ def main() -> None:
     # (tools/profile.sh -> tools/pmc_to_json.py); null when there is none
     pmc = {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc_note = None
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path)).get(args.workload, {}) or {}
         except Exception:
+            pmc = {}
+        # counters of ANOTHER build of the kernel say nothing about this one: the profile records the hash of the kernel
+        # source it was taken with (tools/pmc_to_json.py)
+        if pmc and pmc.get("kernel_source_sha16") != _kernel_source_sha16():
+            pmc_note = (f"profiles/pmc_traffic.json was taken with kernel source {pmc.get('kernel_source_sha16')}, this is "
+                        f"{_kernel_source_sha16()}: counter figures dropped")
+            pmc = {}
+        if pmc and args.synth != "genome":
+            pmc_note = "profiles/pmc_traffic.json was taken on the default weight law: counter figures dropped"
             pmc = {}
     traffic = pmc.get("hbm_bytes_per_launch")
     valu_insts = pmc.get("SQ_INSTS_VALU")  # wave-level VALU instructions of one launch
@@ -212,9 +242,12 @@ def main() -> None:
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {res.n_contigs} contigs, {n_genes} genes, {nnz} domain hits per GPU; "
-                        f"A=35000 synthetic 2-label model, window 20 step 1, pad.  Deviation from SURVEY.md 8d: weights "
-                        f"~ Laplace(-0.4, 1.7) (8d: location 0) and the Zipf head (ids < A/50) forced negative, so that "
-                        f"most genes lean to label '0' as under the embedded model (mean w1-w0 = -0.76)",
+                        f"A=35000 synthetic 2-label model, window 20 step 1, pad.  " + (
+                            "Deviation from SURVEY.md 8d: weights ~ Laplace(-0.4, 1.7) (8d: location 0) and the Zipf head "
+                            "(ids < A/50) forced negative, so that most genes lean to label '0' as under the embedded model "
+                            "(mean w1-w0 = -0.76); `roofline_8d` carries the same kernel on the 8d-exact law"
+                            if args.synth == "genome" else "Weights exactly as SURVEY.md 8d: Laplace(0, 1.7), no forced head"),
+            "synth_law": args.synth,
             "genes_per_gpu": n_genes,
             "viterbi_in_step": not args.windowed_only,
             "device_preroll_ms": args.preroll_ms,
@@ -228,7 +261,7 @@ def main() -> None:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
-            "traffic_source": pmc.get("source"),
+            "traffic_source": pmc.get("source") or pmc_note,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": kern_ms,
             # the limiter in practice: fp64 VALU issue.  wave-level VALU instructions of one launch (PMC
@@ -239,10 +272,15 @@ def main() -> None:
             # SIMD of independent chains: 4.6-4.8 "2.4 GHz cycles" per wave instruction for v_add/v_mul/v_fma_f64 and the
             # DPP moves, i.e. ~2.05 GHz effective under this load) instead of the nominal 4 cycles at 2.4 GHz
             "valu_frac_at_sustained_rate": (valu_frac * VALU_SUSTAINED_CYCLES / 4.0) if valu_frac else None,
-            "ratio_form_fallback_frac": _ratio_form_fallback_fraction(wl, res.plan.num_tiles, 2 * (256 - (W - 1)))
+            "ratio_form_fallback_frac": _ratio_form_fallback_fraction(wl, res.plan.num_tiles, _tile_out(res.plan, n_genes))
             if args.workload != "Cinf" else None,
         },
     }
+    if world > 1:
+        # who ran where: the process group that carried the timing barrier, and every rank's device
+        devs = [None] * world
+        dist.all_gather_object(devs, {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)})
+        out["dist"] = {"backend": backend, "world_size": dist.get_world_size(), "ranks": devs}
 
     # ---- C4: the ONE base batch partitioned over the ranks (strong scaling, BASELINE.json configs[3])
     if world > 1:
@@ -257,6 +295,10 @@ def main() -> None:
                       f"(gecco_amd.sharding.partition_contigs), no collective",
             "value": tot * args.steps / el, "unit": "genes/s", "ms_per_step": el / args.steps * 1e3,
             "genes_on_rank0": shard.n_genes, "scaling": "strong",
+            # what the launch law of the window kernel (T = 6.5 us + 6.35 us per 1000 workgroups, measured at
+            # N = 1) plus a launch-bound Viterbi kernel (~5 us + its share of the 11 us at full size) predicts for a shard
+            "predicted_ms_per_step": (6.5 + 6.35 * shard.plan.num_tiles / 1000.0 + 5.0 + 6.0 * shard.n_genes / 2.0e6) * 1e-3,
+            "speedup_vs_one_device": (out["ms_per_step"] / (el / args.steps * 1e3)) if out.get("ms_per_step") else None,
         }
 
     # ---- the HBM-resident point: C3 sits in the 256 MiB Infinity Cache across repeated steps; 2e8 genes do not
@@ -275,6 +317,70 @@ def main() -> None:
             torch.cuda.empty_cache()
         except Exception as err:  # a smaller device, a busy box: the headline numbers do not depend on this point
             out["roofline_past_l3"] = {"error": str(err)}
+
+    # ---- the strong-scaling ceiling before the hardware is there: ONE shard of the 8-way partition of this batch
+    # (BASELINE.json configs[3], C4), decoded on this device.  A step of a shard is launch-bound.
+    if rank == 0 and world == 1 and args.workload == "C3":
+        lengths = np.diff(base["contig_ptr"]).astype(np.int64)
+        mine = sharding.partition_contigs(lengths, 8)[0]
+        cptr, gptr, attr, _ = sharding.extract_shard(base["contig_ptr"], base["gene_ptr"], base["attr_id"], mine)
+        sh = Resident(model, cptr, gptr, attr)
+        el = sh.timed(args.steps, min(args.warmup, 50), 0.0)
+        wms = sh.plan.time_windowed(sh.d_gp.data_ptr(), sh.d_at.data_ptr(), sh.d_p.data_ptr(), LABEL, sh.stream, warmup=3, iters=50)
+        out["c4_shard"] = {"genes": sh.n_genes, "workgroups": sh.plan.num_tiles, "c4_shard_ms": el / args.steps * 1e3,
+                           "windowed_ms": wms,
+                           "note": "rank 0's shard of the 8-way greedy partition (sharding.partition_contigs) on ONE device: "
+                                   "8 devices cannot decode the batch faster than this per step"}
+        out["c4_shard_ms"] = out["c4_shard"]["c4_shard_ms"]
+        del sh
+
+    # ---- the same kernel on SURVEY.md 8d's weight law to the letter (Laplace location 0, no forced head): more slots
+    # lean to the label, more workgroups leave the 3 + 3-op ratio form
+    if rank == 0 and world == 1 and args.workload == "C3" and args.synth == "genome" and not args.no_8d:
+        w8 = synth.workload("C3", seed=synth.SEED, law="8d")
+        m8 = nat.Model.from_tables(w8["w"], w8["trans"])
+        r8 = Resident(m8, w8["contig_ptr"], w8["gene_ptr"], w8["attr_id"])
+        el8 = r8.timed(min(args.steps, 200), 20, 0.0)
+        ms8 = r8.plan.time_windowed(r8.d_gp.data_ptr(), r8.d_at.data_ptr(), r8.d_p.data_ptr(), LABEL, r8.stream, warmup=3, iters=50)
+        ab8 = _alg_bytes(r8.n_genes, r8.nnz, r8.n_contigs)
+        out["roofline_8d"] = {
+            "workload": f"C3 contigs, weights exactly as SURVEY.md 8d: {r8.n_genes} genes, {r8.nnz} domain hits",
+            "kernel_ms": ms8, "achieved": ab8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": ab8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "ms_per_step": el8 / min(args.steps, 200) * 1e3,
+            "ratio_form_fallback_frac": _ratio_form_fallback_fraction(w8, r8.plan.num_tiles, _tile_out(r8.plan, r8.n_genes)),
+        }
+        del r8, m8, w8
+        torch.cuda.empty_cache()
+
+    # ---- SURVEY.md 8d's other levels: host buffers through the C ABI (H2D + kernel + D2H), cluster calls, table columns,
+    # Gene objects -- a few iterations each; and the path `GECCO_HIP_DEVICES` users take on a multi-GPU node: ONE process,
+    # one session over every visible device, host buffers in, host buffers out
+    if rank == 0 and world == 1 and not args.no_levels and args.workload in ("C2", "C3"):
+        from gecco_amd import levels
+
+        golden = os.path.join(ROOT, "tests", "golden")
+        lv = {"resident_step": {"ms": out["ms_per_step"], "genes_per_s": out["value"], "genes": n_genes,
+                                "note": "the headline: inputs resident in HBM, windowed marginals + Viterbi"}}
+        try:
+            lv.update(levels.host_buffer_levels(model, wl, devices=(local_rank,)))
+            lv["predict_tables"] = levels.tables_level(golden)
+            lv["object_api"] = levels.object_level(golden)
+        except Exception as err:
+            lv["error"] = f"{type(err).__name__}: {err}"
+        out["levels"] = lv
+        nvis = torch.cuda.device_count()
+        try:
+            smd = {"visible_devices": nvis,
+                   "one_device": levels.host_buffer_levels(model, wl, devices=(0,), reps=5)["one_shot_pinned"]}
+            if nvis > 1:
+                smd["all_devices"] = levels.host_buffer_levels(model, wl, devices=tuple(range(nvis)), reps=5)["one_shot_pinned"]
+                smd["speedup"] = smd["one_device"]["ms"] / smd["all_devices"]["ms"]
+            else:
+                smd["all_devices"] = None
+                smd["note"] = "one device visible: nothing to shard over (the same call deals chunks over every listed device)"
+            out["session_multi_device"] = smd
+        except Exception as err:
+            out["session_multi_device"] = {"error": f"{type(err).__name__}: {err}"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (C restatement of the CRFsuite tagger driven window by
@@ -303,7 +409,7 @@ def main() -> None:
                       + ("" if args.windowed_only else f" + Viterbi {dt_vit:.2f} s") + ", C oracle driven window by window like the reference",
         }
         # SURVEY.md 8d also asks for the same restatement on all host cores (contigs over threads)
-        ncpu = os.cpu_count() or 1
+        ncpu, cpu_note = _usable_host_threads()
         best = None
         for _ in range(2):  # first threaded pass wakes the cores up
             t0 = time.perf_counter()
@@ -313,7 +419,8 @@ def main() -> None:
             d = time.perf_counter() - t0
             best = d if best is None else min(best, d)
         out["cpu_baseline_all_cores"] = {"value": ng / best, "unit": "genes/s", "cores": ncpu, "kind": "port",
-                                         "sample": "same sample, contigs spread over all host threads, best of 2"}
+                                         "speedup_over_one_thread": (ng / best) / (ng / dt),
+                                         "sample": f"same sample, OpenMP over ranges of 8 contigs inside the C oracle, best of 2; {cpu_note}"}
         out["parity"] = {
             "max_abs_dp_vs_oracle": float(np.abs(got - p_ref).max()),
             "cluster_call_mismatches": int(((got > 0.8) != (p_ref > 0.8)).sum()),
@@ -332,6 +439,40 @@ def main() -> None:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _usable_host_threads():
+    """Threads the all-core baseline may really use: the affinity mask, capped by the cgroup CPU quota of the box (more
+    threads than the quota only get throttled)."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count() or 1
+    note = f"{aff} hardware threads in the affinity mask"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, int(-(-int(quota) // int(period))))
+            note += f", cgroup CPU quota {cores} cores"
+            aff = min(aff, cores)
+    except Exception:
+        pass
+    return aff, note
+
+
+def _kernel_source_sha16():
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("crf_kernels.hip", "crf_device.hpp"):
+        with open(os.path.join(ROOT, "gecco_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _tile_out(plan, n_genes):
+    """Output slots per workgroup of the plan's window kernel."""
+    return max(1, plan.tile_out)
 
 
 def _true_reference_baseline():

@@ -66,6 +66,7 @@ SIGNATURES = {
     "gecco_crf_plan_num_genes": (ctypes.c_int32, [_vp]),
     "gecco_crf_plan_num_windows": (ctypes.c_int64, [_vp]),
     "gecco_crf_plan_num_tiles": (ctypes.c_int32, [_vp]),
+    "gecco_crf_plan_tile_out": (ctypes.c_int32, [_vp]),
     "gecco_crf_plan_kernel_name": (ctypes.c_char_p, [_vp]),
     "gecco_crf_plan_run_windowed": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     "gecco_crf_plan_run_decode": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp]),
@@ -731,6 +732,10 @@ class Plan:
     @property
     def num_tiles(self) -> int:
         return self._lib.gecco_crf_plan_num_tiles(self._h)
+
+    @property
+    def tile_out(self) -> int:
+        return self._lib.gecco_crf_plan_tile_out(self._h)
 
     @property
     def kernel_name(self) -> str:

@@ -203,6 +203,7 @@ GECCO_API void gecco_crf_plan_free(gecco_crf_plan *p) {
 GECCO_API int32_t gecco_crf_plan_num_genes(const gecco_crf_plan *p) { return p ? p->p.n_genes : 0; }
 GECCO_API int64_t gecco_crf_plan_num_windows(const gecco_crf_plan *p) { return p ? p->p.n_windows : 0; }
 GECCO_API int32_t gecco_crf_plan_num_tiles(const gecco_crf_plan *p) { return p ? p->p.ntiles : 0; }
+GECCO_API int32_t gecco_crf_plan_tile_out(const gecco_crf_plan *p) { return p ? p->p.tile_out : 0; }
 GECCO_API const char *gecco_crf_plan_kernel_name(const gecco_crf_plan *p) { return p ? p->p.kernel_name.c_str() : ""; }
 
 GECCO_API int gecco_crf_plan_run_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,

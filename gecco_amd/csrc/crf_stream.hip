@@ -285,8 +285,12 @@ struct Stream {
         const double rho = x.rho;
         // where lane 63 parks the running maximum that leaves the wave at step k: row `wave`, or for the last wave the
         // row of this phase's parity (read by the first wave of the next phase).  One address register for all steps.
-        double *crow = m.CARRY + (wave < NW - 1 ? wave : NW - 1 + (cd & 1)) * (W - 1);
-        asm volatile("" : "+v"(crow));
+        // (an LDS address as a 32-bit register: a generic pointer that went through an asm statement would make every one
+        // of these stores a flat_store through the vector memory pipeline)
+        typedef __attribute__((address_space(3))) double lds_double;
+        uint32_t crow_a = uint32_t(reinterpret_cast<uintptr_t>((lds_ptr)(m.CARRY + (wave < NW - 1 ? wave : NW - 1 + (cd & 1)) * (W - 1))));
+        asm volatile("" : "+v"(crow_a));
+        lds_double *const crow = reinterpret_cast<lds_double *>(crow_a);
         // rare: a slot in reach leans so far towards the label that the ratio form could overflow -> max-normalised
         // pairs (e0, f) for this phase, rebuilt from r in the (idle) parking area: r > mu01 <=> d > 0:
         // (e0, f) = (exp(-d), mu01) = (mu01 / r, mu01); else (1, mu01 exp(d)) = (1, r)

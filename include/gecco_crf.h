@@ -163,6 +163,7 @@ void gecco_crf_plan_free(gecco_crf_plan *p);
 int32_t gecco_crf_plan_num_genes(const gecco_crf_plan *p);
 int64_t gecco_crf_plan_num_windows(const gecco_crf_plan *p); /* = the reference's progress `total` */
 int32_t gecco_crf_plan_num_tiles(const gecco_crf_plan *p);   /* workgroups of the windowed kernel */
+int32_t gecco_crf_plan_tile_out(const gecco_crf_plan *p);    /* output slots per workgroup of the windowed kernel */
 /* Name of the kernel variant the plan dispatches to (for profiles / bench). */
 const char *gecco_crf_plan_kernel_name(const gecco_crf_plan *p);
 int gecco_crf_plan_run_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,

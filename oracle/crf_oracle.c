@@ -265,6 +265,63 @@ ORACLE_API int oracle_viterbi(const double *w, const double *trans, int A, int L
     return 0;
 }
 
+/* ---- all host cores ("1 thread and all host cores (OpenMP over contigs)"): contigs are independent
+ * (gecco/crf/__init__.py:244), so the loops above run contig ranges in parallel, every thread with its own scratch.
+ * Same arithmetic, same outputs.  Ranges of `grain` contigs are handed out dynamically (contig lengths differ). */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+ORACLE_API int oracle_windowed_marginals_omp(const double *w, const double *trans, int A, int L,
+                                             const int32_t *contig_ptr, int n_contigs,
+                                             const int32_t *gene_ptr, const int32_t *attr_id,
+                                             int W, int step, int label, int pad, double *p_out, int threads, int grain)
+{
+    if (grain < 1) grain = 1;
+    const int n_ranges = (n_contigs + grain - 1) / grain;
+    int rc_all = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : rc_all)
+    for (int r = 0; r < n_ranges; ++r) {
+        const int c0 = r * grain, c1 = c0 + grain < n_contigs ? c0 + grain : n_contigs;
+        rc_all |= oracle_windowed_marginals(w, trans, A, L, contig_ptr + c0, c1 - c0, gene_ptr, attr_id, W, step, label, pad, p_out);
+    }
+    return rc_all;
+}
+
+ORACLE_API int oracle_viterbi_omp(const double *w, const double *trans, int A, int L,
+                                  const int32_t *contig_ptr, int n_contigs,
+                                  const int32_t *gene_ptr, const int32_t *attr_id,
+                                  int32_t *labels, double *score, int threads, int grain)
+{
+    if (grain < 1) grain = 1;
+    const int n_ranges = (n_contigs + grain - 1) / grain;
+    int rc_all = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : rc_all)
+    for (int r = 0; r < n_ranges; ++r) {
+        const int c0 = r * grain, c1 = c0 + grain < n_contigs ? c0 + grain : n_contigs;
+        rc_all |= oracle_viterbi(w, trans, A, L, contig_ptr + c0, c1 - c0, gene_ptr, attr_id, labels, score ? score + c0 : NULL);
+    }
+    return rc_all;
+}
+
+ORACLE_API int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* ---- row V, difference form: the SPECIFICATION of the device's 2-label label-only Viterbi kernels
  * (gecco_amd/csrc/crf_sequence.hip).  With Delta = delta[1] - delta[0] and d = s[1] - s[0], crf1dc_viterbi's
  * recursion reads  Delta_t = clamp(Delta_{t-1}, lo, hi) + (t11 - t00) + d_t,  lo = t01 - t11, hi = t00 - t10

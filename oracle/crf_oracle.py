@@ -82,57 +82,38 @@ def _contig_chunks(contig_ptr, parts):
     return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
 
-def windowed_marginals_mt(w, trans, contig_ptr, gene_ptr, attr_id, W, step=1, label=1, pad=True, threads=None):
-    """Same as `windowed_marginals`, contigs spread over `threads` host threads (contigs are
-    independent, gecco/crf/__init__.py:244; the C call releases the GIL).  Identical output."""
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-
-    threads = threads or os.cpu_count() or 1
+def windowed_marginals_mt(w, trans, contig_ptr, gene_ptr, attr_id, W, step=1, label=1, pad=True, threads=None, grain=8):
+    """Same as `windowed_marginals` on all host cores: OpenMP over ranges of `grain` contigs inside the C library
+    (contigs are independent, gecco/crf/__init__.py:244).  Identical output."""
     w, trans, contig_ptr, gene_ptr, attr_id = _prep(w, trans, contig_ptr, gene_ptr, attr_id)
     A, L = w.shape
     n = int(contig_ptr[-1])
     out = np.zeros(max(n, 1), dtype=np.float64)
-    fn = lib().oracle_windowed_marginals
-
-    def run(ab):
-        a, b = ab
-        cp = np.ascontiguousarray(contig_ptr[a:b + 1])
-        return fn(_p(w, _D), _p(trans, _D), A, L, _p(cp, _I), b - a, _p(gene_ptr, _I), _p(attr_id, _I),
-                  int(W), int(step), int(label), int(bool(pad)), _p(out, _D))
-
-    with ThreadPoolExecutor(threads) as ex:
-        rcs = list(ex.map(run, _contig_chunks(contig_ptr, threads * 4)))
-    if any(rcs):
-        raise RuntimeError(f"oracle_windowed_marginals rc={rcs}")
+    rc = lib().oracle_windowed_marginals_omp(_p(w, _D), _p(trans, _D), A, L, _p(contig_ptr, _I), len(contig_ptr) - 1,
+                                             _p(gene_ptr, _I), _p(attr_id, _I), int(W), int(step), int(label), int(bool(pad)),
+                                             _p(out, _D), int(threads or 0), int(grain))
+    if rc:
+        raise RuntimeError(f"oracle_windowed_marginals_omp rc={rc}")
     return out[:n]
 
 
-def viterbi_mt(w, trans, contig_ptr, gene_ptr, attr_id, threads=None):
-    """Threaded `viterbi` (labels only)."""
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-
-    threads = threads or os.cpu_count() or 1
+def viterbi_mt(w, trans, contig_ptr, gene_ptr, attr_id, threads=None, grain=8):
+    """`viterbi` on all host cores (OpenMP over contig ranges)."""
     w, trans, contig_ptr, gene_ptr, attr_id = _prep(w, trans, contig_ptr, gene_ptr, attr_id)
     A, L = w.shape
     n = int(contig_ptr[-1])
     nc = len(contig_ptr) - 1
     lab = np.zeros(max(n, 1), dtype=np.int32)
     sc = np.zeros(max(nc, 1), dtype=np.float64)
-    fn = lib().oracle_viterbi
-
-    def run(ab):
-        a, b = ab
-        cp = np.ascontiguousarray(contig_ptr[a:b + 1])
-        return fn(_p(w, _D), _p(trans, _D), A, L, _p(cp, _I), b - a, _p(gene_ptr, _I), _p(attr_id, _I), _p(lab, _I),
-                  ctypes.cast(ctypes.addressof(_p(sc, _D).contents) + 8 * a, ctypes.POINTER(_D)))
-
-    with ThreadPoolExecutor(threads) as ex:
-        rcs = list(ex.map(run, _contig_chunks(contig_ptr, threads * 4)))
-    if any(rcs):
-        raise RuntimeError(f"oracle_viterbi rc={rcs}")
+    rc = lib().oracle_viterbi_omp(_p(w, _D), _p(trans, _D), A, L, _p(contig_ptr, _I), nc, _p(gene_ptr, _I), _p(attr_id, _I),
+                                  _p(lab, _I), _p(sc, _D), int(threads or 0), int(grain))
+    if rc:
+        raise RuntimeError(f"oracle_viterbi_omp rc={rc}")
     return lab[:n], sc[:nc]
+
+
+def max_threads() -> int:
+    return int(lib().oracle_max_threads())
 
 
 def full_marginals(w, trans, contig_ptr, gene_ptr, attr_id):

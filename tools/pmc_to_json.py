@@ -29,7 +29,14 @@ def main():
             kernel = mm.group(1) if mm else k
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         raise SystemExit(f"no FETCH_SIZE / WRITE_SIZE for a kernel matching {pat!r} under {root}")
-    out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_path = os.path.join(repo, "profiles", "pmc_traffic.json")
+    import hashlib
+
+    sha = hashlib.sha256()
+    for name in ("crf_kernels.hip", "crf_device.hpp"):
+        with open(os.path.join(repo, "gecco_amd", "csrc", name), "rb") as fh:
+            sha.update(fh.read())
     try:
         doc = json.load(open(out_path))
     except Exception:
@@ -40,8 +47,10 @@ def main():
         "hbm_bytes_per_launch": int(round(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)),
         "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
         "kernel": kernel,
-        "source": f"profiles/{tag}_pmc.json <- gpurun_out/{tag}/pmc*: rocprofv3 --pmc passes of `bench.py --windowed-only` "
-                  f"({datetime.date.today().isoformat()}), FETCH_SIZE x2 (gfx950 read-side correction) + WRITE_SIZE",
+        "source": f"profiles/{tag}_pmc.json <- {os.path.relpath(os.path.abspath(root), repo)}/pmc*: rocprofv3 --pmc passes of "
+                  f"`bench.py --windowed-only` ({datetime.date.today().isoformat()}), FETCH_SIZE x2 (gfx950 read-side correction) "
+                  f"+ WRITE_SIZE",
+        "kernel_source_sha16": sha.hexdigest()[:16],  # bench.py drops these figures when the kernel source has changed since
     }
     for c in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
               "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM", "GRBM_GUI_ACTIVE", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
