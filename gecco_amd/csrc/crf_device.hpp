@@ -138,6 +138,12 @@ struct SeqArgs {
     double mx;                  // max(trans)
     double v_lo, v_hi, v_k;     // difference-form Viterbi: t01-t11, t00-t10, t11-t00
     int32_t v_exact;            // 1: decisions within rounding noise of a threshold are re-derived sequentially (GECCO_CRF_VD_EXACT=0: A/B runs)
+    // CSR of the batch + weight pairs (w[a][0], w[a][1]): contigs with such a decision are decoded again with
+    // CRFsuite's own delta recursion on freshly summed state scores (null: no such pass)
+    const int32_t *csr_gene_ptr, *csr_attr_id;
+    const double2 *csr_wtab01;
+    int32_t csr_n_attrs;
+    uint8_t *fix_flag;          // [n_contigs] long contigs: 1 = decode this contig again (vd_replay -> vd_exact_fix)
     double expc[12];            // Taylor coefficients of exp (SGPR-resident), see exp_neg
     // workspaces: one element per lane (n_genes / kSeqGenesPerLane) or per workgroup
     VE *vLane, *vBlock;

@@ -676,6 +676,7 @@ SeqLayout seq_layout(size_t n) {
     l.bytes = o + 256;
     return l;
 }
+// (the per-contig "decode again" flags of the long-contig Viterbi path live behind the scan workspace)
 
 }  // namespace
 
@@ -802,7 +803,7 @@ int ensure_seq(Plan &p, hipStream_t stream) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(p.ws_mutex);
     const SeqLayout l = seq_layout(size_t(p.n_genes));
-    return grow_ws(p.d_seq_ws, p.seq_ws_cap, l.bytes, "hipMalloc scan workspace");
+    return grow_ws(p.d_seq_ws, p.seq_ws_cap, l.bytes + align256(size_t(p.n_contigs) + 8), "hipMalloc scan workspace");
 }
 
 int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
@@ -830,6 +831,7 @@ int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
     a.fBlock = reinterpret_cast<FE *>(w + l.off_fblock);
     a.fLaneSuf = reinterpret_cast<FE *>(w + l.off_flanesuf);
     a.fBlockSuf = reinterpret_cast<FE *>(w + l.off_fblocksuf);
+    a.fix_flag = reinterpret_cast<uint8_t *>(w + l.bytes);
     a.flags = p.d_seq_flags;
     a.lane_bits = p.d_seq_lane_bits;
     a.flat_bits = p.d_seq_flat_bits;
@@ -930,6 +932,10 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
     }
     a.y = d_y;
     a.score = d_score;
+    a.csr_gene_ptr = d_gene_ptr;
+    a.csr_attr_id = d_attr_id;
+    a.csr_wtab01 = p.tables_model->wtab2[1];
+    a.csr_n_attrs = p.model->A;
     if (viterbi_delta_ok(a, d_score)) {
         if ((rc = check_hip(launch_seq_state_delta(d_gene_ptr, d_attr_id, p.tables_model->wtab2[1], p.model->A, p.n_genes,
                                                    const_cast<double *>(a.dstate), stream), "state score launch")))
@@ -1027,6 +1033,10 @@ static int run_decode_launches(Plan &p, const int32_t *d_gene_ptr, const int32_t
     }
     a.y = d_y;
     a.score = d_score;
+    a.csr_gene_ptr = d_gene_ptr;
+    a.csr_attr_id = d_attr_id;
+    a.csr_wtab01 = p.tables_model->wtab2[1];
+    a.csr_n_attrs = p.model->A;
     if (viterbi_delta_ok(a, d_score)) {
         if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, const_cast<double *>(a.dstate), stream)))
             return rc;

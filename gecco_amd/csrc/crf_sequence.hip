@@ -464,6 +464,208 @@ __global__ void __launch_bounds__(kT) v_labels(const SeqArgs A) {
     }
 }
 
+// ---- CRFsuite's own recursion for the contigs that need it ------------------------------------------------
+// The difference form decides like [EXT] crf1dc_viterbi wherever a decision keeps its distance from its threshold: both
+// evaluate the same real quantity, the rounding noise of either (accumulated scores of n genes: ~ n |score| 2^-53, 1e-11
+// for 50 000 genes) is far below the margin of 1e-6.  A contig with a decision INSIDE the margin -- exact ties of
+// integer-valued models included -- is decoded again here, the way CRFsuite does it: state scores summed attribute by
+// attribute, delta_t[j] = max_i(delta_{t-1}[i] + trans[i][j]) + state_t[j] with the strict-< first-arg-max update, one
+// gene after the other from the contig's first (oracle_viterbi_seq is this recursion).  The workgroup computes the state
+// scores of 1024 genes at a time in parallel (LDS), one lane walks them; back-pointers go to a byte per gene in global
+// scratch.  Rare (real-valued weights: about one gene in a million lies inside the margin), so nothing here is tuned.
+constexpr int kFixChunk = 1024;
+struct FixStage {
+    double2 st[kFixChunk];            // state scores of one chunk
+    uint32_t bpw[kFixChunk / 16];      // its back-pointers, 2 bits per gene (bit y: predecessor of label y)
+};
+// state scores of genes [g0, g0 + m) -> fx.st, by the lanes `first_lane` .. kT-1 of the workgroup; a lane takes four
+// genes at a time so that their (dependent) row-pointer, id and weight loads are in flight together.  Sums in CSR order.
+__device__ __forceinline__ void exact_states(const SeqArgs &A, int g0, int m, FixStage &fx, int first_lane) {
+    const int nl = kT - first_lane, me = int(threadIdx.x) - first_lane;
+    if (me < 0) return;
+    for (int base = me; base < m; base += 4 * nl) {
+        int lo[4], hi[4];
+        double s0[4], s1[4];
+        int longest = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * nl;
+            lo[u] = hi[u] = 0;
+            if (i < m) {
+                lo[u] = A.csr_gene_ptr[g0 + i];
+                hi[u] = A.csr_gene_ptr[g0 + i + 1];
+            }
+            s0[u] = s1[u] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) longest = max(longest, hi[u] - lo[u]);
+        for (int k = 0; k < longest; ++k) {
+            int a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = lo[u] + k < hi[u] ? A.csr_attr_id[lo[u] + k] : -1;
+            double2 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = unsigned(a[u]) < unsigned(A.csr_n_attrs) ? A.csr_wtab01[a[u]] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // (+0.0 for the genes that have run out: their sums do not change)
+                s0[u] += w[u].x;
+                s1[u] += w[u].y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * nl;
+            if (i < m) fx.st[i] = make_double2(s0[u], s1[u]);
+        }
+    }
+}
+// ONE lane: the recursion over the chunk's m genes (the contig's first gene, if `first`, only initialises).  The lane
+// leaves delta of every gene where the gene's state scores were; the back-pointers -- which of the two candidates won,
+// the same comparisons on the same numbers -- are recomputed from them by all lanes afterwards (exact_backpointers), so
+// the sequential chain is 8 instructions per gene (4 adds, 2 max, 2 adds), 3 of them in a dependent row.
+__device__ __forceinline__ void exact_walk(const SeqArgs &A, FixStage &fx, int m, bool first, double &d0, double &d1) {
+    int i = 0;
+    if (first) {
+        d0 = fx.st[0].x;
+        d1 = fx.st[0].y;
+        i = 1;
+    }
+    auto step = [&](const double2 s) {
+        const double a0 = d0 + A.t00, b0 = d1 + A.t10;
+        const double a1 = d0 + A.t01, b1 = d1 + A.t11;
+        d0 = fmax(a0, b0) + s.x;  // (on a tie both candidates are the same number)
+        d1 = fmax(a1, b1) + s.y;
+    };
+    for (; i < m && (i & 7); ++i) {
+        step(fx.st[i]);
+        fx.st[i] = make_double2(d0, d1);
+    }
+    for (; i + 8 <= m; i += 8) {  // the eight state pairs are requested before the first step
+        double2 sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] = fx.st[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            step(sv[u]);
+            fx.st[i + u] = make_double2(d0, d1);
+        }
+    }
+    for (; i < m; ++i) {
+        step(fx.st[i]);
+        fx.st[i] = make_double2(d0, d1);
+    }
+}
+// all lanes: back-pointer words of the chunk from the delta values exact_walk left in fx.st; (e0, e1) = delta of the gene
+// before the chunk.  [EXT] crf1dc_viterbi: candidates from label 0, then 1; `max_score < s` keeps the first on ties.
+__device__ __forceinline__ void exact_backpointers(const SeqArgs &A, FixStage &fx, int m, bool first, double e0, double e1) {
+    for (int w = threadIdx.x; 16 * w < m; w += kT) {
+        uint32_t word = 0;
+        for (int i = max(16 * w, first ? 1 : 0); i < min(16 * w + 16, m); ++i) {
+            const double p0 = i ? fx.st[i - 1].x : e0, p1 = i ? fx.st[i - 1].y : e1;
+            const uint32_t arg0 = (p0 + A.t00) < (p1 + A.t10) ? 1u : 0u, arg1 = (p0 + A.t01) < (p1 + A.t11) ? 1u : 0u;
+            word |= (arg0 | (arg1 << 1)) << (2 * (i & 15));
+        }
+        fx.bpw[w] = word;
+    }
+}
+// Back-pointer words in global scratch (alpha: marginals only), 16 genes of the CONTIG per word, the contig's words
+// starting at word `gs`: a contig of n genes takes ceil(n / 16) <= n words, so contigs that different workgroups
+// decode at the same time never share one.  A second array of the same shape behind it (n_genes words further) takes
+// the label at the end of every word for the parallel backtrack.
+__device__ __forceinline__ uint32_t *exact_bp_words(const SeqArgs &A, int gs) { return reinterpret_cast<uint32_t *>(A.alpha) + size_t(gs); }
+__device__ __forceinline__ uint32_t *exact_end_labels(const SeqArgs &A, int gs) {
+    return reinterpret_cast<uint32_t *>(A.alpha) + size_t(A.n_genes) + size_t(gs);
+}
+// Labels from the back-pointers of contig [gs, ge) and the scores of its last gene.  Every lane composes the sixteen
+// steps of a word into one map (label behind the word -> label in front of it), one lane walks the words, every lane
+// expands its words.
+__device__ __forceinline__ void exact_backtrack(const SeqArgs &A, int gs, int ge, double d0, double d1) {
+    const int n = ge - gs, nw = (n + 15) / 16;
+    uint32_t *bpc = exact_bp_words(A, gs), *endl = exact_end_labels(A, gs);
+    // position t of the contig (t >= 1) holds the predecessors of gene t; word w covers t in [16 w, 16 w + 15]
+    auto word_map = [&](uint32_t bits, int w, uint32_t y) {  // label at the word's last position -> label at 16 w - 1
+        const int hi = min(16 * w + 15, n - 1), lo = max(16 * w, 1);
+        for (int t = hi; t >= lo; --t) y = (bits >> (2 * (t & 15) + y)) & 1u;
+        return y;
+    };
+    for (int w = threadIdx.x; w < nw; w += kT) {
+        const uint32_t bits = bpc[w];
+        endl[w] = word_map(bits, w, 0) | (word_map(bits, w, 1) << 1);  // (bit y: where label y leads)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t y = d0 < d1 ? 1u : 0u;  // first arg max: the label of the last gene
+        for (int w = nw - 1; w >= 0; --w) {
+            const uint32_t mp = endl[w];
+            endl[w] = y;  // the label at the word's last position
+            y = (mp >> y) & 1u;
+        }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < nw; w += kT) {
+        const uint32_t bits = bpc[w];
+        uint32_t y = endl[w];
+        const int hi = min(16 * w + 15, n - 1), lo = 16 * w;
+        for (int t = hi; t >= lo; --t) {
+            A.y[gs + t] = int8_t(y);
+            if (t >= 1) y = (bits >> (2 * (t & 15) + y)) & 1u;
+        }
+    }
+    __syncthreads();
+}
+
+// a contig of a few chunks, inside vd_short (one LDS buffer: the state scores of a chunk, then the walk)
+__device__ __forceinline__ void exact_delta_contig(const SeqArgs &A, int gs, int ge, FixStage &fx) {
+    uint32_t *bpc = exact_bp_words(A, gs);
+    double d0 = 0.0, d1 = 0.0;  // delta of the last gene walked so far (every lane holds a copy)
+    for (int cb = gs; cb < ge; cb += kFixChunk) {
+        const int m = min(kFixChunk, ge - cb);
+        const double e0 = d0, e1 = d1;
+        exact_states(A, cb, m, fx, 0);
+        __syncthreads();
+        if (threadIdx.x == 0) exact_walk(A, fx, m, cb == gs, d0, d1);
+        __syncthreads();
+        d0 = fx.st[m - 1].x;  // (lane 0's result, for everybody)
+        d1 = fx.st[m - 1].y;
+        exact_backpointers(A, fx, m, cb == gs, e0, e1);
+        __syncthreads();
+        for (int i = threadIdx.x; i < (m + 15) / 16; i += kT) bpc[(cb - gs) / 16 + i] = fx.bpw[i];
+        __syncthreads();
+    }
+    exact_backtrack(A, gs, ge, d0, d1);
+}
+
+// long contigs: vd_replay flags the contigs that hold a decision inside the margin, this kernel decodes them again.
+// Two LDS buffers: lanes 64.. sum the state scores of the next chunk while lane 0 walks the current one (the walk,
+// ~50 cycles per gene, is what a 50 000-gene contig costs: about a millisecond).
+__global__ void __launch_bounds__(kT) vd_exact_fix(const SeqArgs A) {
+    __shared__ FixStage fx[2];
+    for (int c = blockIdx.x; c < A.n_contigs; c += gridDim.x) {
+        if (!A.fix_flag[c]) continue;  // (workgroup-uniform)
+        const int gs = A.contig_ptr[c], ge = A.contig_ptr[c + 1];
+        if (ge <= gs) continue;
+        uint32_t *bpc = exact_bp_words(A, gs);
+        double d0 = 0.0, d1 = 0.0;  // delta of the last gene walked so far (every lane holds a copy)
+        exact_states(A, gs, min(kFixChunk, ge - gs), fx[0], 0);
+        __syncthreads();
+        int k = 0;
+        for (int cb = gs; cb < ge; cb += kFixChunk, k ^= 1) {
+            const int m = min(kFixChunk, ge - cb);
+            const double e0 = d0, e1 = d1;
+            if (threadIdx.x == 0) exact_walk(A, fx[k], m, cb == gs, d0, d1);
+            if (cb + kFixChunk < ge) exact_states(A, cb + kFixChunk, min(kFixChunk, ge - cb - kFixChunk), fx[k ^ 1], 64);
+            __syncthreads();
+            d0 = fx[k].st[m - 1].x;  // (lane 0's result, for everybody)
+            d1 = fx[k].st[m - 1].y;
+            exact_backpointers(A, fx[k], m, cb == gs, e0, e1);
+            __syncthreads();
+            for (int i = threadIdx.x; i < (m + 15) / 16; i += kT) bpc[(cb - gs) / 16 + i] = fx[k].bpw[i];
+            __syncthreads();
+        }
+        exact_backtrack(A, gs, ge, d0, d1);
+    }
+}
+
 // ---- difference form: fold / replay on 8-byte inputs ------------------------------------------
 // Positions of a workgroup past its last gene behave as one-gene contigs with a score difference far from every
 // threshold (the host sets their start / end bits in `lane_bits`): they decide nothing, perturb nothing that comes before
@@ -526,13 +728,26 @@ __global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
                               reinterpret_cast<const CE *>(A.vLane)[blockIdx.x * kT + slot]);
     double D = M.L;  // the map entering a lane is constant once a contig has started
     uint32_t maps = 0, lane_map = MapOp::identity();
+    const double margin = 1e-6 * fmax(1.0, fmax(fabs(A.v_lo), fabs(A.v_hi)));
+    bool sensitive = false;  // some decision of this lane lies within the noise of its threshold
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
         D = ((L.first >> k) & 1u) ? L.d[k] : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + L.d[k]);
         // back-pointers the next gene will take; a contig's last gene decides the end label (first arg max): both of
         // its "thresholds" are 0
         const bool lst = (L.last >> k) & 1u;
-        maps |= ((D > (lst ? 0.0 : A.v_hi) ? 1u : 0u) | (D > (lst ? 0.0 : A.v_lo) ? 2u : 0u)) << (2 * k);
+        const double thi = lst ? 0.0 : A.v_hi, tlo = lst ? 0.0 : A.v_lo;
+        maps |= ((D > thi ? 1u : 0u) | (D > tlo ? 2u : 0u)) << (2 * k);
+        if (k < L.cnt) sensitive |= fabs(D - thi) <= margin || fabs(D - tlo) <= margin;
+    }
+    if (sensitive && A.v_exact && A.fix_flag) {
+        // the contigs of the lane's genes are decoded again with CRFsuite's own recursion (vd_exact_fix)
+        int lo = 0, hi = A.n_contigs - 1;  // largest c with contig_ptr[c] <= g0
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (A.contig_ptr[mid] <= L.g0) lo = mid; else hi = mid - 1;
+        }
+        for (int c = lo; c < A.n_contigs && A.contig_ptr[c] < L.g0 + L.cnt; ++c) A.fix_flag[c] = 1;
     }
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
@@ -614,7 +829,9 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
         }
     }
     // (one barrier either way: the workgroup learns whether any of its lanes has to look back)
-    if (__syncthreads_or((sensitive && A.v_exact) ? 1 : 0)) {
+    const bool lane_sensitive = sensitive && A.v_exact;
+    const bool wg_sensitive = __syncthreads_or(lane_sensitive ? 1 : 0);
+    if (wg_sensitive) {
         // marks for the walk: per gene 1 = beyond hi, 2 = beyond lo (after this gene), 0 = inside or too close to tell
         double Dq = M.L;
         uint64_t sat = 0;
@@ -685,6 +902,45 @@ __global__ void __launch_bounds__(kT) vd_short(const SeqArgs A) {
     for (int j = 0; j < kGPL; ++j) {
         const int idx = j * kT + slot;
         if (idx < n) A.y[g0 + idx] = int8_t(stg.yb[idx]);
+    }
+    // ---- contigs with a decision inside the margin: CRFsuite's own recursion decides (exact_delta_contig).  The
+    // sensitive lanes mark the first genes of the contigs they touch; the workgroup then takes the marked contigs one by one.
+    if (wg_sensitive && A.csr_gene_ptr) {
+        uint32_t *mark = reinterpret_cast<uint32_t *>(stg.yb);          // kBlockGenes bits
+        int *c_end = reinterpret_cast<int *>(stg.yb + kBlockGenes / 8);  // one word behind them
+        __syncthreads();  // (drains the label stores above: the exact pass overwrites some of them)
+        if (slot < kBlockGenes / 32) mark[slot] = 0;
+        __syncthreads();
+        if (lane_sensitive) {
+            int prev = -1;
+            for (int k = 0; k < cnt; ++k) {
+                int t = slot * kGPL + k;
+                while (!(A.flags[g0 + t] & 1u)) --t;  // the contig's first gene (local gene 0 starts one)
+                if (t != prev) atomicOr(&mark[t >> 5], 1u << (t & 31));
+                prev = t;
+            }
+        }
+        __syncthreads();
+        FixStage &st2 = *reinterpret_cast<FixStage *>(stg.st);  // 18 KB: kFixChunk pairs + their back-pointer words
+        static_assert(sizeof(stg.st) >= sizeof(FixStage), "exact pass: LDS for one chunk of state scores");
+        for (int wi = 0; wi < kBlockGenes / 32; ++wi) {
+            uint32_t bits = mark[wi];  // (every lane reads the same word: uniform control flow)
+            while (bits) {
+                const int cs = wi * 32 + __builtin_ctz(bits);
+                bits &= bits - 1;
+                if (slot == 0) *c_end = n;
+                __syncthreads();
+                for (int i = cs + slot; i < n; i += kT)
+                    if (A.flags[g0 + i] & 2u) {
+                        atomicMin(c_end, i + 1);
+                        break;
+                    }
+                __syncthreads();
+                const int ce = *c_end;
+                __syncthreads();
+                exact_delta_contig(A, g0 + cs, g0 + ce, st2);
+            }
+        }
     }
 }
 
@@ -1039,9 +1295,18 @@ hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream) {
         hipLaunchKernelGGL(vd_short, dim3(a.n_cblocks), dim3(kT), 0, stream, a);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(vd_fold, dim3(nb), dim3(kT), 0, stream, a);
-    hipLaunchKernelGGL(vd_replay, dim3(nb), dim3(kT), 0, stream, a);
-    hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, a);
+    const bool exact = a.v_exact && a.csr_gene_ptr && a.fix_flag;
+    SeqArgs b = a;
+    if (!exact) b.fix_flag = nullptr;
+    if (exact) {
+        const hipError_t e = hipMemsetAsync(a.fix_flag, 0, size_t(a.n_contigs), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(vd_fold, dim3(nb), dim3(kT), 0, stream, b);
+    hipLaunchKernelGGL(vd_replay, dim3(nb), dim3(kT), 0, stream, b);
+    hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, b);
+    // contigs that vd_replay flagged (a decision inside the rounding margin): CRFsuite's own recursion
+    if (exact) hipLaunchKernelGGL(vd_exact_fix, dim3(min(a.n_contigs, 1024)), dim3(kT), 0, stream, b);
     return hipGetLastError();
 }
 

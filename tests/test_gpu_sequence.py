@@ -307,3 +307,67 @@ def test_random_shapes_against_the_oracle(monkeypatch, capsys):
     monkeypatch.setattr(sys, "argv", [tool, "80", "7"])
     runpy.run_path(tool, run_name="__main__")
     assert "ok 80 batches" in capsys.readouterr().out
+
+
+def _plant_end_tie(rng, T, w, trans, base_attr, ulps):
+    """A contig of T genes (gene g carries attribute base_attr + g alone) whose CRFsuite delta recursion ends on
+    delta[1] - delta[0] = `ulps` units in the last place of delta[0]: 0 = an exact tie (first arg max: label 0),
+    +1 = label 1 by one ulp.  Real-valued weights everywhere else; returns nothing (fills w in place)."""
+    t00, t01, t10, t11 = trans[0, 0], trans[0, 1], trans[1, 0], trans[1, 1]
+    w[base_attr:base_attr + T, 0] = rng.normal(0.0, 1.0, size=T)
+    w[base_attr:base_attr + T, 1] = rng.normal(0.0, 1.0, size=T)
+    d0, d1 = w[base_attr, 0], w[base_attr, 1]
+    for t in range(1, T - 1):  # [EXT] crf1dc_viterbi, the oracle's oracle_viterbi_seq
+        a0, b0, a1, b1 = d0 + t00, d1 + t10, d0 + t01, d1 + t11
+        m0 = b0 if a0 < b0 else a0
+        m1 = b1 if a1 < b1 else a1
+        d0, d1 = m0 + w[base_attr + t, 0], m1 + w[base_attr + t, 1]
+    a0, b0, a1, b1 = d0 + t00, d1 + t10, d0 + t01, d1 + t11
+    m0 = b0 if a0 < b0 else a0
+    m1 = b1 if a1 < b1 else a1
+    # last gene: s0 = 0, s1 chosen so that m1 + s1 lands exactly `ulps` ulps above m0 + 0
+    target = m0
+    for _ in range(abs(ulps)):
+        target = np.nextafter(target, np.inf if ulps > 0 else -np.inf)
+    s1 = target - m1
+    for _ in range(64):  # the subtraction rounds: walk s1 until the sum is exact
+        got = m1 + s1
+        if got == target:
+            break
+        s1 = np.nextafter(s1, np.inf if got < target else -np.inf)
+    assert m1 + s1 == target
+    w[base_attr + T - 1] = (0.0, s1)
+
+
+def test_viterbi_labels_are_crfsuites_on_planted_ties(nat):
+    """Labels are CRFsuite's, not merely those of an equivalent recursion: contigs whose decisions keep their distance
+    from the thresholds are decided identically by every form (the rounding noise of any of them is far below the
+    margin), and a contig with a decision inside the margin is decoded again with CRFsuite's own delta recursion
+    (exact_delta_contig).  Here: real-valued weights, contigs of 200 (one launch) and of 50 000 genes (look-back path)
+    that end on an exact tie of the ACCUMULATED scores or one ulp either side of it -- the difference form sees another
+    rounding of the same quantity and, on its own, gets a share of them wrong.  Checker: oracle.viterbi, the delta form."""
+    from oracle import crf_oracle as orc
+
+    trans = np.array([[2.669891070463728, -2.599571900486168], [-2.6019205422130995, 2.5683226020688488]])
+    for lengths in ([200] * 300, [50000, 177, 50000, 50000, 23, 50000]):
+        rng = np.random.default_rng(len(lengths))
+        n = sum(lengths)
+        w = np.zeros((n, 2))
+        cptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+        gptr = np.arange(n + 1, dtype=np.int32)
+        attr = np.arange(n, dtype=np.int32)
+        for c, T in enumerate(lengths):
+            _plant_end_tie(rng, T, w, trans, int(cptr[c]), ulps=(0, 1, -1)[c % 3])
+        model = nat.Model.from_tables(w, trans)
+        ey, _ = orc.viterbi(w, trans, cptr, gptr, attr)
+        # the planted ends decide the last label: tie -> 0, +1 ulp -> 1, -1 ulp -> 0
+        np.testing.assert_array_equal(ey[cptr[1:] - 1], [(0, 1, 0)[c % 3] for c in range(len(lengths))])
+        y, _ = model.viterbi(cptr, gptr, attr, want_score=False)
+        np.testing.assert_array_equal(y.astype(np.int32), ey)
+        ses = nat.Session(model, [0])
+        _, y2 = ses.decode(cptr, gptr, attr, 20)
+        np.testing.assert_array_equal(y2.astype(np.int32), ey)
+        # the difference form alone does not get all of them (the case is real) -- unless every planted end happens to
+        # round the same way in both forms
+        yd = orc.viterbi_delta(w, trans, cptr, gptr, attr)
+        assert (yd != ey).any() or len(lengths) < 10
