@@ -53,5 +53,35 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+OBJPATH_SRC = os.path.join(CSRC, "objpath.c")
+
+
+def objpath_path() -> str:
+    import sysconfig
+
+    return os.path.join(LIBDIR, "_objpath" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_objpath(force: bool = False, verbose: bool = False) -> str:
+    """The CPython extension with the object-model loops of the drop-in class (csrc/objpath.c): gcc + Python headers."""
+    import sysconfig
+
+    out = objpath_path()
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(OBJPATH_SRC):
+        return out
+    os.makedirs(LIBDIR, exist_ok=True)
+    cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        raise RuntimeError("no C compiler for gecco_amd/csrc/objpath.c")
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I" + sysconfig.get_paths()["include"],
+           OBJPATH_SRC, "-o", out + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 if __name__ == "__main__":
+    print(build_objpath(force="--force" in sys.argv, verbose=True))
     print(build_native(force="--force" in sys.argv, verbose=True))

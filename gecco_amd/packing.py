@@ -21,6 +21,13 @@ class PackedBatch:
 
 
 def pack_contigs(contigs: Sequence[Sequence[Any]], attr_index: Dict[str, int], feature_type: str = "protein") -> PackedBatch:
+    if feature_type == "protein":
+        from ._objpath_loader import module
+
+        native = module()  # csrc/objpath.c: the loop below against the CPython C API
+        if native is not None:
+            ip, ap, at = native.pack_protein(contigs, attr_index)
+            return PackedBatch(np.frombuffer(ip, dtype=np.int64), np.frombuffer(ap, dtype=np.int64), np.frombuffer(at, dtype=np.int32))
     item_ptr: List[int] = [0]
     attr_ptr: List[int] = [0]
     attr: List[int] = []

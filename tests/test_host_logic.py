@@ -653,3 +653,54 @@ def test_duck_typed_models_go_through_their_own_with_methods(trained, oracle_eng
         assert [(d.name, d.probability, d.cluster_weight) for d in ga.protein.domains] == \
             [(d.name, d.probability, d.cluster_weight) for d in gb.protein.domains]
     assert all(type(g) is G and type(g.protein) is P for g in b)
+
+
+def test_objpath_extension_equals_python_statements(monkeypatch):
+    """csrc/objpath.c (CPython C API) against the Python statements of the same two loops: repeated domain names
+    collapse, unknown names drop, more than sixteen domains per gene, genes without domains; the clones are new objects
+    that compare equal to what the Python loop builds; an object of another class makes the fast path give up."""
+    import numpy as np
+
+    from gecco_amd import _objpath_loader, crf as crf_mod, packing
+    from gecco_amd.model import Domain, Gene, Protein, Source, Strand
+
+    native = _objpath_loader.module()
+    assert native is not None, "gecco_amd/csrc/objpath.c did not build"
+    rng = np.random.default_rng(5)
+    names = [f"PF{i:05d}" for i in range(60)]
+    attr_index = {n: i for i, n in enumerate(names[:40])}  # the last 20 names are unknown to the model
+    contigs = []
+    for c in range(7):
+        src = Source(f"c{c}")
+        genes = []
+        for i in range(int(rng.integers(0, 40))):
+            k = int(rng.choice([0, 1, 2, 3, 5, 20]))
+            doms = [Domain(names[int(a)], 3 * j, 3 * j + 2, "Pfam", 1e-9, 1e-11, qualifiers={"x": [str(j)]})
+                    for j, a in enumerate(rng.integers(0, 60, size=k))]
+            genes.append(Gene(src, 10 * i, 10 * i + 9, Strand.Coding, Protein(f"c{c}_{i}", None, doms), qualifiers={"g": ["q"]}))
+        contigs.append(genes)
+    got = packing.pack_contigs(contigs, attr_index, "protein")
+    w1 = {n: float(i) for i, n in enumerate(names[:30])}
+    probs = [[float(x) for x in rng.random(len(c))] for c in contigs]
+    fast = [crf_mod._annotate_all(c, p, w1) for c, p in zip(contigs, probs)]
+    monkeypatch.setenv("GECCO_AMD_NO_OBJPATH", "1")
+    monkeypatch.setattr(_objpath_loader, "_tried", False)
+    monkeypatch.setattr(_objpath_loader, "_mod", None)
+    exp = packing.pack_contigs(contigs, attr_index, "protein")
+    slow = [crf_mod._annotate_all(c, p, w1) for c, p in zip(contigs, probs)]
+    for a, b in ((got.item_ptr, exp.item_ptr), (got.attr_ptr, exp.attr_ptr), (got.attr_id, exp.attr_id)):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    assert fast == slow
+    for c, f in zip(contigs, fast):
+        for g, ng in zip(c, f):
+            assert ng is not g and ng.protein is not g.protein and ng.qualifiers is not g.qualifiers and ng.qualifiers == g.qualifiers
+            for d, nd in zip(g.protein.domains, ng.protein.domains):
+                assert nd is not d and nd.qualifiers is not d.qualifiers and nd.cluster_weight == w1.get(d.name)
+    # an object of another class: the C loop returns None like the Python one
+    class Other:
+        pass
+
+    o = Other()
+    o.__dict__.update(contigs[0][0].__dict__) if contigs[0] else None
+    if contigs[1]:
+        assert native.annotate_all([contigs[1][0], o], [0.1, 0.2], w1, Gene, Protein, Domain) is None
