@@ -144,6 +144,7 @@ struct SeqArgs {
     const double2 *csr_wtab01;
     int32_t csr_n_attrs;
     uint8_t *fix_flag;          // [n_contigs] long contigs: 1 = decode this contig again (vd_replay -> vd_exact_fix)
+    int32_t raw_fold;           // 1: eight max-normalised factors multiply without renormalisation (transition spread * 8 < 600)
     double expc[12];            // Taylor coefficients of exp (SGPR-resident), see exp_neg
     // workspaces: one element per lane (n_genes / kSeqGenesPerLane) or per workgroup
     VE *vLane, *vBlock;

@@ -853,6 +853,10 @@ int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
     a.m10 = std::exp(a.t10 - a.mx);
     a.m11 = std::exp(a.t11 - a.mx);
     a.dstate = reinterpret_cast<const double *>(a.state);  // same workspace, one of the two forms per call
+    {
+        const double lo = *std::min_element(m.trans.begin(), m.trans.end());
+        a.raw_fold = (a.mx - lo) * double(kSeqGenesPerLane) < 600.0 ? 1 : 0;
+    }
     a.v_lo = a.t01 - a.t11;
     a.v_hi = a.t00 - a.t10;
     a.v_k = a.t11 - a.t00;
@@ -894,10 +898,16 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
     }
     a.marg = d_marg;
     a.lognorm = d_lognorm;
-    if (p.seq_short) {  // whole contigs per workgroup: 8-byte inputs, one fused kernel (alpha is parked in the state area)
+    static const bool general_path = [] {  // GECCO_CRF_MARGINALS=general: the three-pass path on 16-byte states (A/B runs, tests)
+        const char *env = std::getenv("GECCO_CRF_MARGINALS");
+        return env && env[0] == 'g';
+    }();
+    if (p.seq_short || !general_path) {
+        // 8-byte inputs, alpha in registers: one fused kernel when workgroups own whole contigs, the workgroups' products
+        // + the fused kernel (look-back / look-ahead over them) for contigs of any length
         a.smax = reinterpret_cast<const double *>(a.alpha);
-        // log Z is written by the kernel at every contig's last gene; contigs without genes get their 0 here
-        if (d_lognorm && p.n_empty_contigs &&
+        // short contigs: log Z is written by the kernel at every contig's last gene; contigs without genes get their 0 here
+        if (p.seq_short && d_lognorm && p.n_empty_contigs &&
             (rc = check_hip(hipMemsetAsync(d_lognorm, 0, size_t(p.n_contigs) * 8, stream), "memset lognorm")))
             return rc;
         return check_hip(launch_seq_marginals_short(a, d_gene_ptr, d_attr_id, p.tables_model->wtab2[1], p.model->A, p.d_contig_ptr,

@@ -47,23 +47,33 @@ struct VOp {
 };
 struct FOp {
     static __device__ __forceinline__ FE identity() { return FE{1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0}; }
-    static __device__ __forceinline__ FE combine(const FE &a, const FE &b) {
+    // the product without the power-of-two renormalisation: for the eight steps a lane folds by itself (entries of the
+    // max-normalised factors lie in (0, 1]: eight of them cannot leave the range), renormalised once at the end
+    static __device__ __forceinline__ FE combine_raw(const FE &a, const FE &b) {
         if (b.rs != 0.0) return b;
         FE c;
         c.a00 = fma(a.a01, b.a10, a.a00 * b.a00);
         c.a01 = fma(a.a01, b.a11, a.a00 * b.a01);
         c.a10 = fma(a.a11, b.a10, a.a10 * b.a00);
         c.a11 = fma(a.a11, b.a11, a.a10 * b.a01);
+        c.ex = a.ex + b.ex;
+        c.ms = a.ms + b.ms;
+        c.rs = a.rs;
+        return c;
+    }
+    static __device__ __forceinline__ FE renorm(FE c) {
         int e;
         (void)frexp(fmax(fmax(c.a00, c.a01), fmax(c.a10, c.a11)), &e);
         c.a00 = ldexp(c.a00, -e);
         c.a01 = ldexp(c.a01, -e);
         c.a10 = ldexp(c.a10, -e);
         c.a11 = ldexp(c.a11, -e);
-        c.ex = a.ex + b.ex + double(e);
-        c.ms = a.ms + b.ms;
-        c.rs = a.rs;
+        c.ex += double(e);
         return c;
+    }
+    static __device__ __forceinline__ FE combine(const FE &a, const FE &b) {
+        if (b.rs != 0.0) return b;
+        return renorm(combine_raw(a, b));
     }
 };
 // Backward matrices B_t (beta_t = B_t beta_{t+1}): a contig's last gene contributes 1 1^T, so whatever
@@ -79,6 +89,16 @@ struct FOpB {
         c.rs = flag;
         return c;
     }
+    static __device__ __forceinline__ FE combine_raw(const FE &a, const FE &b) {
+        if (a.rs != 0.0) return a;
+        FE bb = b;
+        const double flag = b.rs;
+        bb.rs = 0.0;
+        FE c = FOp::combine_raw(a, bb);
+        c.rs = flag;
+        return c;
+    }
+    static __device__ __forceinline__ FE renorm(const FE &c) { return FOp::renorm(c); }
 };
 // Flag-free products for workgroups that own WHOLE contigs and only want marginals (f_short): a contig's first
 // gene contributes the rank-one matrix 1 e^T, so whatever stands before it only scales the product's rows, and
@@ -86,12 +106,15 @@ struct FOpB {
 // needs.  No `rs` test (7 selects per combine), no exponent / maxima sums, 4 doubles through the DPP network.
 struct F4Op {
     static __device__ __forceinline__ F4 identity() { return F4{1.0, 0.0, 0.0, 1.0}; }
-    static __device__ __forceinline__ F4 combine(const F4 &a, const F4 &b) {  // a earlier
+    static __device__ __forceinline__ F4 combine_raw(const F4 &a, const F4 &b) {  // a earlier; no renormalisation (lane folds)
         F4 c;
         c.a00 = fma(a.a01, b.a10, a.a00 * b.a00);
         c.a01 = fma(a.a01, b.a11, a.a00 * b.a01);
         c.a10 = fma(a.a11, b.a10, a.a10 * b.a00);
         c.a11 = fma(a.a11, b.a11, a.a10 * b.a01);
+        return c;
+    }
+    static __device__ __forceinline__ F4 renorm(F4 c) {
         int e;
         (void)frexp(fmax(fmax(c.a00, c.a01), fmax(c.a10, c.a11)), &e);
         c.a00 = ldexp(c.a00, -e);
@@ -100,6 +123,7 @@ struct F4Op {
         c.a11 = ldexp(c.a11, -e);
         return c;
     }
+    static __device__ __forceinline__ F4 combine(const F4 &a, const F4 &b) { return renorm(combine_raw(a, b)); }
 };
 
 // Difference form of the 2-label Viterbi recursion.  With Delta = delta[1] - delta[0] and d = s[1] - s[0],
@@ -1106,19 +1130,31 @@ __device__ __forceinline__ FE f_step_e(const SeqArgs &A, double2 e, double m, bo
               (first ? 1.0 : A.m11) * e.y, 0.0, m, first ? 1.0 : 0.0};
 }
 
-template <bool WANT_Z>
+// MODE 0 (f_short): workgroups own whole contigs, everything in one launch.
+// MODE 1 / 2 (any contig length, the flat layout: lane l of workgroup b owns genes 2048 b + 8 l ..): the same design in two
+// launches -- 1: only the workgroup's forward and backward products (`fBlock`, `fBlockSuf`); 2: the body of f_short, with
+// the vector entering the workgroup from the left looked back over the forward products of the workgroups before it (up
+// to the nearest one that holds a contig start) and the one entering from the right looked ahead over the backward
+// products (lookback_prefix / lookahead_suffix).  Per gene 8 B (+ 8 B of maxima for log Z) are read twice and 16 B
+// written; the previous general path read 16-byte states three times and parked alpha in HBM (204 us for the 5 M genes
+// of BASELINE.json's configs[4]).  The flat elements carry the contig flags (FE) whether or not log Z is wanted: the
+// look-back needs them.
+template <bool WANT_Z, int MODE>
 __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
+    constexpr bool FLAT = MODE != 0;
     // with log Z: elements carry exponents, emission maxima and the contig-start flag; without: bare 2x2 products
-    using E_t = typename std::conditional<WANT_Z, FE, F4>::type;
-    using OpF = typename std::conditional<WANT_Z, FOp, F4Op>::type;
-    using OpB = typename std::conditional<WANT_Z, FOpB, F4Op>::type;
+    using E_t = typename std::conditional<WANT_Z || FLAT, FE, F4>::type;
+    using OpF = typename std::conditional<WANT_Z || FLAT, FOp, F4Op>::type;
+    using OpB = typename std::conditional<WANT_Z || FLAT, FOpB, F4Op>::type;
+    constexpr bool ELEM_FE = WANT_Z || FLAT;
     __shared__ E_t lds[kT / 64];
     __shared__ E_t xch[kT];
     __shared__ struct {
         double2 st[kT * (kGPL + 1)];  // d (and maxima) in, marginals out
     } stg;  // 36 KB + 14 KB of exchange: three workgroups per CU (the contig flags are read by their owner lanes directly)
     const int slot = threadIdx.x;
-    const int g0 = A.cblk[blockIdx.x], n = A.cblk[blockIdx.x + 1] - g0;
+    const int g0 = FLAT ? int(blockIdx.x) * kBlockGenes : A.cblk[blockIdx.x];
+    const int n = FLAT ? min(kBlockGenes, A.n_genes - g0) : A.cblk[blockIdx.x + 1] - g0;
     constexpr bool want_z = WANT_Z;
 #pragma unroll
     for (int j = 0; j < kGPL; ++j) {
@@ -1128,7 +1164,10 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
             make_double2(ok ? A.dstate[g0 + idx] : 0.0, (ok && want_z) ? A.smax[g0 + idx] : 0.0);
     }
     const int cnt = min(kGPL, n - slot * kGPL);
-    const uint32_t bits = A.lane_bits[blockIdx.x * kT + slot];  // which of the lane's genes start / end a contig (host-packed)
+    // which of the lane's genes start / end a contig (host-packed; positions past the last gene: one-gene contigs)
+    const uint32_t bits = FLAT ? A.flat_bits[blockIdx.x * kT + slot] : A.lane_bits[blockIdx.x * kT + slot];
+    // flat layout: the gene behind the workgroup's last one (its emission enters the last lane's backward step)
+    const double d_next_block = (FLAT && g0 + kBlockGenes < A.n_genes) ? A.dstate[g0 + kBlockGenes] : 0.0;
     __syncthreads();
     // the emission pair of every gene the lane touches (its own 8 and its right neighbour's first): ONE exp per gene,
     // used by the forward fold, the forward replay, the backward fold and the backward replay
@@ -1140,31 +1179,68 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
         E[k] = emit_d(A, v.x);
         mx[k] = v.y;
     }
-    E[kGPL] = emit_d(A, slot + 1 < kT ? stg.st[(slot + 1) * (kGPL + 1)].x : 0.0);
+    E[kGPL] = emit_d(A, slot + 1 < kT ? stg.st[(slot + 1) * (kGPL + 1)].x : d_next_block);
     const uint32_t first = bits & 0xffu, last = bits >> 8;
     auto step = [&](double2 e, double m, bool fst) {
-        if constexpr (WANT_Z) {
+        if constexpr (ELEM_FE) {
             return f_step_e(A, e, m, fst);
         } else {
             return F4{(fst ? 1.0 : A.m00) * e.x, (fst ? 1.0 : A.m01) * e.y, (fst ? 1.0 : A.m10) * e.x, (fst ? 1.0 : A.m11) * e.y};
         }
     };
+    auto bstep = [&](int k) {  // backward matrix of the lane's gene k
+        const bool lst = (last >> k) & 1u;
+        if constexpr (ELEM_FE) {
+            return lst ? FE{1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0} : f_step_e(A, E[k + 1], 0.0, false);
+        } else {
+            const F4 nx = step(E[k + 1], 0.0, false);
+            return lst ? F4{1.0, 1.0, 1.0, 1.0} : nx;
+        }
+    };
     E_t P = OpF::identity();
 #pragma unroll
     for (int k = 0; k < kGPL; ++k)
-        P = OpF::combine(P, step(E[k], mx[k], (first >> k) & 1u));  // (positions past the last gene: one-gene contigs, d = 0)
+    {   // (positions past the last gene: one-gene contigs, d = 0.)  The eight steps a lane folds by itself are renormalised
+        // once at the end when the transition weights allow it (A.raw_fold, set by the host: entries of eight
+        // max-normalised factors then stay far inside the range), after every step otherwise
+        P = OpF::combine_raw(P, step(E[k], mx[k], (first >> k) & 1u));
+        if (!A.raw_fold) P = OpF::renorm(P);
+    }
+    P = OpF::renorm(P);
     E_t total;
-    const E_t M = block_scan_exclusive<OpF, false>(P, lds, &total);
+    E_t M = block_scan_exclusive<OpF, false>(P, lds, &total);
+    if constexpr (MODE == 1) {
+        // products only: forward total, backward total (the lanes' backward folds, scanned back to front)
+        E_t Bf = OpB::identity();
+#pragma unroll
+        for (int k = 0; k < kGPL; ++k) {
+            Bf = OpB::combine_raw(Bf, bstep(k));
+            if (!A.raw_fold) Bf = OpB::renorm(Bf);
+        }
+        Bf = OpB::renorm(Bf);
+        __syncthreads();
+        xch[kT - 1 - slot] = Bf;
+        __syncthreads();
+        const E_t mine1 = xch[slot];
+        E_t btot;
+        (void)block_scan_exclusive<OpB, true>(mine1, lds, &btot);
+        if (slot == 0) {
+            A.fBlock[blockIdx.x] = total;
+            A.fBlockSuf[blockIdx.x] = btot;
+        }
+        return;
+    }
+    if constexpr (MODE == 2) M = FOp::combine(lookback_prefix(A.fBlock, blockIdx.x), M);
     // contig ends before this lane (workgroup-wide count): which contig a log Z belongs to
     uint32_t ends_before = 0;
-    if (want_z) {
+    if (want_z && !FLAT) {
         __shared__ U2 ldsc[kT / 64];
         U2 ctot;
         ends_before = block_scan_exclusive<AddOp, false>(U2{uint32_t(__builtin_popcount(last & ((1u << (cnt > 0 ? cnt : 0)) - 1u))), 0u}, ldsc, &ctot).x;
     }
     // forward replay: alpha of every gene of the lane (registers), log Z at contig ends; backward matrices folded
     double a0 = M.a00, a1 = M.a01, ex = 0.0, ms = 0.0;
-    if constexpr (WANT_Z) {
+    if constexpr (ELEM_FE) {
         ex = M.ex;
         ms = M.ms;
     }
@@ -1193,21 +1269,21 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
             al[k] = make_double2(a0, a1);
             const bool lst = (last >> k) & 1u;
             if (lst && want_z && k < cnt) {
-                // log Z = log Z' (max-normalised emissions and transitions) + the emission maxima + (n - 1) max(trans)
-                const int c = A.ne_contig[A.cblk_rank[blockIdx.x] + int(ends_before) + __builtin_popcount(last & ((1u << k) - 1u))];
-                const int len = A.contig_ptr[c + 1] - A.contig_ptr[c];
-                A.lognorm[c] = (ex * 0.6931471805599453 + log(a0 + a1)) + ms + double(len - 1) * A.mx;
+                if constexpr (FLAT) {
+                    // (log Z', emission maxima) parked at the contig's last gene: f_lognorm finishes the sum per contig
+                    A.contigTmp[g0 + slot * kGPL + k] = make_double2(ex * 0.6931471805599453 + log(a0 + a1), ms);
+                } else {
+                    // log Z = log Z' (max-normalised emissions and transitions) + the emission maxima + (n - 1) max(trans)
+                    const int c = A.ne_contig[A.cblk_rank[blockIdx.x] + int(ends_before) + __builtin_popcount(last & ((1u << k) - 1u))];
+                    const int len = A.contig_ptr[c + 1] - A.contig_ptr[c];
+                    A.lognorm[c] = (ex * 0.6931471805599453 + log(a0 + a1)) + ms + double(len - 1) * A.mx;
+                }
             }
-            E_t B;
-            if constexpr (WANT_Z) {
-                B = lst ? FE{1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0} : f_step_e(A, E[k + 1], 0.0, false);
-            } else {
-                const F4 nx = step(E[k + 1], 0.0, false);
-                B = lst ? F4{1.0, 1.0, 1.0, 1.0} : nx;
-            }
-            Bfold = OpB::combine(Bfold, B);
+            Bfold = OpB::combine_raw(Bfold, bstep(k));
+            if (!A.raw_fold) Bfold = OpB::renorm(Bfold);
         }
     }
+    Bfold = OpB::renorm(Bfold);
     __syncthreads();  // every lane has read its neighbour's d: the stage may be overwritten below
     xch[kT - 1 - slot] = Bfold;
     __syncthreads();
@@ -1217,7 +1293,8 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     __syncthreads();
     xch[kT - 1 - slot] = bexcl;
     __syncthreads();
-    const E_t S = xch[slot];  // product of the backward matrices of the lanes to the right (up to the contig's end)
+    E_t S = xch[slot];  // product of the backward matrices of the lanes to the right (up to the contig's end)
+    if constexpr (MODE == 2) S = FOpB::combine(S, lookahead_suffix(A.fBlockSuf, blockIdx.x, gridDim.x));
     double b0 = S.a00 + S.a01, b1 = S.a10 + S.a11;
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) {
@@ -1330,11 +1407,24 @@ hipError_t launch_seq_marginals_short(const SeqArgs &a, const int32_t *gene_ptr,
         else
             hipLaunchKernelGGL(seq_state_blocks<0>, grid_for(a.n_genes, kStateGenes), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01,
                                n_attrs, a.n_genes, const_cast<double *>(a.dstate), (double *)nullptr, (double2 *)nullptr);
-        if (a.lognorm)
-            hipLaunchKernelGGL(f_short<true>, dim3(a.n_cblocks), dim3(kT), 0, stream, a);  // writes log Z itself
-        else
-            hipLaunchKernelGGL(f_short<false>, dim3(a.n_cblocks), dim3(kT), 0, stream, a);
+        if (a.short_contigs) {
+            if (a.lognorm)
+                hipLaunchKernelGGL((f_short<true, 0>), dim3(a.n_cblocks), dim3(kT), 0, stream, a);  // writes log Z itself
+            else
+                hipLaunchKernelGGL((f_short<false, 0>), dim3(a.n_cblocks), dim3(kT), 0, stream, a);
+        } else {
+            // contigs of any length, flat layout: the workgroups' products first, then the fused kernel looks them up
+            const dim3 nb((a.n_genes + kBlockGenes - 1) / kBlockGenes);
+            if (a.lognorm) {
+                hipLaunchKernelGGL((f_short<true, 1>), nb, dim3(kT), 0, stream, a);
+                hipLaunchKernelGGL((f_short<true, 2>), nb, dim3(kT), 0, stream, a);
+            } else {
+                hipLaunchKernelGGL((f_short<false, 1>), nb, dim3(kT), 0, stream, a);
+                hipLaunchKernelGGL((f_short<false, 2>), nb, dim3(kT), 0, stream, a);
+            }
+        }
     }
+    if (!a.short_contigs && a.lognorm) hipLaunchKernelGGL(f_lognorm, grid_for(a.n_contigs, kT), dim3(kT), 0, stream, a, d_contig_ptr);
     return hipGetLastError();
 }
 
