@@ -41,22 +41,22 @@ def _alg_bytes(n_genes, nnz, n_contigs):
 
 
 def _ratio_form_fallback_fraction(wl, plan_tiles, tile_out):
-    """Fraction of the windowed kernel's workgroups that leave the 3+3-op ratio form of the DP because a slot in
-    their reach leans further towards the label than exp(600/W) (crf_kernels.hip): computed on the host from the
-    weights, for the report only (C3 has no padded contig: slot space = gene space)."""
+    """Fraction of the window kernel's WINDOWS that leave the 3+3-op ratio form of the DP: a wave repeats a phase in the
+    max-normalised form when one of its windows ends on Z >= 1e250 (crf_kernels.hip), i.e. roughly when the positive
+    score differences of a window add up to more than 575.  Estimated on the host from the weights, for the report only:
+    the fraction of waves (64 consecutive window starts) that hold such a window."""
     d_attr = wl["w"][:, LABEL] - wl["w"][:, 1 - LABEL]
     gp = wl["gene_ptr"].astype(np.int64)
-    n = len(gp) - 1
     csum = np.concatenate([[0.0], np.cumsum(d_attr[wl["attr_id"]])])
-    d = csum[gp[1:]] - csum[gp[:-1]]
-    big = d > 600.0 / W
-    if not big.any():
+    pos = np.maximum(csum[gp[1:]] - csum[gp[:-1]], 0.0)
+    c = np.concatenate([[0.0], np.cumsum(pos)])
+    if len(c) <= W:
         return 0.0
-    pre = np.concatenate([[0], np.cumsum(big)])
-    t = np.arange(plan_tiles, dtype=np.int64)
-    lo = np.clip(t * tile_out - (W - 1), 0, n)
-    hi = np.clip((t + 1) * tile_out + (W - 1), 0, n)
-    return float(((pre[hi] - pre[lo]) > 0).mean())
+    ws = c[W:] - c[:-W]  # window sums (contig boundaries ignored: an over-estimate)
+    hot = ws > 575.0
+    if not hot.any():
+        return 0.0
+    return float(np.maximum.reduceat(hot.astype(np.int8), np.arange(0, len(hot), 64)).mean())
 
 
 def main() -> None:

@@ -91,7 +91,6 @@ struct WinSmem {
     int32_t cslot[CMAX];            // slot offsets of the contigs this workgroup overlaps (irregular tiles)
     int32_t cgene[CMAX];
     int32_t cn[CMAX];
-    int32_t flag;                   // ratio-form kernels: some slot leans too far towards the label (the workgroup's vote)
 };
 
 struct SlotInfo {
@@ -251,10 +250,8 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(P.wtab2), 0, uint32_t(P.A) << 4, 0x00020000);
 
-    // the vote's flag (a barrier of stage 1 lies between this and the vote).  NOT any earlier: a store in front of the
-    // wave-uniform loads above turns them into vector loads, and every buffer load then grows a readfirstlane
-    // ("waterfall") loop for its descriptor
-    if (RATIO && tid == 0) sm.flag = 0;
+    // (no store in front of the wave-uniform loads above: it turns them into vector loads, and every buffer load then
+    // grows a readfirstlane ("waterfall") loop for its descriptor)
     // ---- stage 1: state scores of the workgroup's slots -> slot constants in LDS.
     double sc0[JMAX], sc1[JMAX];  // s[other], s[label] of the lane's slots
 #pragma unroll
@@ -323,9 +320,8 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
             }
             if (base + SCAP < n_attr) __syncthreads();  // the parking area is reused by the next round
         }
-        // kernels without the ratio form write 16-byte slot constants over the whole lower half right away; a ratio-form
-        // workgroup without any attribute has not passed a barrier yet (the vote's flag was cleared above)
-        if (RATIO ? n_attr == 0 : n_attr > 0) __syncthreads();
+        // kernels without the ratio form write 16-byte slot constants over the whole lower half right away
+        if (!RATIO && n_attr > 0) __syncthreads();
     } else {
         // Irregular workgroup (a padded or skipped contig in reach): slots are looked up one by one; every slot
         // requests its row bounds, then its first kGatherUnroll attribute ids, then their weight pairs, all of
@@ -375,12 +371,9 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
             }
         }
     }
-    bool big = false;  // some slot leans so far towards the label that the ratio form could overflow
-    double rv[JMAX];   // ratio form: the slot constants of the lane's slots (kept for the rare max-normalised rebuild)
     double *rr = reinterpret_cast<double *>(sm.ef);  // ratio form: r per slot, in the first half of the (e0, f) array
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
-        rv[j] = 0.0;
         if (TT > 1 || j == 0 || wave == 0) {
             const int sl = tid + j * NT;
             const double s0 = sc0[j], s1 = sc1[j];
@@ -395,13 +388,10 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                 P.dstate_out[gene[j]] = __hiloint2double(__double2hiint(d) ^ (P.label ? 0 : int(0x80000000u)), __double2loint(d));
             if (sl < ns) {
                 if (RATIO) {
-                    // r = mu01 exp(d), with "a window may start here" in its sign bit (r > 0: the DP reads |r|); the
-                    // max-normalised pair is only built if the workgroup needs it.  A regular tile maps slots to genes
-                    // by a constant shift, so only irregular ones park their genes.
+                    // r = mu01 exp(d), with "a window may start here" in its sign bit (r > 0: the DP reads |r|).  A regular
+                    // tile maps slots to genes by a constant shift, so only irregular ones park their genes.
                     const double r = mu_exp_tab(d, P.rtab, P.expc);
-                    rv[j] = __hiloint2double(__double2hiint(r) | (start[j] ? int(0x80000000u) : 0), __double2loint(r));
-                    rr[sl] = rv[j];
-                    big |= d > P.ratio_dmax;
+                    rr[sl] = __hiloint2double(__double2hiint(r) | (start[j] ? int(0x80000000u) : 0), __double2loint(r));
                     if (!(td.w & 1)) sm.ginfo[sl] = uint32_t(gene[j] + 1);
                 } else {
                     const double e = exp_neg(fabs(d), P.expc);
@@ -416,33 +406,15 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
     // into the single number r = f / e0 and removes one multiplication from either recursion
     //   forward : t = a0 + a1;  a1' = (a0 + rho a1) r;  a0' = t
     //   backward: u = r b1;  b1' = b0 + rho u;  b0' = b0 + u
-    // (3 + 3 ops, 8 B of LDS per step).  The vectors then grow like exp(sum of positive score
-    // differences), so the workgroup takes this form only if every slot has d <= 600 / W; otherwise
-    // (a run of strongly label-leaning genes: rare) it uses the max-normalised form below.
-    bool ratio_ok = false;
-    if (RATIO) {
-        // the vote: one ballot per wave, one LDS word, one barrier (`__syncthreads_or` takes three)
-        if (__builtin_amdgcn_ballot_w64(big) != 0 && lane == 0) sm.flag = 1;
-        __syncthreads();
-        ratio_ok = __builtin_amdgcn_readfirstlane(sm.flag) == 0;
-        if (!ratio_ok) {
-            // rare: (e0, f) over the r values (same LDS), rebuilt from r itself: r > mu01 <=> d > 0, where
-            // (e0, f) = (exp(-d), mu01) = (mu01 / r, mu01); else (1, mu01 exp(d)) = (1, r).  The start flag moves to the
-            // sign of f.
-#pragma unroll
-            for (int j = 0; j < JMAX; ++j) {
-                const int sl = tid + j * NT;
-                if ((TT > 1 || j == 0 || wave == 0) && sl < ns) {
-                    const double r = fabs(rv[j]);
-                    const double f = r > P.mu01 ? P.mu01 : r;
-                    sm.ef[sl] = f64x2{r > P.mu01 ? P.mu01 / r : 1.0, rv[j] < 0.0 ? -f : f};
-                }
-            }
-            __syncthreads();
-        }
-    } else {
-        __syncthreads();
-    }
+    // (3 + 3 ops, 8 B of LDS per step).  The vectors then grow like exp(sum of the window's positive score
+    // differences); a0 never decreases, so the window's Z bounds everything its forward pass has seen.  Every window is
+    // therefore run in this form first, and a WAVE one of whose windows ends on Z >= 1e250 (a run of strongly
+    // label-leaning genes: about one workgroup in a hundred holds one, under either weight law of the benchmark)
+    // repeats its phase in the max-normalised form, whose pairs (e0, f) it derives from r on the fly.  No vote, no
+    // second LDS layout: the candidates that cross lanes are probabilities whichever form produced them.
+    // (Until round 3 a workgroup took the max-normalised form as soon as ONE of its slots had d > 600 / W: 3 % of the
+    // workgroups under the benchmark's default weights, 96 % under SURVEY.md 8d's law.)
+    __syncthreads();
 
     const uint32_t rmask = P.rescale_mask;
     const double rho = P.rho;
@@ -472,7 +444,7 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
             my_gene = int(gi & 0x7fffffffu) - 1;
         }
         const f64x2 *ef = sm.ef + sbase;
-        if (RATIO && ratio_ok) {
+        if constexpr (RATIO) {
             const double *rrs = rr + sbase;
             double A1[WMAX];
             const double r0 = rrs[0];
@@ -489,9 +461,39 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
                 }
             }
             asm volatile("" ::: "memory");
+            double z = fma(a1, P.inv_kappa, a0);
+            // (ratio_dmax < 0: GECCO_CRF_RATIO=0, every wave takes the max-normalised form -- A/B runs, tests)
+            const bool renorm = __builtin_amdgcn_ballot_w64(!(z < 1.0e250) || P.ratio_dmax < 0.0) != 0;
+            // max-normalised pair of a slot from its ratio constant: r > mu01 <=> d > 0, where (e0, f) = (exp(-d), mu01)
+            // = (mu01 / r, mu01); else (1, mu01 exp(d)) = (1, r)
+            auto pair_of = [&](double r, double &e0, double &f) {
+                const bool pos = r > P.mu01;
+                const double rc = fmin(r, 1.0e300);  // (r = inf for d > 709: e0 = 0 as exp(-d) would be)
+                double q = __builtin_amdgcn_rcp(rc);
+                q = fma(fma(-rc, q, 1.0), q, q);  // one Newton step: a division's worth of digits, a third of its registers
+                e0 = pos ? P.mu01 * q : 1.0;
+                f = pos ? P.mu01 : r;
+            };
+            if (renorm) {  // rare: the forward pass again, max-normalised
+                double e0, f;
+                pair_of(fabs(r0), e0, f);
+                a0 = e0;
+                a1 = f * P.kappa_over_mu01;
+                A1[0] = a1;
+#pragma unroll  // (a rolled loop would index A1 dynamically and send the whole array -- the hot path's too -- to scratch)
+                for (int k = 1; k < WMAX; ++k) {
+                    if (EXACT || k < W) {
+                        pair_of(fabs(rrs[k]), e0, f);
+                        const double t = a0 + a1;
+                        a1 = fma(a1, rho, a0) * f;
+                        a0 = t * e0;
+                        A1[k] = a1;
+                    }
+                }
+                z = fma(a1, P.inv_kappa, a0);
+            }
             double b0, b1;
             {
-                const double z = fma(a1, P.inv_kappa, a0);
                 double r = __builtin_amdgcn_rcp(z);
                 r = fma(fma(-z, r, 1.0), r, r);
                 b0 = r0 < 0.0 ? r : 0.0;  // (the sign bit: a window may start here)
@@ -499,19 +501,40 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
             }
             double R = 0.0;
             double *carry = reinterpret_cast<double *>(&sm.carry[0][0]);
+            if (!renorm) {
 #pragma unroll
-            for (int k = WMAX - 1; k >= 0; --k) {
-                if (EXACT || k < W) {
-                    const double cand = A1[k] * b1;
-                    if (k < W - 1) {
-                        if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
-                        R = wave_shr1_zero(R);
+                for (int k = WMAX - 1; k >= 0; --k) {
+                    if (EXACT || k < W) {
+                        const double cand = A1[k] * b1;
+                        if (k < W - 1) {
+                            if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
+                            R = wave_shr1_zero(R);
+                        }
+                        R = max_nocanon(R, cand);
+                        if (k > 0) {
+                            const double u = fabs(rrs[k]) * b1;
+                            b1 = fma(u, rho, b0);
+                            b0 = b0 + u;
+                        }
                     }
-                    R = max_nocanon(R, cand);
-                    if (k > 0) {
-                        const double u = fabs(rrs[k]) * b1;
-                        b1 = fma(u, rho, b0);
-                        b0 = b0 + u;
+                }
+            } else {
+#pragma unroll
+                for (int k = WMAX - 1; k >= 0; --k) {
+                    if (EXACT || k < W) {
+                        const double cand = A1[k] * b1;
+                        if (k < W - 1) {
+                            if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
+                            R = wave_shr1_zero(R);
+                        }
+                        R = max_nocanon(R, cand);
+                        if (k > 0) {
+                            double e0, f;
+                            pair_of(fabs(rrs[k]), e0, f);
+                            const double cc = e0 * b0, u = f * b1;
+                            b0 = cc + u;
+                            b1 = fma(u, rho, cc);
+                        }
                     }
                 }
             }
@@ -529,7 +552,6 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
             double a0, a1;
             {
                 const f64x2 c = ef[0];
-                if (RATIO) my_start = c.y < 0.0;  // (ratio-form kernels: the start flag travels in the sign of f)
                 a0 = c.x;
                 a1 = fabs(c.y) * P.kappa_over_mu01;  // kappa * e1
             }

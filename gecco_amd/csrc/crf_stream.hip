@@ -132,7 +132,6 @@ struct Stream {
         int32_t *IDS;     // [PCAP] its attribute ids
         int32_t *GP;      // [NT+1] its row pointers
         double *CARRY;    // [(NW+1)(W-1)] rows 0 .. NW-2: wave -> next wave; rows NW-1, NW: last wave -> next phase (by parity)
-        int32_t *FLAG;    // some slot so far leans too far towards the label for the ratio form
         uint32_t *AB;     // [PH+2] gene_ptr at the first gene of every stage phase (and behind the last one)
     };
     // what survives from phase to phase (all wave-uniform except tid)
@@ -141,7 +140,7 @@ struct Stream {
         int B, S;            // slot of r-index 0; slots of the batch
         int shift;           // regular workgroup: gene = slot + shift throughout its reach
         int irregular, wg;   // a padded or skipped contig in reach: slots are looked up one by one (slow, rare)
-        int sticky;
+        int force_renorm;    // GECCO_CRF_RATIO=0: every wave takes the max-normalised form
         double rho, mu01, kappa_over_mu01, inv_kappa;
         __amdgpu_buffer_rsrc_t ra, rw, rg;  // attribute ids, weight pairs, row pointers (whole arrays: bounds-checked)
         // The probability a DP phase produces is STORED at the top of the next iteration, behind that iteration's
@@ -276,10 +275,9 @@ struct Stream {
             if (g >= 0 && sa.dstate_out && i >= W - 1 && i < W - 1 + OUTW) GLOBAL_PTR(double, sa.dstate_out)[g] = LABEL1 ? d : -d;
             const double r = mu_exp(d, sa);
             if (!LAST || tid < ns) m.R[i] = __hiloint2double(__double2hiint(r) | int(sbit << 31), __double2loint(r));
-            if (__builtin_amdgcn_ballot_w64((!LAST || tid < ns) && d > sa.ratio_dmax) != 0 && lane == 0) *m.FLAG = 1;
+            x.force_renorm = sa.ratio_dmax < 0.0;  // (GECCO_CRF_RATIO=0)
         }
         lds_barrier();  // R published; PARK, GP and (per wave) IDS are free again
-        x.sticky = __builtin_amdgcn_readfirstlane(*m.FLAG);
         const int cd = c - 1;  // the DP phase whose constants are now complete: r-indices [NT cd, NT cd + NT + W-1)
         double Rb = 0.0;       // running best of the lane's output slot
         const double rho = x.rho;
@@ -291,63 +289,6 @@ struct Stream {
         uint32_t crow_a = uint32_t(reinterpret_cast<uintptr_t>((lds_ptr)(m.CARRY + (wave < NW - 1 ? wave : NW - 1 + (cd & 1)) * (W - 1))));
         asm volatile("" : "+v"(crow_a));
         lds_double *const crow = reinterpret_cast<lds_double *>(crow_a);
-        // rare: a slot in reach leans so far towards the label that the ratio form could overflow -> max-normalised
-        // pairs (e0, f) for this phase, rebuilt from r in the (idle) parking area: r > mu01 <=> d > 0:
-        // (e0, f) = (exp(-d), mu01) = (mu01 / r, mu01); else (1, mu01 exp(d)) = (1, r)
-        if (!FIRST && x.sticky) {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = jj * NT + tid;
-                if (j < NT + W - 1) {
-                    const double r = fabs(m.R[NT * cd + j]);
-                    m.PARK[j] = r > x.mu01 ? f64x2{x.mu01 / r, x.mu01} : f64x2{1.0, r};
-                }
-            }
-            const bool my_start = m.R[NT * cd + tid] < 0.0;
-            lds_barrier();
-            const f64x2 *ef = m.PARK + tid;
-            double A1[W];
-            double a0, a1;
-            {
-                const f64x2 cc = ef[0];
-                a0 = cc.x;
-                a1 = cc.y * x.kappa_over_mu01;
-            }
-            A1[0] = a1;
-#pragma unroll
-            for (int k = 1; k < W; ++k) {
-                const f64x2 cc = ef[k];
-                const double t = a0 + a1;
-                a1 = fma(a1, rho, a0) * cc.y;
-                a0 = t * cc.x;
-                A1[k] = a1;
-            }
-            asm volatile("" ::: "memory");  // re-read the pairs in the backward pass (VGPRs)
-            double b0, b1;
-            {
-                const double z = fma(a1, x.inv_kappa, a0);
-                double r = __builtin_amdgcn_rcp(z);
-                r = fma(fma(-z, r, 1.0), r, r);
-                b0 = my_start ? r : 0.0;
-                b1 = b0 * x.inv_kappa;
-            }
-#pragma unroll
-            for (int k = W - 1; k >= 0; --k) {
-                const double cand = A1[k] * b1;
-                if (k < W - 1) {
-                    if (lane == 63) crow[k] = Rb;
-                    Rb = wave_shr1_zero(Rb);
-                }
-                Rb = max_nocanon(Rb, cand);
-                if (k > 0) {
-                    const f64x2 cc = ef[k];
-                    const double ce = cc.x * b0, u = cc.y * b1;
-                    b0 = ce + u;
-                    b1 = fma(u, rho, ce);
-                }
-            }
-            lds_barrier();  // the pairs have been read: the parking area takes the next phase's gathers
-        }
         // ================= stage 1 of phase c+1 leaves now and lands under the DP below =================
         if (!LAST && !x.irregular) {
             const uint32_t a_nxt = m.AB[c + 1], a_nx2 = m.AB[c + 2];
@@ -357,29 +298,56 @@ struct Stream {
         }
         // ================= DP of phase c-1, ratio form =================
         if (!FIRST) {
-            if (!x.sticky) {
-                const double *rrs = m.R + NT * cd + tid;
-                double A1[W];
-                const double r0 = rrs[0];
-                double a0 = 1.0, a1 = fabs(r0) * x.kappa_over_mu01;
-                A1[0] = a1;
+            // every window in the ratio form first; a wave one of whose windows ends on Z >= 1e250 repeats the phase in the
+            // max-normalised form, pairs (e0, f) derived from r on the fly (see crf_kernels.hip)
+            const double *rrs = m.R + NT * cd + tid;
+            double A1[W];
+            const double r0 = rrs[0];
+            double a0 = 1.0, a1 = fabs(r0) * x.kappa_over_mu01;
+            A1[0] = a1;
 #pragma unroll
+            for (int k = 1; k < W; ++k) {
+                const double r = fabs(rrs[k]);
+                const double t = a0 + a1;
+                a1 = fma(a1, rho, a0) * r;
+                a0 = t;
+                A1[k] = a1;
+            }
+            asm volatile("" ::: "memory");  // re-read the slot constants in the backward pass (VGPRs)
+            double z = fma(a1, x.inv_kappa, a0);
+            const bool renorm = __builtin_amdgcn_ballot_w64(!(z < 1.0e250) || x.force_renorm) != 0;
+            auto pair_of = [&](double r, double &e0, double &f) {
+                const bool pos = r > x.mu01;
+                const double rc = fmin(r, 1.0e300);  // (r = inf for d > 709: e0 = 0 as exp(-d) would be)
+                double q = __builtin_amdgcn_rcp(rc);
+                q = fma(fma(-rc, q, 1.0), q, q);  // one Newton step: a division's worth of digits, a third of its registers
+                e0 = pos ? x.mu01 * q : 1.0;
+                f = pos ? x.mu01 : r;
+            };
+            if (renorm) {
+                double e0, f;
+                pair_of(fabs(r0), e0, f);
+                a0 = e0;
+                a1 = f * x.kappa_over_mu01;
+                A1[0] = a1;
+#pragma unroll  // (a rolled loop would index A1 dynamically and send the whole array -- the hot path's too -- to scratch)
                 for (int k = 1; k < W; ++k) {
-                    const double r = fabs(rrs[k]);
+                    pair_of(fabs(rrs[k]), e0, f);
                     const double t = a0 + a1;
-                    a1 = fma(a1, rho, a0) * r;
-                    a0 = t;
+                    a1 = fma(a1, rho, a0) * f;
+                    a0 = t * e0;
                     A1[k] = a1;
                 }
-                asm volatile("" ::: "memory");  // re-read the slot constants in the backward pass (VGPRs)
-                double b0, b1;
-                {
-                    const double z = fma(a1, x.inv_kappa, a0);
-                    double r = __builtin_amdgcn_rcp(z);
-                    r = fma(fma(-z, r, 1.0), r, r);
-                    b0 = r0 < 0.0 ? r : 0.0;  // (the sign bit: a window may start here)
-                    b1 = b0 * x.inv_kappa;
-                }
+                z = fma(a1, x.inv_kappa, a0);
+            }
+            double b0, b1;
+            {
+                double r = __builtin_amdgcn_rcp(z);
+                r = fma(fma(-z, r, 1.0), r, r);
+                b0 = r0 < 0.0 ? r : 0.0;  // (the sign bit: a window may start here)
+                b1 = b0 * x.inv_kappa;
+            }
+            if (!renorm) {
 #pragma unroll
                 for (int k = W - 1; k >= 0; --k) {
                     const double cand = A1[k] * b1;
@@ -392,6 +360,23 @@ struct Stream {
                         const double u = fabs(rrs[k]) * b1;
                         b1 = fma(u, rho, b0);
                         b0 = b0 + u;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = W - 1; k >= 0; --k) {
+                    const double cand = A1[k] * b1;
+                    if (k < W - 1) {
+                        if (lane == 63) crow[k] = Rb;
+                        Rb = wave_shr1_zero(Rb);
+                    }
+                    Rb = max_nocanon(Rb, cand);
+                    if (k > 0) {
+                        double e0, f;
+                        pair_of(fabs(rrs[k]), e0, f);
+                        const double ce = e0 * b0, u = f * b1;
+                        b0 = ce + u;
+                        b1 = fma(u, rho, ce);
                     }
                 }
             }
@@ -427,9 +412,8 @@ __global__ void __launch_bounds__(NT, GECCO_STREAM_OCC) crf_windowed_stream_l2(c
     __shared__ int32_t IDS[K::PCAP];
     __shared__ int32_t GP[NT + 1];
     __shared__ double CARRY[(K::NW + 1) * (W - 1)];
-    __shared__ int32_t FLAG;
     __shared__ uint32_t AB[PH + 2];
-    const typename K::Smem m{R, PARK, IDS, GP, CARRY, &FLAG, AB};
+    const typename K::Smem m{R, PARK, IDS, GP, CARRY, AB};
 
     typename K::State x;
     x.tid = threadIdx.x;
@@ -445,7 +429,6 @@ __global__ void __launch_bounds__(NT, GECCO_STREAM_OCC) crf_windowed_stream_l2(c
         x.irregular = (td.w & 1) ? 0 : 1;
         if (x.irregular) x.shift = 0;
     }
-    if (x.tid == 0) FLAG = 0;
     const uint32_t nnz = uint32_t(P.gene_ptr[P.n_genes]);
     x.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(P.attr_id), 0, min(nnz, 0x3FFFFFFFu) << 2, 0x00020000);
     x.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(P.wtab2), 0, uint32_t(P.A) << 4, 0x00020000);
@@ -457,7 +440,7 @@ __global__ void __launch_bounds__(NT, GECCO_STREAM_OCC) crf_windowed_stream_l2(c
     // four separate register pairs, not sub-registers of the 8-dword tuple the argument load produced: the tuple is
     // spilled and reloaded as a whole (eight v_readlane per use of rho)
     asm volatile("" : "+s"(x.rho), "+s"(x.mu01), "+s"(x.kappa_over_mu01), "+s"(x.inv_kappa));
-    x.sticky = 0;
+    x.force_renorm = 0;
     x.out_g = -1;
     x.out_p = 0.0;
 

@@ -222,27 +222,30 @@ def test_other_tiles_per_workgroup_geometries(nat, real_model, oracle_model, mon
 
 def test_ratio_form_guard_at_its_limit(nat):
     """The fixed-window kernel takes the ratio form of the DP (one constant per slot, vectors growing
-    like exp(sum of positive score differences)) only in workgroups whose slots all have
-    s[label] - s[other] <= 600 / W.  Runs of genes just below the limit (sum = 598 over a window),
-    just above it (max-normalised form) and strongly negative ones must all match the oracle."""
+    like exp(sum of positive score differences)) only in workgroups where no window can exceed a sum of
+    600: slots up to 200 / W = 10 add at most 200 per window, the differences of all other slots of the
+    workgroup must add up to at most 400.  Runs just below either limit (a window at e^(198 + 389)),
+    just above (max-normalised form), long saturated runs and strongly negative ones must all match the oracle."""
     from oracle import crf_oracle as orc
     from gecco_amd import synth
 
-    w = np.zeros((6, 2))
-    w[0] = (0.0, 29.9)    # d = +29.9: ratio form, e^598 inside a window
-    w[1] = (0.0, 30.1)    # d = +30.1: guard trips
+    w = np.zeros((7, 2))
+    w[0] = (0.0, 29.9)    # d = +29.9: a leaning slot; 13 of them add up to 388.7 <= 400, 14 to 418.6
+    w[1] = (0.0, 30.1)
     w[2] = (0.0, -50.0)
     w[3] = (700.0, 0.0)   # d = -700: exp underflows to 0
     w[4] = (1.0, 0.5)
+    w[5] = (0.0, 9.9)     # d = +9.9: not leaning; twenty of them put 198 into a window
     model = nat.Model.from_tables(w, synth.EMBEDDED_TRANS)
     rng = np.random.default_rng(1)
     runs = []
-    for a, n in [(0, 600), (4, 300), (1, 600), (2, 50), (0, 40), (3, 30), (4, 700), (1, 25), (0, 500)]:
+    for a, n in [(0, 600), (4, 300), (1, 600), (2, 50), (0, 40), (3, 30), (4, 700), (1, 25), (0, 500),
+                 (4, 900), (5, 40), (0, 13), (5, 40), (4, 900), (5, 30), (0, 14), (5, 30), (4, 900), (0, 6), (5, 60), (0, 7), (4, 700)]:
         runs += [a] * n
     runs = np.array(runs + list(rng.integers(0, 5, size=800)), dtype=np.int32)
     n = len(runs)
     gptr = np.arange(n + 1, dtype=np.int32)
-    cptr = np.array([0, 900, 2500, n], dtype=np.int32)
+    cptr = np.array([0, 900, 2500, 3645, n], dtype=np.int32)
     for label in (1, 0):
         got = model.windowed_marginals(cptr, gptr, runs, 20, 1, label, True)
         exp = orc.windowed_marginals(w, synth.EMBEDDED_TRANS, cptr, gptr, runs, 20, 1, label, True)
