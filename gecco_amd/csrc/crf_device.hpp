@@ -261,6 +261,11 @@ struct GenArgs {
 };
 hipError_t launch_gen_state(const GenArgs &a, hipStream_t stream);
 hipError_t launch_gen_windowed(const GenArgs &a, hipStream_t stream);   // p_out must be zeroed first
+// 3 or 4 labels: one lane per window start (the two-label kernel's design); tile geometry gen_small_tile_out(W)
+bool gen_small_ok(int L, int W, const double *trans_host);
+int gen_small_tile_out(int W);
+hipError_t launch_gen_windowed_small(const GenArgs &a, const double *trans_host, const int4 *d_tile_desc, int ntiles,
+                                     hipStream_t stream);
 hipError_t launch_gen_marginals(const GenArgs &a, hipStream_t stream);
 hipError_t launch_gen_viterbi(const GenArgs &a, hipStream_t stream);
 int gen_chunk_genes();

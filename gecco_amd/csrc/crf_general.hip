@@ -142,6 +142,134 @@ __global__ void __launch_bounds__(kGT) gl_windowed(GenArgs a) {
     }
 }
 
+// ---- rows A/B, P, W for a handful of labels (3 or 4): the two-label kernel's design ---------------------------------
+// One LANE per window start, everything of the window in its registers (crf_kernels.hip): with L <= 4 the vectors are
+// L doubles, a step is L*L FMAs + L multiplications, and a group of lanes exchanging vector components through LDS --
+// the kernel above, written for up to 32 labels -- spends most of its time on that exchange (1.6 G genes/s at L = 3).
+//   * un-normalised recurrences on max-normalised factors (exp(state - max state): gl_state; exp(trans - max trans)):
+//     alpha_k . beta_k = Z at every position of the window, so the marginal of the queried label is
+//     alpha_k[label] beta_k[label] / Z with 1/Z folded into the initial beta; only alpha_k[label] is kept (W doubles).
+//     The host checks that W - 1 steps cannot leave the range (spread of the transition weights * (W - 1) < 600);
+//     models beyond that take the kernel above.  Labels are permuted so that the queried one is component 0.
+//   * the maximum over the windows that cover a gene is the DPP diagonal of the two-label kernel (running best shifted
+//     one lane up per step, hand-over between waves through LDS): no atomics, p_out written once.
+//   * a workgroup of 256 window starts owns 256 - (W - 1) output slots; the emissions of its 256 + (W - 1) slots are
+//     staged in LDS once (regular tiles: slots map to genes by a constant shift; others look every slot up).
+constexpr int kSmallNT = 256;
+__device__ __forceinline__ double gl_wave_shr1_zero(double v) {  // lane l <- lane l-1, lane 0 <- +0.0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+struct SmallTrans {
+    double m[16];  // exp(trans - max), labels permuted (queried label first), row-major L x L
+};
+template <int L, int WMAX>
+__global__ void __launch_bounds__(kSmallNT) gl_windowed_small(GenArgs a, SmallTrans T, const int4 *__restrict__ tile_desc) {
+    constexpr int NT = kSmallNT, CAP = NT + WMAX - 1;
+    __shared__ double Es[L * CAP];       // emissions of the tile's slots, one row per label (conflict-free lane stride)
+    __shared__ uint32_t ginfo[CAP];      // bit 31: a window may start here; low bits: gene + 1 (0: none)
+    __shared__ double carry[(NT / 64) * WMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = a.W, OUT = NT - (W - 1), ns = NT + W - 1;
+    const int q0 = blockIdx.x * OUT - (W - 1);
+    const int4 td = tile_desc[blockIdx.x];
+    // queried label first, the others in their own order
+    int perm[L];
+    perm[0] = a.label;
+#pragma unroll
+    for (int j = 1; j < L; ++j) perm[j] = j <= a.label ? j - 1 : j;
+    for (int sl = tid; sl < ns; sl += NT) {
+        const int q = q0 + sl;
+        int gene = -1;
+        bool start = false;
+        if (q >= 0 && q < a.S) {
+            start = (a.start_bits[q >> 6] >> (q & 63)) & 1ull;
+            if (td.w & 1) {
+                gene = q + td.x;
+            } else {
+                int lo = td.y, hi = td.z;  // largest k with c_slot[k] <= q among the contigs in reach
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (a.c_slot[mid] <= q) lo = mid; else hi = mid - 1;
+                }
+                const int pos = q - a.c_slot[lo], np = a.c_slot[lo + 1] - a.c_slot[lo], n = a.c_n[lo];
+                const int gl = pos - ((np - n) >> 1);  // delta // 2 empty items in front (crf/__init__.py:227)
+                if (gl >= 0 && gl < n) gene = a.c_gene[lo] + gl;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < L; ++j)  // padding items have no attributes: state 0, exp(0 - 0) = 1
+            Es[j * CAP + sl] = gene >= 0 ? a.E[size_t(gene) * L + perm[j]] : 1.0;
+        ginfo[sl] = (start ? 0x80000000u : 0u) | uint32_t(gene + 1);
+    }
+    __syncthreads();
+    const uint32_t gi = ginfo[tid];
+    const bool my_start = gi >> 31;
+    const int my_gene = int(gi & 0x7fffffffu) - 1;
+    const double *es = Es + tid;
+    // forward: alpha_0 = E_0; alpha_k[j] = (sum_i alpha_{k-1}[i] M[i][j]) E_k[j]
+    double al[L], A0[WMAX];
+#pragma unroll
+    for (int j = 0; j < L; ++j) al[j] = es[j * CAP];
+    A0[0] = al[0];
+#pragma unroll
+    for (int k = 1; k < WMAX; ++k) {
+        if (k < W) {
+            double nx[L];
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                double acc = al[0] * T.m[j];
+#pragma unroll
+                for (int i = 1; i < L; ++i) acc = fma(al[i], T.m[i * L + j], acc);
+                nx[j] = acc * es[j * CAP + k];
+            }
+#pragma unroll
+            for (int j = 0; j < L; ++j) al[j] = nx[j];
+            A0[k] = al[0];
+        }
+    }
+    asm volatile("" ::: "memory");  // re-read the emissions in the backward pass (VGPRs)
+    double z = al[0];
+#pragma unroll
+    for (int j = 1; j < L; ++j) z += al[j];
+    double rz = __builtin_amdgcn_rcp(z);
+    rz = fma(fma(-z, rz, 1.0), rz, rz);
+    double be[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) be[j] = my_start ? rz : 0.0;  // beta_{W-1} = 1, times 1/Z; lanes that start no window: 0
+    double R = 0.0;
+#pragma unroll
+    for (int k = WMAX - 1; k >= 0; --k) {
+        if (k < W) {
+            const double cand = A0[k] * be[0];
+            if (k < W - 1) {
+                if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
+                R = gl_wave_shr1_zero(R);
+            }
+            R = fmax(R, cand);
+            if (k > 0) {  // beta_{k-1}[i] = sum_j M[i][j] E_k[j] beta_k[j]
+                double u[L];
+#pragma unroll
+                for (int j = 0; j < L; ++j) u[j] = es[j * CAP + k] * be[j];
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    double acc = T.m[i * L] * u[0];
+#pragma unroll
+                    for (int j = 1; j < L; ++j) acc = fma(T.m[i * L + j], u[j], acc);
+                    be[i] = acc;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave > 0 && lane < W - 1) R = fmax(R, carry[(wave - 1) * WMAX + lane]);
+    R = fmin(R, 1.0);
+    // genes no window covers (step > 1) keep 0.0 like numpy.zeros (crf/__init__.py:251)
+    if (tid >= W - 1 && my_gene >= 0) a.p_out[my_gene] = R;
+}
+
 // ---- row F: whole-contig marginals, one group per contig, CRFsuite's own sequential recursion ----
 template <int LP>
 __global__ void __launch_bounds__(kGT) gl_marginals_seq(GenArgs a) {
@@ -707,6 +835,44 @@ hipError_t launch_any(int what, const GenArgs &a, hipStream_t stream) {
 }  // namespace
 
 hipError_t launch_gen_state(const GenArgs &a, hipStream_t stream) { return launch_any(0, a, stream); }
+int gen_small_tile_out(int W) { return kSmallNT - (W - 1); }
+
+// the lane-per-window kernel takes 3 or 4 labels, windows of up to 32 genes and transition weights whose spread
+// cannot take W - 1 un-normalised steps out of the range
+bool gen_small_ok(int L, int W, const double *trans_host) {
+    if ((L != 3 && L != 4) || W < 1 || W > 32 || !trans_host) return false;
+    double lo = trans_host[0], hi = trans_host[0];
+    for (int i = 0; i < L * L; ++i) {
+        lo = trans_host[i] < lo ? trans_host[i] : lo;
+        hi = trans_host[i] > hi ? trans_host[i] : hi;
+    }
+    return hi - lo == hi - lo && (hi - lo) * double(W - 1) < 600.0;  // (finite)
+}
+
+hipError_t launch_gen_windowed_small(const GenArgs &a, const double *trans_host, const int4 *d_tile_desc, int ntiles,
+                                     hipStream_t stream) {
+    if (ntiles <= 0) return hipSuccess;
+    const int L = a.L;
+    SmallTrans T{};
+    double mx = trans_host[0];
+    for (int i = 0; i < L * L; ++i) mx = trans_host[i] > mx ? trans_host[i] : mx;
+    int perm[4];
+    perm[0] = a.label;
+    for (int j = 1; j < L; ++j) perm[j] = j <= a.label ? j - 1 : j;
+    for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j) T.m[i * L + j] = exp(trans_host[perm[i] * L + perm[j]] - mx);
+    const dim3 grid(ntiles), block(kSmallNT);
+    if (L == 3 && a.W <= 20)
+        hipLaunchKernelGGL((gl_windowed_small<3, 20>), grid, block, 0, stream, a, T, d_tile_desc);
+    else if (L == 3)
+        hipLaunchKernelGGL((gl_windowed_small<3, 32>), grid, block, 0, stream, a, T, d_tile_desc);
+    else if (a.W <= 20)
+        hipLaunchKernelGGL((gl_windowed_small<4, 20>), grid, block, 0, stream, a, T, d_tile_desc);
+    else
+        hipLaunchKernelGGL((gl_windowed_small<4, 32>), grid, block, 0, stream, a, T, d_tile_desc);
+    return hipGetLastError();
+}
+
 hipError_t launch_gen_windowed(const GenArgs &a, hipStream_t stream) {
     if (a.W > kGenMaxW) return hipErrorNotSupported;
     return launch_any(1, a, stream);

@@ -236,6 +236,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
         return GECCO_CRF_EINVAL;
     }
     p.decode_graph.reset();  // (device pointers of the previous layout are baked into it)
+    p.gen_small = false;
     p.model = &m;
     p.device = device;
     p.W = W;
@@ -348,6 +349,11 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     if (p.stream_phases) {
         p.kernel_name = "crf_windowed_stream_l2<20>";
         p.tile_out = windowed_stream_tile_out(W, p.stream_phases);
+    } else if (p.general && gen_small_ok(m.L, W, m.trans.data()) && !std::getenv("GECCO_CRF_GENERAL_GROUPS")) {
+        // a handful of labels: one lane per window start (GECCO_CRF_GENERAL_GROUPS=1: the lane-group kernel, tests / A/B)
+        p.kernel_name = "gl_windowed_small";
+        p.gen_small = true;
+        p.tile_out = gen_small_tile_out(W);
     } else {
         p.kernel_name = p.general ? "gl_windowed" : windowed_kernel_name(W, m.L, p.fast_ok);
         p.tile_out = windowed_tile_out(W, m.L, p.tiles_per_wg);
@@ -432,13 +438,23 @@ int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, 
     const size_t b_vec = align256g(n * L * 8 + 8), b_one = align256g(n * 8 + 8), b_back = align256g(n * L + 8);
     // chunk tables of the long-contig path, built on the host (n / 64 entries)
     std::vector<int32_t> ch_g0, ch_contig, cc_ptr;
-    bool chunked = false;
+    // Whole-contig recursions go through the chunked kernels for EVERY batch (round 3): a contig-sequential group of lanes
+    // is a dependent chain as long as the contig, and a batch of 200-gene contigs has three to seven chunks' worth of
+    // parallelism inside every contig (1 000 contigs x 200 genes, L = 3: Viterbi 0.40 -> 1.5 G genes/s, marginals 0.17 ->
+    // 1.1 G).  Chunks of 32 genes for batches of short contigs, 64 when a contig is longer than kGenLongContig (the walk
+    // over a contig's chunks is the serial part).  GECCO_CRF_GENERAL_CHUNKED=0: the contig-sequential kernels (tests).
+    bool chunked = whole_contig;
+    bool has_long = false;
     if (whole_contig) {
-        for (int32_t c = 0; c < p.n_contigs && !chunked; ++c) chunked = p.contig_ptr[c + 1] - p.contig_ptr[c] > kGenLongContig;
+        for (int32_t c = 0; c < p.n_contigs && !has_long; ++c) has_long = p.contig_ptr[c + 1] - p.contig_ptr[c] > kGenLongContig;
         if (const char *env = std::getenv("GECCO_CRF_GENERAL_CHUNKED")) chunked = env[0] == '1';  // tests: force either path
     }
     if (chunked) {
-        const int32_t C = gen_chunk_genes();
+        int32_t C = has_long ? gen_chunk_genes() : gen_chunk_genes() / 2;
+        if (const char *env = std::getenv("GECCO_CRF_GENERAL_CHUNK")) {
+            const int v = std::atoi(env);
+            if (v >= 4 && v <= 4096) C = v;
+        }
         cc_ptr.push_back(0);
         for (int32_t c = 0; c < p.n_contigs; ++c) {
             for (int32_t g = p.contig_ptr[c]; g < p.contig_ptr[c + 1]; g += C) {
@@ -536,6 +552,8 @@ int run_windowed_general(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_at
     a.state = nullptr;  // marginals only need exp(state - max)
     if ((rc = check_hip(launch_gen_state(a, stream), "state score launch"))) return rc;
     a.state = keep_state;
+    if (p.gen_small)
+        return check_hip(launch_gen_windowed_small(a, p.model->trans.data(), p.d_tile_desc, p.ntiles, stream), "windowed launch");
     return check_hip(launch_gen_windowed(a, stream), "windowed launch");
 }
 }  // namespace

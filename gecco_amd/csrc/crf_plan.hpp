@@ -54,6 +54,7 @@ struct Plan {
     bool fast_ok = false;       // the register-resident kernel takes this shape
     bool force_generic = false; // GECCO_CRF_FORCE_GENERIC=1 (tests): always use the generic kernel
     bool general = false;       // any-L kernels (crf_general.hip): L != 2, or GECCO_CRF_FORCE_GENERAL=1 (tests)
+    bool gen_small = false;     // ... 3 or 4 labels: the lane-per-window kernel (gl_windowed_small) and its tile geometry
     std::string kernel_name;
     // device copies (all inside `tables`)
     Arena tables;

@@ -37,7 +37,7 @@ def main():
     dev = torch.device("cuda:0")
     d_gp = torch.from_numpy(gptr).to(dev)
     d_at = torch.from_numpy(attr).to(dev)
-    for L in (2, 3, 8, 32):
+    for L in (2, 3, 4, 8, 32):
         if L == 2:
             w, trans = synth.synth_model(A, rng)
             os.environ["GECCO_CRF_FORCE_GENERAL"] = "1"
