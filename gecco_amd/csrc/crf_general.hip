@@ -505,83 +505,120 @@ __global__ void __launch_bounds__(kGT) gl_chunk_rows(GenArgs a) {
     if (!MAXPLUS && j == 0) a.chEx[static_cast<size_t>(ci) * L + i] = ex;
 }
 
-// forward over the chunks of a contig: the vector entering every chunk (normalised alpha of the gene before
-// it / delta of the gene before it)
+// The walks over the chunks of a contig: forwards, the vector entering every chunk (normalised alpha / delta of the gene
+// before it); backwards (marginals), beta of the last gene of every chunk up to a factor.  One group of lanes per contig
+// and direction (blockIdx.y), n / chunk dependent steps.  A step is a few dozen instructions; what it waited for in
+// round 2 was the load of the chunk's matrix (~0.7 us from L2/HBM per step: 41 us for the 64 chunks of the longest contig
+// of a 1 000-contig batch, 0.5 ms for a 50 000-gene contig).  The matrices do not depend on the walk, so a lane fetches
+// its column (row) of the next kWalkAhead chunks in one go and then takes those steps from registers.
+template <int LP>
+struct WalkAhead {
+    static constexpr int B = LP <= 4 ? 8 : LP == 8 ? 4 : LP == 16 ? 2 : 1;
+};
+
 template <int LP, bool MAXPLUS>
-__global__ void __launch_bounds__(kGT) gl_chunk_vecs_fwd(GenArgs a) {
-    __shared__ double vecs[kGT];
-    constexpr int G = kGT / LP;
-    const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
-    double *vec = vecs + grp * LP;
+__device__ __forceinline__ void chunk_walk_fwd(const GenArgs &a, long long ct, int j, double *vec) {
+    constexpr int B = WalkAhead<LP>::B;
     const int L = a.L;
-    const long long ct = static_cast<long long>(blockIdx.x) * G + grp;
-    if (ct >= a.n_contigs) return;
     const bool on = j < L;
     const double ninf = -__builtin_huge_val();
     const int c0 = a.cc_ptr[ct], c1 = a.cc_ptr[ct + 1];
     double v = MAXPLUS ? (j == 0 ? 0.0 : ninf) : (j == 0 ? 1.0 : 0.0);
-    for (int c = c0; c < c1; ++c) {
-        if (on) a.chV[static_cast<size_t>(c) * L + j] = v;
-        if (c + 1 == c1) break;
-        const double *M = a.chM + static_cast<size_t>(c) * L * L;
-        double w = v;
-        if (!MAXPLUS) {  // rows carry their own power-of-two exponents
-            const int exj = on ? a.chEx[static_cast<size_t>(c) * L + j] : 0;
-            const double exm = group_max<LP>((on && v > 0.0) ? double(exj) : -1e300);
-            w = (on && v > 0.0) ? ldexp(v, exj - int(exm)) : 0.0;
+    for (int cb = c0; cb < c1; cb += B) {
+        double mc[B][LP];
+        int ex[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int c = cb + b;
+            const bool live = on && c + 1 < c1;  // (nothing leaves the contig's last chunk)
+            const double *M = a.chM + static_cast<size_t>(c) * L * L;
+#pragma unroll
+            for (int k = 0; k < LP; ++k) mc[b][k] = (live && k < L) ? M[static_cast<size_t>(k) * L + j] : (MAXPLUS ? ninf : 0.0);
+            ex[b] = (!MAXPLUS && live) ? a.chEx[static_cast<size_t>(c) * L + j] : 0;
         }
-        vec[j] = w;
-        __builtin_amdgcn_wave_barrier();
-        double acc = MAXPLUS ? ninf : 0.0;
-        for (int k = 0; k < L; ++k) {
-            const double mkj = on ? M[static_cast<size_t>(k) * L + j] : (MAXPLUS ? ninf : 0.0);
-            acc = MAXPLUS ? fmax(acc, vec[k] + mkj) : fma(vec[k], mkj, acc);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (MAXPLUS) {
-            v = acc;
-        } else {
-            const double sm = group_sum<LP>(on ? acc : 0.0);
-            v = sm != 0.0 ? acc / sm : acc;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int c = cb + b;
+            if (c < c1) {
+                if (on) a.chV[static_cast<size_t>(c) * L + j] = v;
+                if (c + 1 < c1) {
+                    double w = v;
+                    if (!MAXPLUS) {  // rows carry their own power-of-two exponents
+                        const double exm = group_max<LP>((on && v > 0.0) ? double(ex[b]) : -1e300);
+                        w = (on && v > 0.0) ? ldexp(v, ex[b] - int(exm)) : 0.0;
+                    }
+                    vec[j] = w;
+                    __builtin_amdgcn_wave_barrier();
+                    double acc = MAXPLUS ? ninf : 0.0;
+#pragma unroll
+                    for (int k = 0; k < LP; ++k)
+                        if (k < L) acc = MAXPLUS ? fmax(acc, vec[k] + mc[b][k]) : fma(vec[k], mc[b][k], acc);
+                    __builtin_amdgcn_wave_barrier();
+                    if (MAXPLUS) {
+                        v = acc;
+                    } else {
+                        const double sm = group_sum<LP>(on ? acc : 0.0);
+                        v = sm != 0.0 ? acc / sm : acc;
+                    }
+                }
+            }
         }
     }
 }
 
-// backward over the chunks of a contig (marginals): beta of the last gene of every chunk, up to a factor;
-// also the contig's log-partition from the chunks' partial sums
 template <int LP>
-__global__ void __launch_bounds__(kGT) gl_chunk_vecs_bwd(GenArgs a) {
+__device__ __forceinline__ void chunk_walk_bwd(const GenArgs &a, long long ct, int j, double *vec) {
+    constexpr int B = WalkAhead<LP>::B;
+    const int L = a.L;
+    const bool on = j < L;
+    const int c0 = a.cc_ptr[ct], c1 = a.cc_ptr[ct + 1];
+    double bt = 1.0;
+    for (int cb = c1 - 1; cb >= c0; cb -= B) {
+        double mr[B][LP];
+        int ex[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int c = cb - b;
+            const bool live = on && c > c0;  // (nothing is in front of the contig's first chunk)
+            const double *row = a.chM + (static_cast<size_t>(live ? c : c0) * L + (on ? j : 0)) * L;
+#pragma unroll
+            for (int k = 0; k < LP; ++k) mr[b][k] = (live && k < L) ? row[k] : 0.0;
+            ex[b] = live ? a.chEx[static_cast<size_t>(c) * L + j] : 0;
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int c = cb - b;
+            if (c >= c0) {
+                if (on) a.chB[static_cast<size_t>(c) * L + j] = bt;
+                if (c > c0) {  // beta of the gene before the chunk = M_c beta: lane j takes row j
+                    vec[j] = on ? bt : 0.0;
+                    __builtin_amdgcn_wave_barrier();
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < LP; ++k)
+                        if (k < L) acc = fma(mr[b][k], vec[k], acc);
+                    __builtin_amdgcn_wave_barrier();
+                    const double exm = group_max<LP>((on && acc > 0.0) ? double(ex[b]) : -1e300);
+                    acc = (on && acc > 0.0) ? ldexp(acc, ex[b] - int(exm)) : 0.0;
+                    const double mx = group_max<LP>(acc);
+                    bt = mx > 0.0 ? acc / mx : 1.0;
+                }
+            }
+        }
+    }
+}
+
+template <int LP, bool MAXPLUS>
+__global__ void __launch_bounds__(kGT) gl_chunk_vecs(GenArgs a) {
     __shared__ double vecs[kGT];
     constexpr int G = kGT / LP;
     const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
-    double *vec = vecs + grp * LP;
-    const int L = a.L;
     const long long ct = static_cast<long long>(blockIdx.x) * G + grp;
     if (ct >= a.n_contigs) return;
-    const bool on = j < L;
-    const int c0 = a.cc_ptr[ct], c1 = a.cc_ptr[ct + 1];
-    if (j == 0 && a.lognorm) {
-        double z = 0.0;
-        for (int c = c0; c < c1; ++c) z += a.chZ[c];
-        a.lognorm[ct] = z;
-    }
-    double b = 1.0;
-    for (int c = c1 - 1; c >= c0; --c) {
-        if (on) a.chB[static_cast<size_t>(c) * L + j] = b;
-        if (c == c0) break;
-        // beta of the gene before the chunk = M_c beta: lane j takes row j
-        const double *row = a.chM + (static_cast<size_t>(c) * L + (on ? j : 0)) * L;
-        vec[j] = on ? b : 0.0;
-        __builtin_amdgcn_wave_barrier();
-        double acc = 0.0;
-        for (int k = 0; k < L; ++k) acc = fma(row[k], vec[k], acc);
-        __builtin_amdgcn_wave_barrier();
-        const int exj = on ? a.chEx[static_cast<size_t>(c) * L + j] : 0;
-        const double exm = group_max<LP>((on && acc > 0.0) ? double(exj) : -1e300);
-        acc = (on && acc > 0.0) ? ldexp(acc, exj - int(exm)) : 0.0;
-        const double mx = group_max<LP>(acc);
-        b = mx > 0.0 ? acc / mx : 1.0;
-    }
+    if (MAXPLUS || blockIdx.y == 0)
+        chunk_walk_fwd<LP, MAXPLUS>(a, ct, j, vecs + grp * LP);
+    else
+        chunk_walk_bwd<LP>(a, ct, j, vecs + grp * LP);
 }
 
 // CRFsuite's forward recursion inside a chunk, from the vector that enters it
@@ -643,6 +680,15 @@ __global__ void __launch_bounds__(kGT) gl_chunk_bwd(GenArgs a) {
     double mrow[LP];
 #pragma unroll
     for (int k = 0; k < LP; ++k) mrow[k] = (k < L && on) ? a.exp_trans[j * L + k] : 0.0;
+    if (a.lognorm) {  // the contig's log-partition from the chunks' partial sums: the group of its first chunk adds them up
+        const int ct = a.ch_contig[ci];
+        if (g0 == a.contig_ptr[ct]) {
+            double z = 0.0;
+            for (int c = a.cc_ptr[ct] + j; c < a.cc_ptr[ct + 1]; c += LP) z += a.chZ[c];
+            z = group_sum<LP>(z);
+            if (j == 0) a.lognorm[ct] = z;
+        }
+    }
     double b = on ? a.chB[static_cast<size_t>(ci) * L + j] : 0.0;
     for (int t = g1 - 1; t >= g0; --t) {
         const double al = on ? a.alpha[static_cast<size_t>(t) * L + j] : 0.0;
@@ -736,16 +782,35 @@ __global__ void __launch_bounds__(kGT) gl_chunk_maps(GenArgs a) {
     a.chMap[static_cast<size_t>(ci) * L + j] = static_cast<uint8_t>(y);
 }
 
-// per contig: the label of every chunk's last gene, back to front (n / kChunk dependent steps)
+// per contig: the label of every chunk's last gene, back to front (n / chunk dependent steps).  One wave per contig:
+// the maps of up to kEndsTile / L chunks are fetched into LDS in one go (they do not depend on the walk), then lane 0
+// follows them there -- a step is an LDS read (~50 ns) instead of a dependent global load (~0.7 us).
+constexpr int kEndsTile = 2048;  // bytes of chunk maps per wave and round
 __global__ void __launch_bounds__(kGT) gl_chunk_ends(GenArgs a) {
-    const long long ct = static_cast<long long>(blockIdx.x) * kGT + threadIdx.x;
+    __shared__ uint8_t maps[(kGT / 64) * kEndsTile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long ct = static_cast<long long>(blockIdx.x) * (kGT / 64) + wave;
     if (ct >= a.n_contigs) return;
+    const int L = a.L;
     const int c0 = a.cc_ptr[ct], c1 = a.cc_ptr[ct + 1];
     if (c1 <= c0) return;
+    uint8_t *mp = maps + wave * kEndsTile;
+    const int T = kEndsTile / L;  // chunks per round
     int y = a.chY[c1 - 1];
-    for (int c = c1 - 1; c > c0; --c) {
-        y = a.chMap[static_cast<size_t>(c) * a.L + y];
-        a.chY[c - 1] = static_cast<int8_t>(y);
+    for (int hi = c1 - 1; hi > c0; hi -= T) {  // chunks (lo, hi] map their last label to the label before them
+        const int lo = hi - T > c0 ? hi - T : c0;
+        const uint8_t *src = a.chMap + static_cast<size_t>(lo + 1) * L;
+        const int bytes = (hi - lo) * L;
+        for (int o = lane; o < bytes; o += 64) mp[o] = src[o];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            for (int c = hi; c > lo; --c) {
+                y = mp[(c - lo - 1) * L + y];
+                a.chY[c - 1] = static_cast<int8_t>(y);
+            }
+        }
+        y = __shfl(y, 0);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -771,16 +836,15 @@ hipError_t launch_chunked(int what, const GenArgs &a, hipStream_t stream) {
     if (a.n_chunks <= 0) return hipSuccess;
     if (what == 2) {
         hipLaunchKernelGGL((gl_chunk_rows<LP, false>), blocks(rows, G), dim3(kGT), 0, stream, a);
-        hipLaunchKernelGGL((gl_chunk_vecs_fwd<LP, false>), blocks(a.n_contigs, G), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL((gl_chunk_vecs<LP, false>), dim3(blocks(a.n_contigs, G).x, 2), dim3(kGT), 0, stream, a);
         hipLaunchKernelGGL(gl_chunk_fwd<LP>, blocks(a.n_chunks, G), dim3(kGT), 0, stream, a);
-        hipLaunchKernelGGL(gl_chunk_vecs_bwd<LP>, blocks(a.n_contigs, G), dim3(kGT), 0, stream, a);
         hipLaunchKernelGGL(gl_chunk_bwd<LP>, blocks(a.n_chunks, G), dim3(kGT), 0, stream, a);
     } else {
         hipLaunchKernelGGL((gl_chunk_rows<LP, true>), blocks(rows, G), dim3(kGT), 0, stream, a);
-        hipLaunchKernelGGL((gl_chunk_vecs_fwd<LP, true>), blocks(a.n_contigs, G), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL((gl_chunk_vecs<LP, true>), blocks(a.n_contigs, G), dim3(kGT), 0, stream, a);
         hipLaunchKernelGGL(gl_chunk_vit<LP>, blocks(a.n_chunks, G), dim3(kGT), 0, stream, a);
         hipLaunchKernelGGL(gl_chunk_maps<LP>, blocks(a.n_chunks, G), dim3(kGT), 0, stream, a);
-        hipLaunchKernelGGL(gl_chunk_ends, blocks(a.n_contigs, kGT), dim3(kGT), 0, stream, a);
+        hipLaunchKernelGGL(gl_chunk_ends, blocks(a.n_contigs, kGT / 64), dim3(kGT), 0, stream, a);
         hipLaunchKernelGGL(gl_chunk_backtrack, blocks(a.n_chunks, kGT), dim3(kGT), 0, stream, a);
     }
     return hipGetLastError();

@@ -145,6 +145,7 @@ Plan::~Plan() {
             (void)hipFree(d_seq_ws);
             (void)hipFree(d_win_scratch);
             (void)hipFree(d_gen_ws);
+            (void)hipFree(d_gen_tab);
             (void)hipFree(d_seg_ws);
             (void)hipSetDevice(prev);
         }
@@ -237,6 +238,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     }
     p.decode_graph.reset();  // (device pointers of the previous layout are baked into it)
     p.gen_small = false;
+    p.gen_tab_chunk = 0;  // (chunk tables of the previous contigs)
     p.model = &m;
     p.device = device;
     p.W = W;
@@ -436,39 +438,56 @@ int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, 
     const Model &m = *p.model;
     const size_t n = size_t(p.n_genes), L = size_t(m.L);
     const size_t b_vec = align256g(n * L * 8 + 8), b_one = align256g(n * 8 + 8), b_back = align256g(n * L + 8);
-    // chunk tables of the long-contig path, built on the host (n / 64 entries)
-    std::vector<int32_t> ch_g0, ch_contig, cc_ptr;
     // Whole-contig recursions go through the chunked kernels for EVERY batch (round 3): a contig-sequential group of lanes
     // is a dependent chain as long as the contig, and a batch of 200-gene contigs has three to seven chunks' worth of
     // parallelism inside every contig (1 000 contigs x 200 genes, L = 3: Viterbi 0.40 -> 1.5 G genes/s, marginals 0.17 ->
     // 1.1 G).  Chunks of 32 genes for batches of short contigs, 64 when a contig is longer than kGenLongContig (the walk
     // over a contig's chunks is the serial part).  GECCO_CRF_GENERAL_CHUNKED=0: the contig-sequential kernels (tests).
     bool chunked = whole_contig;
-    bool has_long = false;
-    if (whole_contig) {
-        for (int32_t c = 0; c < p.n_contigs && !has_long; ++c) has_long = p.contig_ptr[c + 1] - p.contig_ptr[c] > kGenLongContig;
+    if (whole_contig)
         if (const char *env = std::getenv("GECCO_CRF_GENERAL_CHUNKED")) chunked = env[0] == '1';  // tests: force either path
-    }
+    size_t nch = 0;
     if (chunked) {
+        // the chunk tables depend on the plan's contigs and the chunk length only: built and uploaded once
+        bool has_long = false;
+        for (int32_t c = 0; c < p.n_contigs && !has_long; ++c) has_long = p.contig_ptr[c + 1] - p.contig_ptr[c] > kGenLongContig;
         int32_t C = has_long ? gen_chunk_genes() : gen_chunk_genes() / 2;
         if (const char *env = std::getenv("GECCO_CRF_GENERAL_CHUNK")) {
             const int v = std::atoi(env);
             if (v >= 4 && v <= 4096) C = v;
         }
-        cc_ptr.push_back(0);
-        for (int32_t c = 0; c < p.n_contigs; ++c) {
-            for (int32_t g = p.contig_ptr[c]; g < p.contig_ptr[c + 1]; g += C) {
-                ch_g0.push_back(g);
-                ch_contig.push_back(c);
+        std::lock_guard<std::mutex> lock(p.ws_mutex);
+        if (!p.d_gen_tab || p.gen_tab_chunk != C) {
+            std::vector<int32_t> ch_g0, ch_contig, cc_ptr;
+            cc_ptr.push_back(0);
+            for (int32_t c = 0; c < p.n_contigs; ++c) {
+                for (int32_t g = p.contig_ptr[c]; g < p.contig_ptr[c + 1]; g += C) {
+                    ch_g0.push_back(g);
+                    ch_contig.push_back(c);
+                }
+                cc_ptr.push_back(int32_t(ch_g0.size()));
             }
-            cc_ptr.push_back(int32_t(ch_g0.size()));
+            ch_g0.push_back(p.n_genes);
+            const size_t n_ch = ch_contig.size();
+            const size_t o1 = align256g(ch_g0.size() * 4), o2 = o1 + align256g(n_ch * 4 + 4), total = o2 + align256g(cc_ptr.size() * 4);
+            if (p.d_gen_tab) (void)hipFree(p.d_gen_tab);
+            p.d_gen_tab = nullptr;
+            int rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_gen_tab), total), "hipMalloc chunk tables");
+            if (rc) return rc;
+            std::vector<char> img(total, 0);
+            std::memcpy(img.data(), ch_g0.data(), ch_g0.size() * 4);
+            std::memcpy(img.data() + o1, ch_contig.data(), n_ch * 4);
+            std::memcpy(img.data() + o2, cc_ptr.data(), cc_ptr.size() * 4);
+            if ((rc = check_hip(hipMemcpy(p.d_gen_tab, img.data(), total, hipMemcpyHostToDevice), "upload chunk tables"))) return rc;
+            p.gen_tab_chunk = C;
+            p.gen_tab_nch = n_ch;
+            p.gen_tab_off1 = o1;
+            p.gen_tab_off2 = o2;
         }
-        ch_g0.push_back(p.n_genes);
+        nch = p.gen_tab_nch;
     }
-    const size_t nch = chunked ? ch_contig.size() : 0;
-    const size_t b_tab = align256g((nch + 1) * 4) + align256g((nch + 1) * 4) + align256g((size_t(p.n_contigs) + 1) * 4);
     const size_t b_chM = align256g(nch * L * L * 8 + 8), b_chv = align256g(nch * L * 8 + 8), b_chs = align256g(nch * 8 + 8);
-    const size_t b_chunks = chunked ? b_tab + b_chM + 3 * b_chv + 2 * b_chs + 2 * align256g(nch * L + 8) : 0;
+    const size_t b_chunks = chunked ? b_chM + 3 * b_chv + 2 * b_chs + 2 * align256g(nch * L + 8) : 0;
     {
         std::lock_guard<std::mutex> lock(p.ws_mutex);
         int rc = grow_ws(p.d_gen_ws, p.gen_ws_cap, 3 * b_vec + 2 * b_one + b_back + b_chunks, "hipMalloc general-L workspace");
@@ -494,19 +513,9 @@ int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, 
     a.back = reinterpret_cast<uint8_t *>(w + 3 * b_vec + 2 * b_one);
     if (chunked && nch) {
         char *q = w + 3 * b_vec + 2 * b_one + b_back;
-        auto put = [&](const std::vector<int32_t> &v) {
-            int32_t *d = reinterpret_cast<int32_t *>(q);
-            q += align256g((v.size() + 1) * 4);
-            return std::make_pair(d, check_hip(hipMemcpyAsync(d, v.data(), v.size() * 4, hipMemcpyHostToDevice, stream), "upload chunk table"));
-        };
-        auto t0 = put(ch_g0), t1 = put(ch_contig), t2 = put(cc_ptr);
-        if (t0.second || t1.second || t2.second) return GECCO_CRF_EHIP;
-        // the tables are host vectors that die with this call: the copies must have left them
-        int rc = check_hip(hipStreamSynchronize(stream), "upload chunk table");
-        if (rc) return rc;
-        a.ch_g0 = t0.first;
-        a.ch_contig = t1.first;
-        a.cc_ptr = t2.first;
+        a.ch_g0 = reinterpret_cast<const int32_t *>(p.d_gen_tab);
+        a.ch_contig = reinterpret_cast<const int32_t *>(p.d_gen_tab + p.gen_tab_off1);
+        a.cc_ptr = reinterpret_cast<const int32_t *>(p.d_gen_tab + p.gen_tab_off2);
         a.n_chunks = int32_t(nch);
         a.chM = reinterpret_cast<double *>(q);
         q += b_chM;

@@ -78,6 +78,11 @@ struct Plan {
     char *d_seq_ws = nullptr, *d_gen_ws = nullptr, *d_seg_ws = nullptr;
     double *d_win_scratch = nullptr;
     size_t seq_ws_cap = 0, gen_ws_cap = 0, seg_ws_cap = 0, win_scratch_cap = 0;
+    // chunk tables of the any-L whole-contig kernels (first gene / contig of every chunk, chunks of every contig): they
+    // depend on the plan's contigs and the chunk length only, so they are built and uploaded on first use
+    char *d_gen_tab = nullptr;
+    int32_t gen_tab_chunk = 0;
+    size_t gen_tab_nch = 0, gen_tab_off1 = 0, gen_tab_off2 = 0;
     bool async_tables = false;  // the owner launches everything on ONE stream (batch driver): table uploads are not waited for
     bool tables_in_host_memory = false;  // the window kernel reads the plan tables from the pinned block itself (batch driver:
                                          // one copy and one inter-copy gap less per chunk; they are ~0.1 MB, read once)

@@ -87,6 +87,74 @@ def test_viterbi_ties_first_argmax(nat, L):
     assert np.array_equal(sc, esc)
 
 
+@pytest.mark.parametrize("L", [3, 4])
+def test_lane_per_window_kernel(nat, L, monkeypatch):
+    """3 and 4 labels take `gl_windowed_small` (one lane per window start, un-normalised recurrences, DPP maximum over
+    the covering windows): every label, windows from 1 to 32 genes, steps, unpadded short contigs (skipped: irregular
+    tiles), against the oracle and against the lane-group kernel (GECCO_CRF_GENERAL_GROUPS=1)."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(700 + L)
+    A = 200
+    w, trans = synth_model(A, rng, L=L)
+    lengths = LENGTHS + list(rng.integers(1, 60, size=40)) + [237, 238, 474, 475, 3000] + list(rng.integers(1, 400, size=30))
+    cptr, gptr, attr = synth_contigs(rng, lengths, A)
+    model = nat.Model.from_tables(w, trans)
+    assert nat.Plan(model, cptr, 20, 1, True, device=0).kernel_name == "gl_windowed_small"
+    cases = [(20, 1, True, lab) for lab in range(L)] + [(1, 1, True, 0), (2, 1, True, 1), (21, 1, True, 2), (32, 1, True, L - 1),
+                                                         (20, 7, True, 1), (20, 1, False, 0), (32, 5, False, 2), (5, 4, False, 1)]
+    for W, step, pad, label in cases:
+        got = model.windowed_marginals(cptr, gptr, attr, W, step, label, pad)
+        exp = orc.windowed_marginals(w, trans, cptr, gptr, attr, W, step, label, pad)
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.abs(got[ok] - exp[ok]).max() <= 1e-12, (L, W, step, pad, label)
+        monkeypatch.setenv("GECCO_CRF_GENERAL_GROUPS", "1")
+        other = model.windowed_marginals(cptr, gptr, attr, W, step, label, pad)
+        monkeypatch.delenv("GECCO_CRF_GENERAL_GROUPS")
+        assert np.abs(got[ok] - other[ok]).max() <= 1e-12, (L, W, step, pad, label)
+
+
+def test_lane_per_window_kernel_range_guard(nat):
+    """Its recurrences are un-normalised: transition weights whose spread times W - 1 stays under 600 keep every value
+    in range (checked at the limit, with state weights as extreme as CRFsuite models get); beyond, the scaled kernel."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(77)
+    A, L, W = 60, 3, 20
+    w = np.clip(rng.laplace(0.0, 6.0, size=(A, L)), -40.0, 40.0)
+    cptr, gptr, attr = synth_contigs(rng, [19, 20, 21, 300, 1000], A)
+    for spread, kernel in ((31.5, "gl_windowed_small"), (31.6, "gl_windowed"), (80.0, "gl_windowed")):
+        trans = rng.uniform(-1.0, 1.0, size=(L, L))
+        trans[1, 2] = trans.max() - spread  # (W - 1) * 31.5 = 598.5
+        trans[trans < trans[1, 2]] = trans[1, 2]
+        model = nat.Model.from_tables(w, trans)
+        assert nat.Plan(model, cptr, W, 1, True, device=0).kernel_name == kernel
+        for label in range(L):
+            got = model.windowed_marginals(cptr, gptr, attr, W, 1, label, True)
+            exp = orc.windowed_marginals(w, trans, cptr, gptr, attr, W, 1, label, True)
+            assert np.abs(got - exp).max() <= 1e-12, (spread, label)
+
+
+@pytest.mark.parametrize("L", [3, 8])
+def test_contig_sequential_kernels(nat, L, monkeypatch):
+    """GECCO_CRF_GENERAL_CHUNKED=0: one group of lanes walks a whole contig (round 2's default for short contigs; kept as
+    the strictly sequential form the chunked kernels are compared with)."""
+    from oracle import crf_oracle as orc
+
+    monkeypatch.setenv("GECCO_CRF_GENERAL_CHUNKED", "0")
+    w, trans, cptr, gptr, attr = _case(L, 600 + L, extra=10)
+    model = nat.Model.from_tables(w, trans)
+    marg, ln = model.marginals_full(cptr, gptr, attr)
+    emarg, eln = orc.full_marginals(w, trans, cptr, gptr, attr)
+    assert np.abs(marg - emarg).max() <= 1e-12
+    assert np.abs(ln - eln).max() <= 1e-10 * max(1.0, np.abs(eln).max())
+    y, sc = model.viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y.astype(np.int32), ey)
+    assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
+
+
 def test_three_labels_against_path_enumeration(nat):
     from oracle import crf_oracle as orc
 

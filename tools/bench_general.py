@@ -37,7 +37,8 @@ def main():
     dev = torch.device("cuda:0")
     d_gp = torch.from_numpy(gptr).to(dev)
     d_at = torch.from_numpy(attr).to(dev)
-    for L in (2, 3, 4, 8, 32):
+    only = [int(v) for v in sys.argv[1:]]  # label counts to run (all, plus the long-contig cases, when none is given)
+    for L in only or (2, 3, 4, 8, 32):
         if L == 2:
             w, trans = synth.synth_model(A, rng)
             os.environ["GECCO_CRF_FORCE_GENERAL"] = "1"
@@ -58,6 +59,9 @@ def main():
             res[name] = {"ms": dt * 1e3, "genes_per_s": n / dt}
         out[f"L={L}" + (" (2-label model forced onto the general kernels)" if L == 2 else "")] = res
     os.environ.pop("GECCO_CRF_FORCE_GENERAL", None)
+    if only:
+        print(json.dumps(out))
+        return
     # long contigs: one 50 000-gene contig, contig-sequential kernels (one group of lanes walks it) against the
     # chunked ones (chunk matrices -> vectors over chunks -> replay inside chunks)
     lc, lg, la = synth.synth_contigs(rng, [50000], A)
