@@ -186,6 +186,8 @@ class _Table:
                 elif _pa.types.is_floating(c.type):
                     cols[h] = c.to_numpy(zero_copy_only=False).astype(np.float64, copy=False)
                 elif _pa.types.is_integer(c.type):
+                    if c.null_count:  # the row parser's int("") (a null would come out of astype as INT64_MIN)
+                        raise ValueError(f"invalid literal for int() with base 10: '' (column {h!r})")
                     cols[h] = c.to_numpy(zero_copy_only=False).astype(np.int64, copy=False)
                 else:
                     cols[h] = np.array(c.to_pylist(), dtype=object)
@@ -242,8 +244,8 @@ class _Table:
                     else:
                         cols.append(np.asarray(col, dtype=np.float64 if types[n] is float else np.int64))
                 text = _native.tsv_format("\t".join(names) + "\n", cols)
-            except (ImportError, OSError):
-                text = None
+            except (ImportError, OSError, TypeError, ValueError):
+                text = None  # (a None in a numeric column, ...: the row writer below copes)
             if text is not None:
                 if isinstance(fh, str):
                     with open(fh, "wb") as f:
