@@ -165,6 +165,17 @@ hipError_t launch_seq_marginals(const SeqArgs &a, const int32_t *d_contig_ptr, h
 hipError_t launch_seq_marginals_short(const SeqArgs &a, const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01,
                                       int n_attrs, const int32_t *d_contig_ptr, hipStream_t stream);
 hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream);
+// The decode step in ONE launch (crf_kernels.hip: crf_decode_fused): window tiles and the Viterbi workgroups of short
+// contigs (vd_short's body) as blocks of the same grid; the tiles hand the score differences over inside the launch.
+struct FusedArgs {
+    const int32_t *role;  // [n_blocks] >= 0: window tile; < 0: Viterbi workgroup ~role; INT32_MIN: nothing to do
+    const int2 *vd_dep;   // [n_cblocks] first and last window tile whose score differences the Viterbi workgroup reads
+    uint32_t *tile_flag;  // [ntiles] epoch of the last launch in which the tile has published its score differences
+    uint32_t epoch;       // this launch (never 0; the plan counts)
+    int32_t n_blocks;
+};
+hipError_t launch_decode_fused(const WinArgs &w, const SeqArgs &s, const FusedArgs &f, hipStream_t stream);
+
 // labels only, from a.dstate; needs trans[0][1] - trans[1][1] <= trans[0][0] - trans[1][0]
 hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream);
 hipError_t launch_seq_state_delta(const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01, int n_attrs, int n_genes,

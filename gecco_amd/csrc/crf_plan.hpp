@@ -83,6 +83,16 @@ struct Plan {
     char *d_gen_tab = nullptr;
     int32_t gen_tab_chunk = 0;
     size_t gen_tab_nch = 0, gen_tab_off1 = 0, gen_tab_off2 = 0;
+    // The decode step in ONE launch (crf_decode_fused: window tiles + the Viterbi workgroups of short contigs as blocks of
+    // one grid): block roles, the tiles every Viterbi workgroup waits for and the tiles' publication flags, built on the
+    // first decode call of a plan that qualifies (plan_ensure_fused).  state 0: not looked at yet, 1: fused, -1: two launches.
+    struct Fused {
+        int state = 0;
+        int32_t n_blocks = 0, lag = 0;
+        char *d = nullptr;
+        size_t off_dep = 0, off_flag = 0, cap = 0;
+        uint32_t epoch = 0;
+    } fused;
     bool async_tables = false;  // the owner launches everything on ONE stream (batch driver): table uploads are not waited for
     bool tables_in_host_memory = false;  // the window kernel reads the plan tables from the pinned block itself (batch driver:
                                          // one copy and one inter-copy gap less per chunk; they are ~0.1 MB, read once)
