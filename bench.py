@@ -6,8 +6,16 @@
 A "step" is one pass of the hot path over one resident batch: the windowed forward-backward
 marginals of every gene (the reference's `ClusterCRF.predict_probabilities` arithmetic,
 gecco/crf/__init__.py:244-258) followed by whole-contig Viterbi decoding of the same batch
-(one `gecco_crf_plan_run_decode`).  Workload at N=1 = BASELINE.json configs[2] ("C3": 10k-contig
-synthetic metagenome, ~2M genes, 35k-attribute synthetic model, W=20).
+.  Workload at N=1 = BASELINE.json configs[2] ("C3": 10k-contig synthetic metagenome, ~2M genes,
+35k-attribute synthetic model, W=20).
+
+Schedule of the steps (`--schedule`): "pipelined" (default) is the throughput form of the decode API,
+`gecco_crf_plan_run_decode_pipelined`: call k enqueues ONE launch that carries the window tiles of batch k
+and the Viterbi workgroups of batch k - 1; the K steps of the timed region are K such calls -- the first
+one tiles only -- plus the flush that delivers the labels of the last batch, so every batch's marginals
+AND labels are computed inside the region (K window passes, K Viterbi passes, K + 1 launches).
+"two-launch" is `gecco_crf_plan_run_decode` (window kernel, then Viterbi kernel, per batch); its step time
+is reported next to the headline as `two_launch_ms_per_step`.
 
 N>1 (one process per GPU, no collective on the data path):
   * `value` is WEAK scaling -- every rank owns its own C3-sized batch of contigs;
@@ -76,6 +84,9 @@ def main() -> None:
                     help="weight law of the synthetic model: 'genome' (default, most genes lean to label 0) or SURVEY.md 8d to the letter")
     ap.add_argument("--no-levels", action="store_true", help="skip the host-buffer / tables / object API levels (SURVEY.md 8d)")
     ap.add_argument("--no-8d", action="store_true", help="skip the second roofline point on the 8d-exact weight law")
+    ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "two-launch"],
+                    help="pipelined: one launch per step = window tiles of batch k + Viterbi workgroups of batch k - 1 "
+                         "(gecco_crf_plan_run_decode_pipelined, + one flush); two-launch: gecco_crf_plan_run_decode")
     args = ap.parse_args()
 
     import torch
@@ -145,27 +156,45 @@ def main() -> None:
             else:
                 self.stream = torch.cuda.current_stream(dev).cuda_stream
 
-        def step(self):
+        primed = False  # pipelined schedule: the previous call has left a batch whose labels are still to come
+
+        def step(self, schedule=None):
+            schedule = schedule or args.schedule
             if args.windowed_only:
                 self.plan.run_windowed(self.d_gp.data_ptr(), self.d_at.data_ptr(), self.d_p.data_ptr(), LABEL, self.stream)
+            elif schedule == "pipelined":  # window tiles of this batch + Viterbi workgroups of the batch before, one launch
+                self.plan.run_decode_pipelined(self.d_gp.data_ptr(), self.d_at.data_ptr(), self.d_p.data_ptr(),
+                                               self.plan if self.primed else None, self.d_y.data_ptr() if self.primed else 0, LABEL,
+                                               self.stream)
+                self.primed = True
             else:  # one pass over the CSR: state scores are accumulated once for both outputs
                 self.plan.run_decode(self.d_gp.data_ptr(), self.d_at.data_ptr(), self.d_p.data_ptr(), self.d_y.data_ptr(), LABEL, 0,
                                      self.stream)
 
-        def timed(self, steps, warmup, preroll_ms):
-            """(seconds for `steps` steps, max over ranks), after `warmup` untimed ones"""
+        def flush(self):
+            """pipelined schedule: the labels of the last batch (a Viterbi-only launch)"""
+            if self.primed:
+                self.plan.flush_decode_pipelined(self.d_y.data_ptr(), self.stream)
+                self.primed = False
+
+        def timed(self, steps, warmup, preroll_ms, schedule=None):
+            """(seconds for `steps` steps, max over ranks), after `warmup` untimed ones.  Pipelined schedule: the region
+            starts with an empty pipeline and ends with the flush, so it holds `steps` window passes and `steps` Viterbi
+            passes (the labels of every one of its batches)."""
             t_pre = time.perf_counter()
             while (time.perf_counter() - t_pre) * 1e3 < preroll_ms:
                 for _ in range(20):
-                    self.step()
+                    self.step(schedule)
                 torch.cuda.synchronize(dev)
             for _ in range(warmup):
-                self.step()
+                self.step(schedule)
+            self.flush()
             barrier()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for _ in range(steps):
-                self.step()
+                self.step(schedule)
+            self.flush()
             torch.cuda.synchronize(dev)
             barrier()
             elapsed = time.perf_counter() - t0
@@ -198,12 +227,26 @@ def main() -> None:
 
     elapsed = res.timed(args.steps, args.warmup, args.preroll_ms)
     total_genes = all_sum(n_genes)
+    pipelined = args.schedule == "pipelined" and not args.windowed_only
+    # the other schedule next to the headline (a quarter of the steps)
+    two_launch_ms = None
+    if pipelined:
+        st2 = max(args.steps // 4, 1)
+        two_launch_ms = res.timed(st2, min(args.warmup, 20), 0.0, schedule="two-launch") / st2 * 1e3
 
     # ---- dominant kernel: average launch duration by HIP events on the launch stream
     kern_ms = res.plan.time_windowed(res.d_gp.data_ptr(), res.d_at.data_ptr(), res.d_p.data_ptr(), LABEL, res.stream, warmup=3,
                                      iters=args.kernel_iters)
     alg_bytes = _alg_bytes(n_genes, nnz, res.n_contigs)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    # pipelined schedule: the launch that IS the step -- window tiles + Viterbi workgroups (crf_decode_pipelined); its
+    # algorithmic bytes are the window kernel's plus one label byte per gene (the score differences the tiles leave for
+    # the Viterbi workgroups of the next launch, 8 B written + 8 B read per gene, are the implementation's own traffic)
+    pipe_ms = pipe_alg = None
+    if pipelined:
+        pipe_ms = res.plan.time_decode_pipelined(res.d_gp.data_ptr(), res.d_at.data_ptr(), res.d_p.data_ptr(), res.d_y.data_ptr(), LABEL,
+                                                 res.stream, warmup=3, iters=args.kernel_iters)
+        pipe_alg = alg_bytes + n_genes
     # PMC figures of this kernel on this workload, from the committed profile of the same command
     # (tools/profile.sh -> tools/pmc_to_json.py); null when there is none
     pmc = {}
@@ -223,6 +266,14 @@ def main() -> None:
         if pmc and args.synth != "genome":
             pmc_note = "profiles/pmc_traffic.json was taken on the default weight law: counter figures dropped"
             pmc = {}
+    pmc_pipe = {}
+    if pipelined and os.path.exists(pmc_path):
+        try:
+            pmc_pipe = json.load(open(pmc_path)).get(args.workload + ":pipelined", {}) or {}
+        except Exception:
+            pmc_pipe = {}
+        if pmc_pipe.get("kernel_source_sha16") != _kernel_source_sha16() or args.synth != "genome":
+            pmc_pipe = {}
     traffic = pmc.get("hbm_bytes_per_launch")
     valu_insts = pmc.get("SQ_INSTS_VALU")  # wave-level VALU instructions of one launch
     valu_frac = (valu_insts * 4.0 / (kern_ms * 1e-3 * SIMDS * SCLK_HZ)) if valu_insts else None
@@ -250,6 +301,10 @@ def main() -> None:
             "synth_law": args.synth,
             "genes_per_gpu": n_genes,
             "viterbi_in_step": not args.windowed_only,
+            "schedule": ("pipelined over batches: launch k = window tiles of batch k + Viterbi workgroups of batch k - 1 "
+                         "(gecco_crf_plan_run_decode_pipelined); the timed region starts with an empty pipeline and ends with the "
+                         "flush: K window passes + K Viterbi passes in K + 1 launches" if pipelined else
+                         "two launches per batch (gecco_crf_plan_run_decode)" if not args.windowed_only else "window kernel only"),
             "device_preroll_ms": args.preroll_ms,
             "sharding": "independent contig batches per rank, no collective",
         },
@@ -276,6 +331,27 @@ def main() -> None:
             if args.workload != "Cinf" else None,
         },
     }
+    if pipelined:
+        # the step IS one launch of crf_decode_pipelined: that is the dominant kernel; the window kernel on its own (plain
+        # launches, back to back) stays in the line as `roofline_window_kernel`
+        out["two_launch_ms_per_step"] = two_launch_ms
+        out["roofline_window_kernel"] = out["roofline"]
+        vi = pmc_pipe.get("SQ_INSTS_VALU")
+        out["roofline"] = {
+            "bound": "hbm",
+            "kernel": "crf_decode_pipelined",
+            "achieved": pipe_alg / (pipe_ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": pipe_alg / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "traffic": pmc_pipe.get("hbm_bytes_per_launch"),
+            "traffic_source": pmc_pipe.get("source") or "no counter profile of this kernel source in profiles/pmc_traffic.json",
+            "algorithmic_bytes_per_launch": pipe_alg,
+            "kernel_ms": pipe_ms,
+            "kernel_ms_note": "HIP events around back-to-back launches on the launch stream: includes the boundary between launches",
+            "valu_insts_per_launch": vi,
+            "valu_frac": (vi * 4.0 / (pipe_ms * 1e-3 * SIMDS * SCLK_HZ)) if vi else None,
+        }
     if world > 1:
         # who ran where: the process group that carried the timing barrier, and every rank's device
         devs = [None] * world
@@ -397,7 +473,9 @@ def main() -> None:
         y_ref, _ = orc.viterbi(wl["w"], wl["trans"], cp, wl["gene_ptr"][: ng + 1], wl["attr_id"])
         dt_vit = time.perf_counter() - t0
         dt = dt_win + (0.0 if args.windowed_only else dt_vit)
+        res.d_y.fill_(7)  # (the parity check below reads the labels this step delivers, not older ones)
         res.step()
+        res.flush()  # pipelined schedule: the labels of that batch come with the next call
         torch.cuda.synchronize(dev)
         got = res.d_p[:ng].cpu().numpy()
         out["cpu_baseline"] = {
@@ -464,7 +542,7 @@ def _kernel_source_sha16():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("crf_kernels.hip", "crf_device.hpp"):
+    for name in ("crf_kernels.hip", "crf_device.hpp", "crf_vd_short.hpp", "crf_scan.hpp"):
         with open(os.path.join(ROOT, "gecco_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -70,6 +70,7 @@ SIGNATURES = {
     "gecco_crf_plan_kernel_name": (ctypes.c_char_p, [_vp]),
     "gecco_crf_plan_run_windowed": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     "gecco_crf_plan_run_decode": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp]),
+    "gecco_crf_plan_run_decode_pipelined": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     "gecco_crf_plan_run_marginals_full": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gecco_crf_plan_run_viterbi": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gecco_crf_plan_run_segment": (
@@ -138,6 +139,9 @@ SIGNATURES = {
     "gecco_crf_buffer_free": (None, [_vp]),
     "gecco_crf_plan_time_windowed": (
         ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]
+    ),
+    "gecco_crf_plan_time_decode_pipelined": (
+        ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]
     ),
 }
 
@@ -749,6 +753,17 @@ class Plan:
         _check(self._lib.gecco_crf_plan_run_decode(self._h, d_gene_ptr, d_attr_id or None, int(label), d_p_out, d_y,
                                                    d_score or None, stream or None))
 
+    def run_decode_pipelined(self, d_gene_ptr: int, d_attr_id: int, d_p_out: int, prev: "Plan" = None, d_prev_y: int = 0, label: int = 1,
+                             stream: int = 0):
+        """Marginals of this plan's batch + Viterbi labels of the batch the previous call scored on `prev` (one launch
+        when both qualify); `Plan.flush_decode_pipelined` delivers the labels of the last batch."""
+        _check(self._lib.gecco_crf_plan_run_decode_pipelined(self._h, d_gene_ptr, d_attr_id or None, int(label), d_p_out,
+                                                             prev._h if prev is not None else None, d_prev_y or None, stream or None))
+
+    def flush_decode_pipelined(self, d_y: int, stream: int = 0):
+        """Labels of the batch the last `run_decode_pipelined` call on this plan scored."""
+        _check(self._lib.gecco_crf_plan_run_decode_pipelined(None, None, None, 1, None, self._h, d_y, stream or None))
+
     def run_marginals_full(self, d_gene_ptr: int, d_attr_id: int, d_marg: int, d_lognorm: int = 0, stream: int = 0):
         _check(self._lib.gecco_crf_plan_run_marginals_full(self._h, d_gene_ptr, d_attr_id, d_marg, d_lognorm or None, stream or None))
 
@@ -764,6 +779,14 @@ class Plan:
                           int(d_marker_ptr), int(d_marker_id))
         _check(self._lib.gecco_crf_plan_run_segment_ex(self._h, d_p, d_annotated, ctypes.byref(q), d_seg, int(max_seg), d_n_seg,
                                                        stream or None))
+
+    def time_decode_pipelined(self, d_gene_ptr: int, d_attr_id: int, d_p_out: int, d_y: int, label=1, stream: int = 0, warmup=2,
+                              iters=10) -> float:
+        """ms per pipelined decode launch (this plan following itself), HIP events on `stream`."""
+        ms = ctypes.c_float(0)
+        _check(self._lib.gecco_crf_plan_time_decode_pipelined(self._h, d_gene_ptr, d_attr_id, int(label), d_p_out, d_y, stream or None,
+                                                              int(warmup), int(iters), ctypes.byref(ms)))
+        return ms.value
 
     def time_windowed(self, d_gene_ptr: int, d_attr_id: int, d_p_out: int, label=1, stream: int = 0, warmup=2, iters=10) -> float:
         ms = ctypes.c_float(0)

@@ -241,12 +241,50 @@ GECCO_API int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_g
     GECCO_GUARD_END
 }
 
+GECCO_API int gecco_crf_plan_time_decode_pipelined(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                                   int32_t label, double *d_p_out, int8_t *d_y, void *stream, int32_t warmup,
+                                                   int32_t iters, float *ms_per_launch) {
+    if (!p || !ms_per_launch || iters <= 0) return GECCO_CRF_EINVAL;
+    DeviceGuard guard;
+    GECCO_GUARD_BEGIN
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    // the plan follows itself: call 0 primes (tiles only), every later call is one launch of tiles + Viterbi workgroups
+    if ((rc = plan_run_decode_pipelined(&p->p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, nullptr, s))) return rc;
+    for (int i = 0; i < warmup; ++i)
+        if ((rc = plan_run_decode_pipelined(&p->p, d_gene_ptr, d_attr_id, label, d_p_out, &p->p, d_y, s))) return rc;
+    hipEvent_t e0, e1;
+    if ((rc = check_hip(hipEventCreate(&e0), "hipEventCreate"))) return rc;
+    if ((rc = check_hip(hipEventCreate(&e1), "hipEventCreate"))) return rc;
+    rc = check_hip(hipEventRecord(e0, s), "hipEventRecord");
+    for (int i = 0; i < iters && !rc; ++i) rc = plan_run_decode_pipelined(&p->p, d_gene_ptr, d_attr_id, label, d_p_out, &p->p, d_y, s);
+    if (!rc) rc = check_hip(hipEventRecord(e1, s), "hipEventRecord");
+    if (!rc) rc = check_hip(hipEventSynchronize(e1), "hipEventSynchronize");
+    float ms = 0.f;
+    if (!rc) rc = check_hip(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!rc) rc = plan_run_decode_pipelined(nullptr, nullptr, nullptr, label, nullptr, &p->p, d_y, s);  // (flush)
+    *ms_per_launch = ms / float(iters);
+    return rc;
+    GECCO_GUARD_END
+}
+
 GECCO_API int gecco_crf_plan_run_decode(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                                         int32_t label, double *d_p_out, int8_t *d_y, double *d_score, void *stream) {
     if (!p) return GECCO_CRF_EINVAL;
     DeviceGuard guard;
     GECCO_GUARD_BEGIN
     return plan_run_decode(p->p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, static_cast<hipStream_t>(stream));
+    GECCO_GUARD_END
+}
+GECCO_API int gecco_crf_plan_run_decode_pipelined(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label,
+                                                  double *d_p_out, gecco_crf_plan *prev, int8_t *d_prev_y, void *stream) {
+    if (!p && !prev) return GECCO_CRF_EINVAL;
+    DeviceGuard guard;
+    GECCO_GUARD_BEGIN
+    return plan_run_decode_pipelined(p ? &p->p : nullptr, d_gene_ptr, d_attr_id, label, d_p_out, prev ? &prev->p : nullptr, d_prev_y,
+                                     static_cast<hipStream_t>(stream));
     GECCO_GUARD_END
 }
 GECCO_API int gecco_crf_plan_run_marginals_full(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,

@@ -175,6 +175,10 @@ struct FusedArgs {
     int32_t n_blocks;
 };
 hipError_t launch_decode_fused(const WinArgs &w, const SeqArgs &s, const FusedArgs &f, hipStream_t stream);
+// The decode step pipelined over batches (crf_decode_pipelined): the window tiles of `w`'s batch and the Viterbi workgroups of
+// `s`'s batch (short contigs, score differences already in s.dstate) in one launch, nothing exchanged inside it.
+bool decode_pipelined_ok(const WinArgs &w, const SeqArgs &s);
+hipError_t launch_decode_pipelined(const WinArgs &w, const SeqArgs &s, hipStream_t stream);
 
 // labels only, from a.dstate; needs trans[0][1] - trans[1][1] <= trans[0][0] - trans[1][0]
 hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream);

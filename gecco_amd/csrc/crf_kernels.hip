@@ -193,7 +193,8 @@ __device__ __forceinline__ void state_scores_buf(__amdgpu_buffer_rsrc_t ra, __am
 // (crf_decode_fused below) and hands the score differences of its genes to the Viterbi workgroups of the SAME launch:
 // write-through stores, and its word of `tile_flag` set to `epoch` once they have left (behind the barrier of its first
 // DP phase, where the stores have long been acknowledged -- the wait costs nothing).
-template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT, bool PUBLISH>
+// LEAN: the tile shares its kernel with the Viterbi workgroups, whose SGPR spills take one VGPR of the 64.
+template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT, bool PUBLISH, bool LEAN = PUBLISH>
 __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT, TT, EXACT> &sm, const int tile, uint32_t *tile_flag,
                                               const uint32_t epoch) {
     using Smem = WinSmem<WMAX, NT, TT, EXACT>;
@@ -577,7 +578,7 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
             }
             if (wave > 0 && lane < W - 1) {
                 int t2 = tid;
-                if (PUBLISH) asm volatile("" : "+v"(t2));  // (same: the index is recomputed per phase, one VGPR less across the DP)
+                if (LEAN) asm volatile("" : "+v"(t2));  // (the index is recomputed per phase: one VGPR less across the DP)
                 R = fmax(R, carry[((t2 >> 6) - 1) * WMAX + (t2 & 63)]);
             }
             R = fmin(R, 1.0);
@@ -787,6 +788,28 @@ __global__ void __launch_bounds__(kWinThreads, 8) crf_decode_fused(const WinArgs
 #endif
 }
 
+// ---- the decode step, software-pipelined over batches: ONE launch, NO hand-over inside it ---------------------------------
+// Launch k carries the window tiles of batch k and the Viterbi workgroups of batch k - 1, whose score differences the
+// tiles of launch k - 1 left in that plan's workspace (two buffers per plan, alternating, so a plan may follow itself).
+// Nothing is exchanged inside the launch -- no flags, no acquire, no block roles: the first blocks are the Viterbi
+// workgroups (rounded up to a multiple of 8, so the tiles keep their XCDs), the rest the tiles.  The Viterbi workgroups
+// -- chains of dependent memory operations that leave the CUs idle when they run alone (vd_short: 10.5 us for 18 MB) --
+// run under the VALU-bound tiles: 32 us for both against 24.3 + 10.5 us and a kernel boundary (C3: 40.7 -> 36.4 us per
+// batch on the first measurement).  K batches take K + 1 launches (plan_run_decode_pipelined: the last call flushes).
+__global__ void __launch_bounds__(kWinThreads, 8) crf_decode_pipelined(const WinArgs P, const SeqArgs A, const int nvd8) {
+    using Smem = WinSmem<20, kWinThreads, 2, true>;
+    constexpr size_t kBytes = sizeof(Smem) > sizeof(VdShortSmem) ? sizeof(Smem) : sizeof(VdShortSmem);
+    static_assert(kBytes <= 20480, "eight workgroups per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
+    const int b = blockIdx.x;
+    if (b >= nvd8) {
+        windowed_tile<20, true, false, kWinThreads, 2, false, true>(P, *reinterpret_cast<Smem *>(raw), xcd_remap(b - nvd8, P.ntiles), nullptr, 0u);
+        return;
+    }
+    if (b >= A.n_cblocks) return;
+    vd_short_block(A, b, *reinterpret_cast<VdShortSmem *>(raw));
+}
+
 // ---- generic window kernel (2 labels, ANY window size, ANY transition spread) -------------
 // Fallback for shapes the register-resident kernel does not take (W > 32, or transition
 // weights so far apart that un-normalised vectors would need rescaling more than once per
@@ -914,6 +937,18 @@ hipError_t launch_decode_fused(const WinArgs &w, const SeqArgs &s, const FusedAr
     if (f.n_blocks <= 0) return hipSuccess;
     if (w.W != 20 || w.rescale_mask != 0 || w.tiles_per_wg != 2 || w.generic || !w.dstate_out || !s.short_contigs) return hipErrorNotSupported;
     hipLaunchKernelGGL(crf_decode_fused, dim3(f.n_blocks), dim3(kWinThreads), 0, stream, w, s, f);
+    return hipGetLastError();
+}
+
+bool decode_pipelined_ok(const WinArgs &w, const SeqArgs &s) {
+    return w.ntiles > 0 && w.W == 20 && w.rescale_mask == 0 && w.tiles_per_wg == 2 && !w.generic && w.L == 2 && !w.state_out &&
+           s.short_contigs && s.n_cblocks > 0 && s.n_genes > 0;
+}
+
+hipError_t launch_decode_pipelined(const WinArgs &w, const SeqArgs &s, hipStream_t stream) {
+    if (!decode_pipelined_ok(w, s)) return hipErrorNotSupported;
+    const int nvd8 = (s.n_cblocks + 7) & ~7;
+    hipLaunchKernelGGL(crf_decode_pipelined, dim3(nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, w, s, nvd8);
     return hipGetLastError();
 }
 

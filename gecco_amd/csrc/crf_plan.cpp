@@ -574,6 +574,8 @@ int run_windowed_general(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_at
 struct FusedLaunch {
     const SeqArgs *seq;
     FusedArgs args;
+    bool pipelined = false;  // seq belongs to the PREVIOUS batch: crf_decode_pipelined (nothing exchanged inside the launch)
+    bool *took = nullptr;    // pipelined: set when the one launch was made (otherwise the caller launches the Viterbi side itself)
 };
 static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                              double2 *d_state_out, double *d_dstate_out, hipStream_t stream, const FusedLaunch *fused = nullptr);
@@ -667,7 +669,14 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     if (!p.skipped.empty())
         if ((rc = check_hip(launch_fill_nan(d_p_out, p.d_skipped, int(p.skipped.size()), stream), "fill_nan launch")))
             return rc;
-    if (fused) return check_hip(launch_decode_fused(a, *fused->seq, fused->args, stream), "fused decode launch");
+    if (fused && fused->pipelined) {
+        if (!a.generic && !p.stream_phases && decode_pipelined_ok(a, *fused->seq)) {
+            *fused->took = true;
+            return check_hip(launch_decode_pipelined(a, *fused->seq, stream), "pipelined decode launch");
+        }
+    } else if (fused) {
+        return check_hip(launch_decode_fused(a, *fused->seq, fused->args, stream), "fused decode launch");
+    }
     if (p.stream_phases && !a.state_out) return check_hip(launch_windowed_stream(a, p.stream_phases, stream), "windowed launch");
     if (p.stream_phases) {
         // 16-byte state scores as a by-product (matrix-form Viterbi, path scores): not a stream-kernel shape
@@ -915,6 +924,7 @@ static bool viterbi_delta_ok(const SeqArgs &a, const double *d_score) {
 
 int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, double *d_marg,
                             double *d_lognorm, hipStream_t stream) {
+    p.pipe.pending = false;  // (the workspace of pipelined decode calls is written below)
     SeqArgs a;
     int rc = fill_seq_args(p, a, stream);
     if (rc) return rc;
@@ -958,6 +968,7 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
 
 int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int8_t *d_y, double *d_score,
                      hipStream_t stream) {
+    p.pipe.pending = false;  // (the workspace of pipelined decode calls is written below)
     SeqArgs a;
     int rc = fill_seq_args(p, a, stream);
     if (rc) return rc;
@@ -1000,6 +1011,7 @@ static int run_decode_launches(Plan &p, const int32_t *d_gene_ptr, const int32_t
 
 int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                     int8_t *d_y, double *d_score, hipStream_t stream) {
+    p.pipe.pending = false;  // (the workspace of pipelined decode calls is written below)
     // A resident batch decoded again and again with the same buffers (a service scoring with several models, the
     // benchmark's steps, a shard of a strong-scaling run where the launches themselves dominate): replay the launches
     // as a graph.  The first call runs plainly (it may allocate workspaces and upload tables: not capturable), the
@@ -1123,7 +1135,6 @@ static int plan_ensure_fused(Plan &p) {
     const int32_t q = nt >> 3, r = nt & 7;
     auto xbase = [&](int x) { return x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q; };
     auto xcnt = [&](int x) { return x < r ? q + 1 : q; };
-    std::vector<std::vector<int32_t>> after(8);  // per XCD: Viterbi workgroups keyed by the local tile they follow
     std::vector<std::vector<int32_t>> seq(8);
     {
         std::vector<std::vector<std::pair<int32_t, int32_t>>> vd(8);
@@ -1250,6 +1261,68 @@ static int run_decode_launches(Plan &p, const int32_t *d_gene_ptr, const int32_t
     if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, const_cast<double2 *>(a.state), nullptr, stream)))
         return rc;
     return check_hip(launch_seq_viterbi(a, p.d_contig_ptr, stream), "viterbi launch");
+}
+
+int plan_run_decode_pipelined(Plan *cur, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                              Plan *prev, int8_t *d_prev_y, hipStream_t stream) {
+    int rc;
+    // ---- the previous batch: labels from the score differences its window tiles left behind (or from its CSR arrays)
+    SeqArgs pa{};
+    bool prev_delta = false;
+    if (prev && prev->n_genes > 0 && prev->n_contigs > 0) {
+        if (!d_prev_y) {
+            set_error("null device buffer");
+            return GECCO_CRF_EINVAL;
+        }
+        if (prev->pipe.pending && !prev->general) {
+            if ((rc = fill_seq_args(*prev, pa, stream))) return rc;
+            pa.dstate = reinterpret_cast<const double *>(pa.state) + size_t(prev->pipe.parity) * (size_t(prev->n_genes) + 8);
+            pa.y = d_prev_y;
+            pa.csr_gene_ptr = prev->pipe.gene_ptr;
+            pa.csr_attr_id = prev->pipe.attr_id;
+            pa.csr_wtab01 = prev->tables_model->wtab2[1];
+            pa.csr_n_attrs = prev->model->A;
+            prev_delta = true;
+        }
+    }
+    const bool prev_work = prev && prev->n_genes > 0 && prev->n_contigs > 0;
+    if (prev_work && !prev_delta) {
+        // no score differences left behind (any-L model, contigs outside slot space, or another call used the workspace since):
+        // the state scores are summed again from the CSR arrays -- BEFORE this batch's tiles write into the workspace
+        const Plan::Pipe keep = prev->pipe;
+        if ((rc = plan_run_viterbi(*prev, keep.gene_ptr, keep.attr_id, d_prev_y, nullptr, stream))) return rc;
+        prev->pipe = keep;
+    }
+    // ---- this batch: marginals, and score differences for the next call where the kernels hand them over
+    bool took = false;
+    if (cur) {
+        Plan &p = *cur;
+        const int parity = p.pipe.parity ^ 1;  // (cur == prev: the Viterbi side reads the other buffer)
+        bool delta = false;
+        double *d_dstate = nullptr;
+        if (!p.general && p.fast_ok && p.skipped.empty() && p.device >= 0 && p.n_genes > 0 && !p.stream_phases) {
+            SeqArgs ca;
+            if ((rc = fill_seq_args(p, ca, stream))) return rc;
+            if (viterbi_delta_ok(ca, nullptr)) {
+                delta = true;
+                d_dstate = const_cast<double *>(reinterpret_cast<const double *>(ca.state)) + size_t(parity) * (size_t(p.n_genes) + 8);
+            }
+        }
+        FusedLaunch fl{};
+        fl.seq = &pa;
+        fl.pipelined = true;
+        fl.took = &took;
+        if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, d_dstate, stream, (delta && prev_delta) ? &fl : nullptr)))
+            return rc;
+        p.pipe.pending = delta;
+        p.pipe.parity = delta ? parity : p.pipe.parity;
+        p.pipe.gene_ptr = d_gene_ptr;
+        p.pipe.attr_id = d_attr_id;
+    }
+    if (prev_work && prev_delta && !took)
+        if ((rc = check_hip(launch_seq_viterbi_delta(pa, stream), "viterbi launch"))) return rc;
+    if (prev && prev != cur) prev->pipe.pending = false;
+    return GECCO_CRF_OK;
 }
 
 int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, const SegParams &params, int32_t *d_seg,

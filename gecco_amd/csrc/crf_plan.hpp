@@ -93,6 +93,13 @@ struct Plan {
         size_t off_dep = 0, off_flag = 0, cap = 0;
         uint32_t epoch = 0;
     } fused;
+    // Pipelined decode (plan_run_decode_pipelined): what the last call left for the next one -- the batch's score differences
+    // in buffer `parity` of the workspace (pending) and the batch's CSR arrays, which the caller keeps alive until then.
+    struct Pipe {
+        bool pending = false;
+        int parity = 0;
+        const int32_t *gene_ptr = nullptr, *attr_id = nullptr;
+    } pipe;
     bool async_tables = false;  // the owner launches everything on ONE stream (batch driver): table uploads are not waited for
     bool tables_in_host_memory = false;  // the window kernel reads the plan tables from the pinned block itself (batch driver:
                                          // one copy and one inter-copy gap less per chunk; they are ~0.1 MB, read once)
@@ -125,6 +132,11 @@ int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, con
 int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                       hipStream_t stream);
 // windowed marginals + whole-contig Viterbi of the same batch in one pass over the CSR
+// Decode pipelined over batches: enqueue the windowed marginals of `cur`'s batch (cur may be null: flush) and the Viterbi
+// labels of the batch the previous call scored on `prev` (null on the first call; may be the same plan) -- in ONE launch
+// when both sides qualify (2-label model, W = 20, short contigs: crf_decode_pipelined), in separate launches otherwise.
+int plan_run_decode_pipelined(Plan *cur, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
+                              Plan *prev, int8_t *d_prev_y, hipStream_t stream);
 int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                     int8_t *d_y, double *d_score, hipStream_t stream);
 int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, double *d_marg,

@@ -178,6 +178,17 @@ int gecco_crf_plan_run_viterbi(gecco_crf_plan *p, const int32_t *d_gene_ptr, con
  * gecco_crf_plan_run_windowed followed by gecco_crf_plan_run_viterbi; d_score may be NULL. */
 int gecco_crf_plan_run_decode(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                               int32_t label, double *d_p_out, int8_t *d_y, double *d_score, void *stream);
+/* The same decode, software-pipelined over a sequence of batches (throughput form): call k enqueues the windowed marginals
+ * of batch k (plan p, its CSR arrays, d_p_out) and the Viterbi labels of batch k - 1 (plan `prev`, the plan of the
+ * previous call -- it may be the same plan --, labels to d_prev_y) -- in ONE launch when both qualify (2-label model,
+ * window 20, no contig longer than 2048 genes): the Viterbi workgroups, which leave the CUs idle when they run alone,
+ * run under the window tiles of the next batch.  First call: prev = NULL.  Last call: p = NULL (labels of the last batch
+ * only), so K batches take K + 1 calls.  Outputs are the bits of gecco_crf_plan_run_decode.  The caller keeps the CSR
+ * arrays of a batch alive until the call that delivers its labels has been enqueued, and does not use `prev` for other
+ * whole-contig calls in between (they would recompute the state scores; results stay correct). */
+int gecco_crf_plan_run_decode_pipelined(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                        int32_t label, double *d_p_out, gecco_crf_plan *prev, int8_t *d_prev_y,
+                                        void *stream);
 /* Row R chained behind the marginals, on the same stream, without moving them: d_p (e.g. the output
  * of gecco_crf_plan_run_windowed) and d_annotated are device arrays over the plan's genes; rows go
  * to d_seg[max_seg][4] and their number to *d_n_seg, both device-accessible (device memory, or
@@ -196,6 +207,11 @@ int gecco_crf_plan_run_segment_ex(gecco_crf_plan *p, const double *d_p, const ui
 int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                                  int32_t label, double *d_p_out, void *stream,
                                  int32_t warmup, int32_t iters, float *ms_per_launch);
+/* The same for the pipelined decode launch (the plan following itself: window tiles of the batch + Viterbi workgroups of
+ * the batch before, one launch per iteration); the interval includes the boundaries between the launches. */
+int gecco_crf_plan_time_decode_pipelined(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
+                                         int32_t label, double *d_p_out, int8_t *d_y, void *stream, int32_t warmup,
+                                         int32_t iters, float *ms_per_launch);
 
 /* ---- batch driver: host buffers in, host buffers out, one or several devices ----------------
  * What `gecco run` reaches through ClusterCRF.predict_probabilities (gecco/crf/__init__.py:244-258:

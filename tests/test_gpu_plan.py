@@ -189,3 +189,87 @@ def test_fused_decode_launch_equals_two_launches(nat, real, oracle_model, monkey
         assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
         ey, _ = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
         assert np.array_equal(out["1"][1].astype(np.int32), ey)
+
+
+def test_pipelined_decode_equals_decode(nat, real, oracle_model):
+    """gecco_crf_plan_run_decode_pipelined: call k carries the marginals of batch k and the Viterbi labels of batch k - 1
+    (one launch when both qualify: crf_decode_pipelined).  Same bits as gecco_crf_plan_run_decode for every batch, over a
+    sequence that mixes qualifying batches, one plan following itself, a batch with skipped contigs (pad=False), a batch
+    with a long contig, an empty batch and a 3-label model (separate launches there)."""
+    rng = np.random.default_rng(321)
+    A = oracle_model["state"].shape[0]
+    w3, t3 = rng.normal(size=(A, 3)), rng.normal(size=(3, 3))
+    m3 = nat.Model.from_tables(w3, t3)
+    specs = [
+        (real, list(rng.integers(1, 400, size=150)), True),
+        (real, list(rng.integers(100, 300, size=300)), True),
+        (real, list(rng.integers(100, 300, size=300)), True),   # (the same layout: its plan is reused below)
+        (real, [5, 30, 7, 200, 19, 21] + list(rng.integers(1, 60, size=100)), False),  # skipped contigs: no hand-over
+        (real, list(rng.integers(1, 400, size=100)), True),
+        (real, [3000, 50, 70], True),                           # a long contig: the general whole-contig path
+        (real, [], True),
+        (m3, list(rng.integers(1, 100, size=40)), True),
+        (real, list(rng.integers(1, 2048, size=30)), True),
+        (real, list(rng.integers(1, 400, size=200)), True),
+    ]
+    batches = []
+    for model, lengths, pad in specs:
+        cptr, gptr, attr = synth_contigs(rng, lengths, A)
+        batches.append((model, cptr, pad, *_dev(gptr, attr), int(cptr[-1])))
+    plans = [nat.Plan(m, cptr, 20, 1, pad, device=0) for m, cptr, pad, _, _, _ in batches]
+    plans[2] = plans[1]  # one plan following itself: the score differences are double-buffered
+    batches[2] = (batches[1][0], batches[1][1], batches[1][2], batches[2][3], batches[2][4], batches[1][5])
+    # batch 2 needs CSR arrays of batch 1's shape: rebuild them for that layout
+    c2, g2, a2 = synth_contigs(np.random.default_rng(77), np.diff(batches[1][1]), A)
+    batches[2] = (batches[1][0], c2, batches[1][2], *_dev(g2, a2), int(c2[-1]))
+    exp = []
+    for (model, cptr, pad, d_gp, d_at, n), plan in zip(batches, plans):
+        p = torch.zeros(max(n, 1), dtype=torch.float64, device="cuda:0")
+        y = torch.full((max(n, 1),), 5, dtype=torch.int8, device="cuda:0")
+        nat.Plan(model, cptr, 20, 1, pad, device=0).run_decode(d_gp.data_ptr() if n else 0, d_at.data_ptr() if n else 0, p.data_ptr(), y.data_ptr())
+        torch.cuda.synchronize()
+        exp.append((p.cpu().numpy()[:n], y.cpu().numpy()[:n]))
+    stream = torch.cuda.Stream(device="cuda:0")
+    outs = [(torch.zeros(max(b[5], 1), dtype=torch.float64, device="cuda:0"), torch.full((max(b[5], 1),), 5, dtype=torch.int8, device="cuda:0"))
+            for b in batches]
+    with torch.cuda.stream(stream):
+        for k, ((model, cptr, pad, d_gp, d_at, n), plan) in enumerate(zip(batches, plans)):
+            plan.run_decode_pipelined(d_gp.data_ptr() if n else 0, d_at.data_ptr() if n else 0, outs[k][0].data_ptr(),
+                                      plans[k - 1] if k else None, outs[k - 1][1].data_ptr() if k else 0, 1, stream.cuda_stream)
+        plans[-1].flush_decode_pipelined(outs[-1][1].data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    for k, ((p, y), (ep, ey)) in enumerate(zip(outs, exp)):
+        n = batches[k][5]
+        got_p, got_y = p.cpu().numpy()[:n], y.cpu().numpy()[:n]
+        assert np.array_equal(np.isnan(got_p), np.isnan(ep)), k
+        ok = ~np.isnan(ep)
+        assert np.array_equal(got_p[ok], ep[ok]), k
+        assert np.array_equal(got_y, ey), k
+
+
+def test_pipelined_decode_ties_take_crfsuites_recursion(nat):
+    """Integer-valued weights make exact ties common: the Viterbi workgroups of the pipelined launch send the contigs that
+    hold one through CRFsuite's own recursion (vd_short's exact pass, same body) -- labels equal the oracle's."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(99)
+    A = 30
+    w = rng.integers(-2, 3, size=(A, 2)).astype(np.float64)
+    trans = np.array([[1.0, -1.0], [-1.0, 1.0]])
+    model = nat.Model.from_tables(w, trans)
+    ys, eys = [], []
+    plans, bufs = [], []
+    for k in range(3):
+        cptr, gptr, attr = synth_contigs(rng, list(rng.integers(1, 300, size=120)), A)
+        n = int(cptr[-1])
+        d_gp, d_at = _dev(gptr, attr)
+        plans.append(nat.Plan(model, cptr, 20, 1, True, device=0))
+        bufs.append((d_gp, d_at, torch.zeros(n, dtype=torch.float64, device="cuda:0"), torch.full((n,), 5, dtype=torch.int8, device="cuda:0")))
+        eys.append(orc.viterbi(w, trans, cptr, gptr, attr)[0])
+    for k in range(3):
+        plans[k].run_decode_pipelined(bufs[k][0].data_ptr(), bufs[k][1].data_ptr(), bufs[k][2].data_ptr(),
+                                      plans[k - 1] if k else None, bufs[k - 1][3].data_ptr() if k else 0)
+    plans[2].flush_decode_pipelined(bufs[2][3].data_ptr())
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert np.array_equal(bufs[k][3].cpu().numpy().astype(np.int32), eys[k]), k

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """rocprofv3 PMC passes (rocpd sqlite, one pass per counter group: tools/profile.sh) -> profiles/pmc_traffic.json,
 the per-launch counter figures bench.py quotes next to its live timings.
-usage: pmc_to_json.py <dir-with-pmc*/ dbs> <workload> <tag> [kernel-substring]"""
+usage: pmc_to_json.py <dir-with-pmc*/ dbs> <workload[:pipelined]> <tag> [kernel-substring]
+(`C3` = the window kernel from passes of `bench.py --windowed-only`; `C3:pipelined` = crf_decode_pipelined from passes of
+the default schedule)"""
 import datetime
 import glob
 import json
@@ -34,7 +36,7 @@ def main():
     import hashlib
 
     sha = hashlib.sha256()
-    for name in ("crf_kernels.hip", "crf_device.hpp"):
+    for name in ("crf_kernels.hip", "crf_device.hpp", "crf_vd_short.hpp", "crf_scan.hpp"):
         with open(os.path.join(repo, "gecco_amd", "csrc", name), "rb") as fh:
             sha.update(fh.read())
     try:
@@ -48,7 +50,7 @@ def main():
         "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
         "kernel": kernel,
         "source": f"profiles/{tag}_pmc.json <- {os.path.relpath(os.path.abspath(root), repo)}/pmc*: rocprofv3 --pmc passes of "
-                  f"`bench.py --windowed-only` ({datetime.date.today().isoformat()}), FETCH_SIZE x2 (gfx950 read-side correction) "
+                  f"`bench.py{'' if ':' in workload else ' --windowed-only'}` ({datetime.date.today().isoformat()}), FETCH_SIZE x2 (gfx950 read-side correction) "
                   f"+ WRITE_SIZE",
         "kernel_source_sha16": sha.hexdigest()[:16],  # bench.py drops these figures when the kernel source has changed since
     }
@@ -59,7 +61,13 @@ def main():
             entry[c] = vals[c]
     doc[workload] = entry
     json.dump(doc, open(out_path, "w"), indent=1)
-    json.dump({workload: dict(entry, all_counters=vals)}, open(os.path.join(os.path.dirname(out_path), f"{tag}_pmc.json"), "w"), indent=1)
+    tag_path = os.path.join(os.path.dirname(out_path), f"{tag}_pmc.json")
+    try:
+        tag_doc = json.load(open(tag_path))
+    except Exception:
+        tag_doc = {}
+    tag_doc[workload] = dict(entry, all_counters=vals)
+    json.dump(tag_doc, open(tag_path, "w"), indent=1)
     print(json.dumps(entry, indent=1))
 
 
