@@ -84,6 +84,7 @@ def main() -> None:
                     help="weight law of the synthetic model: 'genome' (default, most genes lean to label 0) or SURVEY.md 8d to the letter")
     ap.add_argument("--no-levels", action="store_true", help="skip the host-buffer / tables / object API levels (SURVEY.md 8d)")
     ap.add_argument("--no-8d", action="store_true", help="skip the second roofline point on the 8d-exact weight law")
+    ap.add_argument("--no-c4", action="store_true", help="skip the 8-way shard point (profiles: keeps the per-kernel averages on one workload)")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "two-launch"],
                     help="pipelined: one launch per step = window tiles of batch k + Viterbi workgroups of batch k - 1 "
                          "(gecco_crf_plan_run_decode_pipelined, + one flush); two-launch: gecco_crf_plan_run_decode")
@@ -373,7 +374,9 @@ def main() -> None:
             "genes_on_rank0": shard.n_genes, "scaling": "strong",
             # what the launch law of the window kernel (T = 6.5 us + 6.35 us per 1000 workgroups, measured at
             # N = 1) plus a launch-bound Viterbi kernel (~5 us + its share of the 11 us at full size) predicts for a shard
-            "predicted_ms_per_step": (6.5 + 6.35 * shard.plan.num_tiles / 1000.0 + 5.0 + 6.0 * shard.n_genes / 2.0e6) * 1e-3,
+            # (pipelined schedule: ONE launch of tiles + ~genes / 2000 Viterbi workgroups on the same law)
+            "predicted_ms_per_step": ((6.5 + 6.35 * (shard.plan.num_tiles + shard.n_genes / 2000.0) / 1000.0 + 1.5) if pipelined else
+                                      (6.5 + 6.35 * shard.plan.num_tiles / 1000.0 + 5.0 + 6.0 * shard.n_genes / 2.0e6)) * 1e-3,
             "speedup_vs_one_device": (out["ms_per_step"] / (el / args.steps * 1e3)) if out.get("ms_per_step") else None,
         }
 
@@ -396,7 +399,7 @@ def main() -> None:
 
     # ---- the strong-scaling ceiling before the hardware is there: ONE shard of the 8-way partition of this batch
     # (BASELINE.json configs[3], C4), decoded on this device.  A step of a shard is launch-bound.
-    if rank == 0 and world == 1 and args.workload == "C3":
+    if rank == 0 and world == 1 and args.workload == "C3" and not args.no_c4:
         lengths = np.diff(base["contig_ptr"]).astype(np.int64)
         mine = sharding.partition_contigs(lengths, 8)[0]
         cptr, gptr, attr, _ = sharding.extract_shard(base["contig_ptr"], base["gene_ptr"], base["attr_id"], mine)

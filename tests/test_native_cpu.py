@@ -146,3 +146,14 @@ def test_no_cpu_fallback(blob):
     with pytest.raises(nat.NativeError) as ei:
         m.windowed_marginals([0, 30], np.arange(31), np.zeros(30, dtype=np.int32), 20)
     assert ei.value.code == nat.ENODEV
+
+
+def test_pipelined_decode_kernel_keeps_its_window_tiles_out_of_scratch():
+    """crf_decode_pipelined: the window tiles share a 64-VGPR kernel with the Viterbi workgroups, whose SGPR spills take
+    one of the 64 registers; a tile value in scratch costs a quarter of the step (44 instead of 35 us, measured).  The
+    cross-compiled assembly is checked: nothing but the entry reload of v0 touches scratch on the tile path."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_tile_path.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
