@@ -244,7 +244,10 @@ def main() -> None:
     # algorithmic bytes are the window kernel's plus one label byte per gene (the score differences the tiles leave for
     # the Viterbi workgroups of the next launch, 8 B written + 8 B read per gene, are the implementation's own traffic)
     pipe_ms = pipe_alg = None
-    if pipelined:
+    # (a batch with a contig longer than one 2 048-gene scan block takes the general whole-contig kernels: separate launches
+    # behind the same pipelined call, and the window kernel stays the dominant one)
+    one_launch = pipelined and int(np.diff(wl["contig_ptr"]).max(initial=0)) <= 2048
+    if one_launch:
         pipe_ms = res.plan.time_decode_pipelined(res.d_gp.data_ptr(), res.d_at.data_ptr(), res.d_p.data_ptr(), res.d_y.data_ptr(), LABEL,
                                                  res.stream, warmup=3, iters=args.kernel_iters)
         pipe_alg = alg_bytes + n_genes
@@ -333,9 +336,10 @@ def main() -> None:
         },
     }
     if pipelined:
+        out["two_launch_ms_per_step"] = two_launch_ms
+    if one_launch:
         # the step IS one launch of crf_decode_pipelined: that is the dominant kernel; the window kernel on its own (plain
         # launches, back to back) stays in the line as `roofline_window_kernel`
-        out["two_launch_ms_per_step"] = two_launch_ms
         out["roofline_window_kernel"] = out["roofline"]
         vi = pmc_pipe.get("SQ_INSTS_VALU")
         out["roofline"] = {
@@ -347,6 +351,9 @@ def main() -> None:
             "frac": pipe_alg / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "traffic": pmc_pipe.get("hbm_bytes_per_launch"),
             "traffic_source": pmc_pipe.get("source") or "no counter profile of this kernel source in profiles/pmc_traffic.json",
+            "traffic_note": "counter traffic holds what the algorithmic bytes leave out: the hand-over between launches (8 B/gene "
+                            "written by the tiles + 8 B/gene read by the Viterbi workgroups = 32 MB on C3), partial-line writes of "
+                            "the write-through stores (+13 MB in WRITE_SIZE) and the tiles' halo; no array is read twice (DESIGN.md 6)",
             "algorithmic_bytes_per_launch": pipe_alg,
             "kernel_ms": pipe_ms,
             "kernel_ms_note": "HIP events around back-to-back launches on the launch stream: includes the boundary between launches",

@@ -27,7 +27,7 @@ def main():
             pmc = []
         if pmc:
             for k, c, v, n in pmc:
-                short = k.split("(")[0].split("::")[-1]
+                short = k.replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1]
                 print(f"{name}\tPMC\t{short}\t{c}\t{v:.1f}\tn={n}")
         elif rows:
             for r in rows:
