@@ -8,6 +8,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+torch = pytest.importorskip("torch")  # (before libgecco_crf.so: the wheel's own libamdhip64 has to be the first one loaded)
+
 TOL = 1e-12
 
 
@@ -32,6 +34,25 @@ def _check_workload(name, whole_contig_marginals):
     eseg = orc.segment(exp, ann, cptr, 0.8, 3, 0, True, carry_state=False)
     assert len(eseg) > 0 and seg.tolist() == eseg.tolist()
     assert seg_off[-1] == int((seg[:, 3] - seg[:, 2]).sum())
+    # the throughput form of the decode step on resident buffers: the plan following itself three times, then the flush
+    # (C3: one launch per batch, crf_decode_pipelined; C5: the general whole-contig kernels behind the same call)
+    dev = torch.device("cuda:0")
+    d_gp, d_at = torch.from_numpy(gptr).to(dev), torch.from_numpy(attr).to(dev)
+    plan = nat.Plan(model, cptr, 20, 1, True, device=0)
+    ps = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(4)]
+    ys = [torch.full((n,), 9, dtype=torch.int8, device=dev) for _ in range(4)]
+    plan.run_decode(d_gp.data_ptr(), d_at.data_ptr(), ps[3].data_ptr(), ys[3].data_ptr())  # two launches, the same tiling
+    torch.cuda.synchronize()
+    p2, y2 = ps[3].cpu().numpy(), ys[3].cpu().numpy()
+    assert np.abs(p2 - exp).max() <= TOL and np.array_equal(y2, y)
+    for k in range(3):
+        plan.run_decode_pipelined(d_gp.data_ptr(), d_at.data_ptr(), ps[k].data_ptr(), plan if k else None, ys[k - 1].data_ptr() if k else 0)
+    plan.flush_decode_pipelined(ys[2].data_ptr())
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert np.array_equal(ps[k].cpu().numpy(), p2), k       # the bits of the two-launch decode
+        assert np.array_equal(ys[k].cpu().numpy(), y2), k
+    del ps, ys, d_gp, d_at, plan
     if whole_contig_marginals:
         marg, ln = model.marginals_full(cptr, gptr, attr)
         em, eln = orc.full_marginals(w, trans, cptr, gptr, attr)
