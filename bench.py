@@ -85,6 +85,8 @@ def main() -> None:
     ap.add_argument("--no-levels", action="store_true", help="skip the host-buffer / tables / object API levels (SURVEY.md 8d)")
     ap.add_argument("--no-8d", action="store_true", help="skip the second roofline point on the 8d-exact weight law")
     ap.add_argument("--no-c4", action="store_true", help="skip the 8-way shard point (profiles: keeps the per-kernel averages on one workload)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="pipelined schedule: independent decode streams (plan + HIP stream each) the batches alternate between")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "two-launch"],
                     help="pipelined: one launch per step = window tiles of batch k + Viterbi workgroups of batch k - 1 "
                          "(gecco_crf_plan_run_decode_pipelined, + one flush); two-launch: gecco_crf_plan_run_decode")
@@ -142,41 +144,50 @@ def main() -> None:
     class Resident:
         """One batch resident on this rank's device: plan + CSR + outputs."""
 
-        def __init__(self, model, cptr, gptr, attr):
+        def __init__(self, model, cptr, gptr, attr, lanes=1):
             self.n_genes, self.nnz, self.n_contigs = int(cptr[-1]), int(gptr[-1]), len(cptr) - 1
-            self.plan = nat.Plan(model, cptr, W, STEP, True, device=local_rank)
             self.d_gp = torch.from_numpy(np.ascontiguousarray(gptr)).to(dev)
             self.d_at = torch.from_numpy(np.ascontiguousarray(attr) if len(attr) else np.zeros(1, np.int32)).to(dev)
-            self.d_p = torch.zeros(max(self.n_genes, 1), dtype=torch.float64, device=dev)
-            self.d_y = torch.zeros(max(self.n_genes, 1), dtype=torch.int8, device=dev)
-            # a stream of its own, not the legacy default one: the decode step is replayed as a HIP graph, and streams
-            # are captured into graphs everywhere but there
-            if os.environ.get("GECCO_BENCH_OWN_STREAM", "1") == "1":
-                self.torch_stream = torch.cuda.Stream(dev)
-                self.stream = self.torch_stream.cuda_stream
-            else:
-                self.stream = torch.cuda.current_stream(dev).cuda_stream
-
-        primed = False  # pipelined schedule: the previous call has left a batch whose labels are still to come
+            # `lanes` independent decode streams (pipelined schedule): a plan (workspace), a HIP stream and output buffers
+            # each; batches alternate between them, so that the tail of one launch overlaps the head of the next
+            self.lanes = []
+            for k in range(max(1, lanes)):
+                ln = {"plan": nat.Plan(model, cptr, W, STEP, True, device=local_rank),
+                      "d_p": torch.zeros(max(self.n_genes, 1), dtype=torch.float64, device=dev),
+                      "d_y": torch.zeros(max(self.n_genes, 1), dtype=torch.int8, device=dev), "primed": False}
+                # a stream of its own, not the legacy default one (streams are captured into graphs everywhere but there)
+                if os.environ.get("GECCO_BENCH_OWN_STREAM", "1") == "1" or k > 0:
+                    ln["torch_stream"] = torch.cuda.Stream(dev)
+                    ln["stream"] = ln["torch_stream"].cuda_stream
+                else:
+                    ln["stream"] = torch.cuda.current_stream(dev).cuda_stream
+                self.lanes.append(ln)
+            l0 = self.lanes[0]
+            self.plan, self.d_p, self.d_y, self.stream = l0["plan"], l0["d_p"], l0["d_y"], l0["stream"]
+            self.turn = 0
 
         def step(self, schedule=None):
             schedule = schedule or args.schedule
             if args.windowed_only:
                 self.plan.run_windowed(self.d_gp.data_ptr(), self.d_at.data_ptr(), self.d_p.data_ptr(), LABEL, self.stream)
-            elif schedule == "pipelined":  # window tiles of this batch + Viterbi workgroups of the batch before, one launch
-                self.plan.run_decode_pipelined(self.d_gp.data_ptr(), self.d_at.data_ptr(), self.d_p.data_ptr(),
-                                               self.plan if self.primed else None, self.d_y.data_ptr() if self.primed else 0, LABEL,
-                                               self.stream)
-                self.primed = True
+            elif schedule == "pipelined":  # window tiles of this batch + Viterbi workgroups of the lane's batch before, one launch
+                ln = self.lanes[self.turn % len(self.lanes)]
+                self.turn += 1
+                ln["plan"].run_decode_pipelined(self.d_gp.data_ptr(), self.d_at.data_ptr(), ln["d_p"].data_ptr(),
+                                                ln["plan"] if ln["primed"] else None, ln["d_y"].data_ptr() if ln["primed"] else 0,
+                                                LABEL, ln["stream"])
+                ln["primed"] = True
             else:  # one pass over the CSR: state scores are accumulated once for both outputs
                 self.plan.run_decode(self.d_gp.data_ptr(), self.d_at.data_ptr(), self.d_p.data_ptr(), self.d_y.data_ptr(), LABEL, 0,
                                      self.stream)
 
         def flush(self):
-            """pipelined schedule: the labels of the last batch (a Viterbi-only launch)"""
-            if self.primed:
-                self.plan.flush_decode_pipelined(self.d_y.data_ptr(), self.stream)
-                self.primed = False
+            """pipelined schedule: the labels of every lane's last batch (a Viterbi-only launch each); the next step goes to lane 0"""
+            for ln in self.lanes:
+                if ln["primed"]:
+                    ln["plan"].flush_decode_pipelined(ln["d_y"].data_ptr(), ln["stream"])
+                    ln["primed"] = False
+            self.turn = 0
 
         def timed(self, steps, warmup, preroll_ms, schedule=None):
             """(seconds for `steps` steps, max over ranks), after `warmup` untimed ones.  Pipelined schedule: the region
@@ -223,17 +234,22 @@ def main() -> None:
         cptr, gptr, attr = synth.synth_contigs(rng, lengths, wl["A"], planted=0.01, hot_attrs=hot)
         wl.update(contig_ptr=cptr, gene_ptr=gptr, attr_id=attr)
     model = nat.Model.from_tables(wl["w"], wl["trans"])
-    res = Resident(model, wl["contig_ptr"], wl["gene_ptr"], wl["attr_id"])
+    n_lanes = args.streams if (args.schedule == "pipelined" and not args.windowed_only) else 1
+    res = Resident(model, wl["contig_ptr"], wl["gene_ptr"], wl["attr_id"], lanes=n_lanes)
     n_genes, nnz = res.n_genes, res.nnz
 
     elapsed = res.timed(args.steps, args.warmup, args.preroll_ms)
     total_genes = all_sum(n_genes)
     pipelined = args.schedule == "pipelined" and not args.windowed_only
     # the other schedule next to the headline (a quarter of the steps)
-    two_launch_ms = None
+    two_launch_ms = one_stream_ms = None
     if pipelined:
         st2 = max(args.steps // 4, 1)
         two_launch_ms = res.timed(st2, min(args.warmup, 20), 0.0, schedule="two-launch") / st2 * 1e3
+        if len(res.lanes) > 1:  # the same pipelined schedule on ONE stream
+            keep, res.lanes = res.lanes, res.lanes[:1]
+            one_stream_ms = res.timed(st2, min(args.warmup, 20), 0.0) / st2 * 1e3
+            res.lanes = keep
 
     # ---- dominant kernel: average launch duration by HIP events on the launch stream
     kern_ms = res.plan.time_windowed(res.d_gp.data_ptr(), res.d_at.data_ptr(), res.d_p.data_ptr(), LABEL, res.stream, warmup=3,
@@ -305,9 +321,12 @@ def main() -> None:
             "synth_law": args.synth,
             "genes_per_gpu": n_genes,
             "viterbi_in_step": not args.windowed_only,
-            "schedule": ("pipelined over batches: launch k = window tiles of batch k + Viterbi workgroups of batch k - 1 "
-                         "(gecco_crf_plan_run_decode_pipelined); the timed region starts with an empty pipeline and ends with the "
-                         "flush: K window passes + K Viterbi passes in K + 1 launches" if pipelined else
+            "schedule": ("pipelined over batches: one launch = window tiles of a batch + Viterbi workgroups of the batch its decode "
+                         "stream scored before (gecco_crf_plan_run_decode_pipelined); "
+                         + (f"batches alternate between {n_lanes} independent decode streams (a plan and a HIP stream each), so "
+                            f"that the tail of one launch overlaps the head of the next; " if n_lanes > 1 else "")
+                         + "the timed region starts with empty pipelines and ends with their flushes: K window passes + K Viterbi "
+                           f"passes in K + {n_lanes} launches" if pipelined else
                          "two launches per batch (gecco_crf_plan_run_decode)" if not args.windowed_only else "window kernel only"),
             "device_preroll_ms": args.preroll_ms,
             "sharding": "independent contig batches per rank, no collective",
@@ -337,6 +356,7 @@ def main() -> None:
     }
     if pipelined:
         out["two_launch_ms_per_step"] = two_launch_ms
+        out["one_stream_ms_per_step"] = one_stream_ms
     if one_launch:
         # the step IS one launch of crf_decode_pipelined: that is the dominant kernel; the window kernel on its own (plain
         # launches, back to back) stays in the line as `roofline_window_kernel`
@@ -356,7 +376,10 @@ def main() -> None:
                             "the write-through stores (+13 MB in WRITE_SIZE) and the tiles' halo; no array is read twice (DESIGN.md 6)",
             "algorithmic_bytes_per_launch": pipe_alg,
             "kernel_ms": pipe_ms,
-            "kernel_ms_note": "HIP events around back-to-back launches on the launch stream: includes the boundary between launches",
+            "kernel_ms_note": "HIP events around back-to-back launches on ONE stream: includes the boundary between launches; with "
+                              "several decode streams two launches overlap, so a launch takes longer than this while a batch "
+                              "takes less (ms_per_step)",
+            "launches_in_flight": n_lanes,
             "valu_insts_per_launch": vi,
             "valu_frac": (vi * 4.0 / (pipe_ms * 1e-3 * SIMDS * SCLK_HZ)) if vi else None,
         }
@@ -371,7 +394,7 @@ def main() -> None:
         lengths = np.diff(base["contig_ptr"]).astype(np.int64)
         mine = sharding.partition_contigs(lengths, world)[rank]
         cptr, gptr, attr, _ = sharding.extract_shard(base["contig_ptr"], base["gene_ptr"], base["attr_id"], mine)
-        shard = Resident(model, cptr, gptr, attr)
+        shard = Resident(model, cptr, gptr, attr, lanes=n_lanes)
         el = shard.timed(args.steps, args.warmup, 0.0)
         tot = all_sum(shard.n_genes)
         out["strong_scaling"] = {
@@ -410,7 +433,7 @@ def main() -> None:
         lengths = np.diff(base["contig_ptr"]).astype(np.int64)
         mine = sharding.partition_contigs(lengths, 8)[0]
         cptr, gptr, attr, _ = sharding.extract_shard(base["contig_ptr"], base["gene_ptr"], base["attr_id"], mine)
-        sh = Resident(model, cptr, gptr, attr)
+        sh = Resident(model, cptr, gptr, attr, lanes=n_lanes)
         el = sh.timed(args.steps, min(args.warmup, 50), 0.0)
         wms = sh.plan.time_windowed(sh.d_gp.data_ptr(), sh.d_at.data_ptr(), sh.d_p.data_ptr(), LABEL, sh.stream, warmup=3, iters=50)
         out["c4_shard"] = {"genes": sh.n_genes, "workgroups": sh.plan.num_tiles, "c4_shard_ms": el / args.steps * 1e3,
@@ -425,7 +448,7 @@ def main() -> None:
     if rank == 0 and world == 1 and args.workload == "C3" and args.synth == "genome" and not args.no_8d:
         w8 = synth.workload("C3", seed=synth.SEED, law="8d")
         m8 = nat.Model.from_tables(w8["w"], w8["trans"])
-        r8 = Resident(m8, w8["contig_ptr"], w8["gene_ptr"], w8["attr_id"])
+        r8 = Resident(m8, w8["contig_ptr"], w8["gene_ptr"], w8["attr_id"], lanes=n_lanes)
         el8 = r8.timed(min(args.steps, 200), 20, 0.0)
         ms8 = r8.plan.time_windowed(r8.d_gp.data_ptr(), r8.d_at.data_ptr(), r8.d_p.data_ptr(), LABEL, r8.stream, warmup=3, iters=50)
         ab8 = _alg_bytes(r8.n_genes, r8.nnz, r8.n_contigs)

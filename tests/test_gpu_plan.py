@@ -273,3 +273,39 @@ def test_pipelined_decode_ties_take_crfsuites_recursion(nat):
     torch.cuda.synchronize()
     for k in range(3):
         assert np.array_equal(bufs[k][3].cpu().numpy().astype(np.int32), eys[k]), k
+
+
+def test_two_pipelined_decode_streams_side_by_side(nat, real, oracle_model):
+    """bench.py's default schedule: batches alternate between two independent decode streams (a plan and a HIP stream each),
+    so that two launches of crf_decode_pipelined are in flight.  Every batch's outputs equal the two-launch decode's."""
+    rng = np.random.default_rng(808)
+    A = oracle_model["state"].shape[0]
+    batches = [synth_contigs(rng, list(rng.integers(50, 400, size=400)), A) for _ in range(6)]
+    devb = [_dev(g, a) for _, g, a in batches]
+    exp = []
+    for (cptr, _, _), (d_gp, d_at) in zip(batches, devb):
+        n = int(cptr[-1])
+        p = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        y = torch.zeros(n, dtype=torch.int8, device="cuda:0")
+        nat.Plan(real, cptr, 20, 1, True, device=0).run_decode(d_gp.data_ptr(), d_at.data_ptr(), p.data_ptr(), y.data_ptr())
+        torch.cuda.synchronize()
+        exp.append((p.cpu().numpy(), y.cpu().numpy()))
+    plans = [nat.Plan(real, c, 20, 1, True, device=0) for c, _, _ in batches]
+    outs = [(torch.zeros(int(c[-1]), dtype=torch.float64, device="cuda:0"), torch.full((int(c[-1]),), 5, dtype=torch.int8, device="cuda:0"))
+            for c, _, _ in batches]
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+    last = [None, None]  # the batch each stream scored last
+    for rep in range(3):  # (the same plans again: a plan following itself two calls later on its stream)
+        for k in range(6):
+            s = k % 2
+            prev = last[s]
+            plans[k].run_decode_pipelined(devb[k][0].data_ptr(), devb[k][1].data_ptr(), outs[k][0].data_ptr(),
+                                          plans[prev] if prev is not None else None, outs[prev][1].data_ptr() if prev is not None else 0, 1,
+                                          streams[s].cuda_stream)
+            last[s] = k
+    for s in range(2):
+        plans[last[s]].flush_decode_pipelined(outs[last[s]][1].data_ptr(), streams[s].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(6):
+        assert np.array_equal(outs[k][0].cpu().numpy(), exp[k][0]) and np.array_equal(outs[k][1].cpu().numpy(), exp[k][1]), k

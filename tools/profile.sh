@@ -8,9 +8,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
-B="python bench.py --no-cpu-baseline --no-past-l3 --no-c4 --no-8d --no-levels $*"
-# kernel trace of the default bench run (device pre-roll + 100 warmup + 1000 timed steps + 200 kernel timings)
+B="python bench.py --no-cpu-baseline --no-past-l3 --no-c4 --no-8d --no-levels --streams 1 $*"
+# kernel trace of the bench run on ONE decode stream (device pre-roll + 100 warmup + 1000 timed steps + 200 kernel timings):
+# per-kernel averages that are launch durations
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B > $O/kt.log 2>&1
+# the same run on the default schedule (two decode streams: two launches of crf_decode_pipelined in flight, each longer than alone)
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt2 -o kt2 -- ${B/--streams 1/--streams 2} > $O/kt2.log 2>&1
 S="--steps 3 --warmup 1 --kernel-iters 3 --preroll-ms 0 --windowed-only --no-past-l3"  # few dispatches of ONE kind (plain windowed launches): the PMC passes serialise and slow every launch
 timeout 180 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc1 -o pmc1 -- $B $S > $O/pmc1.log 2>&1
 timeout 180 rocprofv3 --pmc FETCH_SIZE -d $O/pmc2 -o pmc2 -- $B $S > $O/pmc2.log 2>&1
