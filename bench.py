@@ -382,6 +382,10 @@ def main() -> None:
             "launches_in_flight": n_lanes,
             "valu_insts_per_launch": vi,
             "valu_frac": (vi * 4.0 / (pipe_ms * 1e-3 * SIMDS * SCLK_HZ)) if vi else None,
+            # the same at the rate batches leave the decode streams (launches overlap): how close the STEP is to the fp64
+            # issue bound; x 4.7 / 4 for the rate the chip sustains on fp64 (tools/ubench/valu_rates.hip)
+            "valu_frac_of_step": (vi * 4.0 / (out["ms_per_step"] * 1e-3 * SIMDS * SCLK_HZ)) if vi else None,
+            "valu_frac_of_step_at_sustained_rate": (vi * VALU_SUSTAINED_CYCLES / (out["ms_per_step"] * 1e-3 * SIMDS * SCLK_HZ)) if vi else None,
         }
     if world > 1:
         # who ran where: the process group that carried the timing barrier, and every rank's device

@@ -91,6 +91,10 @@ SIGNATURES = {
         ctypes.c_int,
         [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p],
     ),
+    "gecco_crf_session_windowed_degrees": (
+        ctypes.c_int,
+        [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _vp, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p],
+    ),
     "gecco_crf_session_decode": (
         ctypes.c_int,
         [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p,
@@ -614,6 +618,14 @@ def pinned_copy(a, dtype=None) -> np.ndarray:
     return out
 
 
+def degree_bytes(gene_ptr) -> np.ndarray:
+    """The wire format of `Session.windowed_marginals(degree=...)`: domain counts of the genes as bytes."""
+    d = np.diff(np.asarray(gene_ptr, dtype=np.int64))
+    if d.size and (d.min() < 0 or d.max() > 255):
+        raise ValueError("degree bytes need 0 <= domains per gene <= 255")
+    return np.ascontiguousarray(d, dtype=np.uint8) if d.size else np.zeros(1, dtype=np.uint8)
+
+
 class Session:
     """Batch driver over one or several devices (include/gecco_crf.h, `gecco_crf_session_*`): host
     arrays in, host arrays out; contig chunks are dealt to the devices longest-first and pipelined
@@ -653,11 +665,19 @@ class Session:
         n = int(contig_ptr[-1]) if len(contig_ptr) else 0
         return contig_ptr, gene_ptr, attr_id, n, max(len(contig_ptr) - 1, 0)
 
-    def windowed_marginals(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True, out=None):
+    def windowed_marginals(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True, out=None, degree=None):
+        """`degree`: the genes' domain counts as uint8 (== numpy.diff(gene_ptr)): they cross PCIe instead of the row pointers
+        (gecco_crf_session_windowed_degrees); `degree_bytes(gene_ptr)` makes them."""
         contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
         if out is None:
             out = np.empty(max(n, 1), dtype=np.float64)
         assert out.dtype == np.float64 and out.flags.c_contiguous and out.size >= n
+        if degree is not None:
+            assert degree.dtype == np.uint8 and degree.flags.c_contiguous and degree.size >= n
+            _check(self._lib.gecco_crf_session_windowed_degrees(self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p),
+                                                                degree.ctypes.data if degree.size else None, _ptr(attr_id, _c_i32p),
+                                                                int(window), int(step), int(label), int(bool(pad)), _ptr(out, _c_f64p)))
+            return out[:n]
         _check(self._lib.gecco_crf_session_windowed(self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p),
                                                     _ptr(attr_id, _c_i32p), int(window), int(step), int(label), int(bool(pad)),
                                                     _ptr(out, _c_f64p)))

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgecco_crf.so")
 SOURCES = ["crf_model.cpp", "crf_plan.cpp", "crf_session.cpp", "crf_tables.cpp", "capi.cpp", "crf_kernels.hip", "crf_stream.hip", "crf_sequence.hip", "crf_segment.hip", "crf_general.hip", "crf_composition.hip"]
-HEADERS = ["crf_model.hpp", "crf_plan.hpp", "crf_device.hpp", "crf_scan.hpp", "crf_session.hpp", "crf_tables.hpp", os.path.join("..", "..", "include", "gecco_crf.h")]
+HEADERS = ["crf_model.hpp", "crf_plan.hpp", "crf_device.hpp", "crf_scan.hpp", "crf_vd_short.hpp", "crf_session.hpp", "crf_tables.hpp", os.path.join("..", "..", "include", "gecco_crf.h")]
 ARCH = "gfx950"
 
 

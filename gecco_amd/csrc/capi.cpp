@@ -382,6 +382,19 @@ GECCO_API int gecco_crf_session_windowed(gecco_crf_session *s, const int32_t *co
     r.p_out = p_out;
     return run_guarded(*s->s, r);
 }
+GECCO_API int gecco_crf_session_windowed_degrees(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                                 const int32_t *gene_ptr, const uint8_t *degree, const int32_t *attr_id,
+                                                 int32_t window, int32_t step, int32_t label, int32_t pad, double *p_out) {
+    if (!s || !p_out || !degree) return GECCO_CRF_EINVAL;
+    BatchRequest r = csr_request(contig_ptr, n_contigs, gene_ptr, attr_id);
+    r.degree = degree;
+    r.window = window;
+    r.step = step;
+    r.label = label;
+    r.pad = pad;
+    r.p_out = p_out;
+    return run_guarded(*s->s, r);
+}
 GECCO_API int gecco_crf_session_decode(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
                                        const int32_t *gene_ptr, const int32_t *attr_id, int32_t window, int32_t step,
                                        int32_t label, int32_t pad, double *p_out, int8_t *y_out) {

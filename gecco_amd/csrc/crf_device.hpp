@@ -233,6 +233,10 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
                           int32_t *d_seg_off, int32_t *d_total, void *d_work, hipStream_t stream);
 // d_out (may be null): the probabilities of the rows' genes; x_*: copies of the rows, their offsets and their number
 // (null: none).  Inputs are read from device memory; the outputs may live in pinned host memory.
+// batch driver's wire format: degree bytes of a chunk's n genes -> its n + 1 row pointers (base + prefix sums); scratch of
+// degree_scratch_bytes(n); d_deg readable for 32 bytes past n
+size_t degree_scratch_bytes(int n);
+hipError_t launch_degree_to_row_ptr(const uint8_t *d_deg, int n, int32_t base, int32_t *d_row_ptr, int32_t *d_scratch, hipStream_t stream);
 hipError_t launch_segment_gather(const double *d_p, const int32_t *d_seg, const int32_t *d_seg_off, const int32_t *d_total,
                                  int max_seg, double *d_out, int cap, hipStream_t stream, int32_t *x_seg = nullptr,
                                  int32_t *x_off = nullptr, int32_t *x_total = nullptr);

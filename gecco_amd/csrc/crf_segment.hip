@@ -412,6 +412,91 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
     return hipGetLastError();
 }
 
+// ---- wire format of the batch driver: one DEGREE BYTE per gene instead of a 4-byte row pointer -------------------------------
+// A chunk's row pointers are the prefix sums of its genes' domain counts, and a gene has a handful of domains: the host
+// sends the counts as bytes (a quarter of the row pointers' bytes; SURVEY.md 8d, PCIe-inclusive level) and three small
+// launches on the compute stream turn them into the int32 row pointers the kernels read (base = the caller's offset of
+// the chunk's first domain, so that the attribute array is still addressed with the caller's offsets).
+namespace {
+constexpr int kDegT = 256, kDegPer = 16, kDegBlock = kDegT * kDegPer;  // 4 096 genes per workgroup, 16 per lane (one 16-byte load)
+
+__device__ __forceinline__ int deg_lane_counts(const uint8_t *__restrict__ deg, int n, int i0, int (&c)[kDegPer]) {
+    // (the buffer is allocated with 32 bytes of slack behind the chunk: the 16-byte load may run past n, the values are masked)
+    const uint4 v = i0 < n ? *reinterpret_cast<const uint4 *>(deg + i0) : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kDegPer; ++k) {
+        c[k] = (i0 + k < n) ? int((w[k >> 2] >> (8 * (k & 3))) & 0xffu) : 0;
+        sum += c[k];
+    }
+    return sum;
+}
+__device__ __forceinline__ int deg_block_exclusive(int mine, int *lds /* kDegT / 64 + 1 */, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    int pre = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kDegT / 64; ++w) {
+        const int t = lds[w];
+        if (w < wave) pre += t;
+        all += t;
+    }
+    __syncthreads();
+    *total = all;
+    return pre + incl - mine;
+}
+__global__ void __launch_bounds__(kDegT) deg_block_sums(const uint8_t *__restrict__ deg, int n, int32_t *__restrict__ sums) {
+    __shared__ int lds[kDegT / 64];
+    int c[kDegPer], total;
+    const int mine = deg_lane_counts(deg, n, blockIdx.x * kDegBlock + threadIdx.x * kDegPer, c);
+    (void)deg_block_exclusive(mine, lds, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(kDegT) deg_scan_sums(int32_t *__restrict__ sums, int nb) {  // ONE workgroup, in place, exclusive
+    __shared__ int lds[kDegT / 64];
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += kDegT) {
+        const int i = b0 + threadIdx.x, mine = i < nb ? sums[i] : 0;
+        int total;
+        const int ex = deg_block_exclusive(mine, lds, &total);
+        if (i < nb) sums[i] = carry + ex;
+        carry += total;
+    }
+}
+__global__ void __launch_bounds__(kDegT) deg_row_ptr(const uint8_t *__restrict__ deg, int n, const int32_t *__restrict__ sums,
+                                                    int32_t base, int32_t *__restrict__ row_ptr) {
+    __shared__ int lds[kDegT / 64];
+    int c[kDegPer], total;
+    const int i0 = blockIdx.x * kDegBlock + threadIdx.x * kDegPer;
+    const int mine = deg_lane_counts(deg, n, i0, c);
+    int run = base + sums[blockIdx.x] + deg_block_exclusive(mine, lds, &total);
+#pragma unroll
+    for (int k = 0; k < kDegPer; ++k) {
+        if (i0 + k <= n) row_ptr[i0 + k] = run;  // (entry n = base + the chunk's total: written by the lane that owns position n)
+        run += c[k];
+    }
+}
+}  // namespace
+
+size_t degree_scratch_bytes(int n) { return (size_t((n + kDegBlock) / kDegBlock) + 1) * 4; }
+
+hipError_t launch_degree_to_row_ptr(const uint8_t *d_deg, int n, int32_t base, int32_t *d_row_ptr, int32_t *d_scratch, hipStream_t stream) {
+    if (n < 0) return hipErrorInvalidValue;
+    const int nb = (n + kDegBlock) / kDegBlock;  // (n + 1 positions: position n carries the total)
+    hipLaunchKernelGGL(deg_block_sums, dim3(nb), dim3(kDegT), 0, stream, d_deg, n, d_scratch);
+    hipLaunchKernelGGL(deg_scan_sums, dim3(1), dim3(kDegT), 0, stream, d_scratch, nb);
+    hipLaunchKernelGGL(deg_row_ptr, dim3(nb), dim3(kDegT), 0, stream, d_deg, n, d_scratch, base, d_row_ptr);
+    return hipGetLastError();
+}
+
 hipError_t launch_segment_gather(const double *d_p, const int32_t *d_seg, const int32_t *d_seg_off, const int32_t *d_total,
                                  int max_seg, double *d_out, int cap, hipStream_t stream, int32_t *x_seg, int32_t *x_off,
                                  int32_t *x_total) {

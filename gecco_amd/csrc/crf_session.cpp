@@ -102,7 +102,7 @@ struct Lane {
     hipEvent_t ev_up = nullptr, ev_comp = nullptr, done = nullptr;
     int chunk = -1;  // index of the chunk in flight, -1: idle
     Plan plan;
-    DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg;
+    DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg, d_deg, d_deg_ws;
     HostBuf h_seg;  // [total][pad..][seg_off: cap+1][rows: cap*4][p of the rows: n_genes]
     int32_t seg_cap = 0;
     size_t o_off = 0, o_rows = 0, o_p = 0;
@@ -135,7 +135,7 @@ Session::~Session() {
         if (hipSetDevice(d->device) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
         for (Lane &ln : d->lanes) {
-            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi, &ln.d_seg}) b->release();
+            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi, &ln.d_seg, &ln.d_deg, &ln.d_deg_ws}) b->release();
             ln.h_seg.release();
             for (hipEvent_t e : {ln.ev_up, ln.ev_comp, ln.done})
                 if (e) (void)hipEventDestroy(e);
@@ -298,7 +298,14 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
     int64_t b0 = 0;  // first marker offset of the chunk (antismash criterion)
     // ---- uploads first: the bulk copies are on their way while the host lays the chunk out
     if (ng) {
-        if (!X.z_gene_ptr) {
+        if (r.degree) {  // degree bytes cross PCIe; the row pointers are rebuilt on the device (below, on the compute stream)
+            if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
+            if ((rc = ln.d_deg.reserve(size_t(ng) + 32, "hipMalloc degrees"))) return rc;
+            if ((rc = ln.d_deg_ws.reserve(degree_scratch_bytes(ng), "hipMalloc degree scan"))) return rc;
+            if ((rc = check_hip(hipMemcpyAsync(ln.d_deg.p, r.degree + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D degrees")))
+                return rc;
+            S.stats.h2d_bytes += int64_t(ng);
+        } else if (!X.z_gene_ptr) {
             if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
             if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.g0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.up), "H2D gene_ptr")))
                 return rc;
@@ -354,7 +361,11 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
     if (ng == 0) return check_hip(hipEventRecord(ln.done, ln.comp), "hipEventRecord");
     // gene_ptr keeps the caller's offsets: the attribute array is addressed from where its element 0 would be
     // (a pinned attribute array is addressed from its own element 0: the offsets are already right)
-    const int32_t *d_gp = X.z_gene_ptr ? X.z_gene_ptr + ck.g0 : reinterpret_cast<const int32_t *>(ln.d_gp.p);
+    const int32_t *d_gp = (X.z_gene_ptr && !r.degree) ? X.z_gene_ptr + ck.g0 : reinterpret_cast<const int32_t *>(ln.d_gp.p);
+    if (r.degree && (rc = check_hip(launch_degree_to_row_ptr(reinterpret_cast<const uint8_t *>(ln.d_deg.p), int(ng), int32_t(a0),
+                                                               reinterpret_cast<int32_t *>(ln.d_gp.p),
+                                                               reinterpret_cast<int32_t *>(ln.d_deg_ws.p), ln.comp), "degree scan launch")))
+        return rc;
     const int32_t *d_at = X.z_attr_id ? X.z_attr_id : reinterpret_cast<const int32_t *>(ln.d_at.p) - a0;
     double *d_p = nullptr, *d_score = nullptr;
     int8_t *d_y = nullptr;

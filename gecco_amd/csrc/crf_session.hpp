@@ -19,6 +19,10 @@ struct BatchRequest {
     const int32_t *contig_ptr = nullptr;
     int32_t n_contigs = 0;
     const int32_t *gene_ptr = nullptr, *attr_id = nullptr;
+    // optional wire format: degree[i] = gene_ptr[i + 1] - gene_ptr[i] as bytes (every gene has at most 255 domains).  When
+    // given, the degrees are what crosses PCIe (1 instead of 4 bytes per gene) and the row pointers are rebuilt on the
+    // device; gene_ptr is then only read at chunk boundaries, on the host.
+    const uint8_t *degree = nullptr;
     int32_t window = 1, step = 1, label = 0, pad = 1;
     // what to compute, by output (null = not wanted)
     double *p_out = nullptr;        // [n_genes]      windowed marginals (row W)

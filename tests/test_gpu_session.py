@@ -257,3 +257,29 @@ def test_session_clusters_antismash(nat, real_model, oracle_model, chunk):
     assert seg.tolist() == exp.tolist()
     with pytest.raises(Exception, match="marker"):
         ses.clusters(cptr, gptr, attr, ann, 20, 1, 1, True, thr, 3, 0, True, criterion="antismash")
+
+
+def test_degree_byte_wire_format_equals_row_pointers(nat, real_model, oracle_model):
+    """gecco_crf_session_windowed_degrees: one degree byte per gene crosses PCIe instead of a 4-byte row pointer, the row
+    pointers are rebuilt on the device (prefix sums, per chunk, with the caller's offsets).  Same bits as the row-pointer
+    call over pageable and pinned buffers, several chunks, sizes around the scan's 4 096-gene blocks, genes with 0 and with
+    many domains, an empty batch."""
+    rng = np.random.default_rng(4242)
+    A = oracle_model["state"].shape[0]
+    ses = nat.Session(real_model, [0])
+    for lengths, chunk in (([4095], 1 << 19), ([4096], 1 << 19), ([4097, 1], 1 << 19), (list(rng.integers(1, 500, size=400)), 4000),
+                           (list(rng.integers(1, 3000, size=60)), 20000), ([], 1 << 19)):
+        cptr, gptr, attr = synth_contigs(rng, lengths, A)
+        ses.set_chunk_genes(chunk)
+        deg = nat.degree_bytes(gptr)
+        n = int(cptr[-1])
+        a = ses.windowed_marginals(cptr, gptr, attr, 20).copy()
+        b = ses.windowed_marginals(cptr, gptr, attr, 20, degree=deg).copy()
+        assert np.array_equal(a, b, equal_nan=True), (lengths[:3], chunk)
+        if n:
+            cp, gp, at, dg = (nat.pinned_copy(x) for x in (cptr, gptr, attr, deg))
+            out = nat.pinned_empty(n, np.float64)
+            c = ses.windowed_marginals(cp, gp, at, 20, out=out, degree=dg)
+            assert np.array_equal(a, c, equal_nan=True)
+    with pytest.raises(ValueError):
+        nat.degree_bytes(np.array([0, 300], dtype=np.int32))
