@@ -22,10 +22,23 @@ static_assert(kBlockGenes == kSeqBlockGenes, "host tables assume this block size
 // 24-byte elements, a 7-op combine, no reset flag, and 8 instead of 16 bytes of input per gene.
 // Differences of accumulated scores stay O(1), so this form is if anything closer to exact
 // arithmetic than the delta recursion itself; with integer-valued weights both are exact.
+// fmin / fmax on a value the compiler cannot prove canonical (it came through LDS, DPP moves or a select) cost a
+// canonicalising v_max_f64 x, x, x each on top; nothing here is ever a NaN (score differences, +-inf of the identity map,
+// 1e30 of the padding positions), so the bare instructions are used.
+__device__ __forceinline__ double vd_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vd_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 struct COp {
     static __device__ __forceinline__ CE identity() { return CE{0.0, -__builtin_huge_val(), __builtin_huge_val()}; }
     static __device__ __forceinline__ CE combine(const CE &a, const CE &b) {  // a applied first
-        return CE{a.a + b.a, fmin(fmax(a.L + b.a, b.L), b.H), fmin(fmax(a.H + b.a, b.L), b.H)};
+        return CE{a.a + b.a, vd_min(vd_max(a.L + b.a, b.L), b.H), vd_min(vd_max(a.H + b.a, b.L), b.H)};
     }
 };
 
@@ -252,15 +265,21 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     // (the lane's values are read from its LDS row in every pass instead of living in 16 VGPRs across the workgroup
     // scans: the body has to fit the 64 registers of the fused decode kernel)
     const double *row = stg.st + slot * (kGPL + 1);
+    // The lane's eight genes as ONE map x -> min(max(x + a, L), H): applying gene k to the map built so far is
+    //   a += c_k;  L = clamp(L, lo, hi) + c_k;  H = clamp(H, lo, hi) + c_k      (c_k = (t11 - t00) + d_k)
+    // -- the same bits as COp::combine with the gene's own map (c, lo + c, hi + c), because rounding is monotone
+    // (fl(max(L, lo) + c) = max(fl(L + c), fl(lo + c))), in 8 instead of 13 fp64 instructions per gene.  A contig's
+    // first gene is the constant map L = H = d (its `a` is never used again: a constant map stays one).
     CE P = COp::identity();
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
         const double dvk = row[k];
-        // a contig's first gene is the constant map L = H = d (its `a` is never used again: a constant map stays one)
         const bool fst = (first >> k) & 1u;
         const double c = A.v_k + dvk;
-        const CE e{c, fst ? dvk : A.v_lo + c, fst ? dvk : A.v_hi + c};
-        P = COp::combine(P, e);
+        const double l2 = vd_min(vd_max(P.L, A.v_lo), A.v_hi) + c, h2 = vd_min(vd_max(P.H, A.v_lo), A.v_hi) + c;
+        P.a += c;
+        P.L = fst ? dvk : l2;
+        P.H = fst ? dvk : h2;
     }
     CE total;
     const CE M = block_scan_exclusive<COp, false>(P, lds, &total);  // the workgroup starts at a contig start
@@ -280,7 +299,7 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
 #pragma unroll
         for (int k = 0; k < kGPL; ++k) {
             const double dvk = row[k];
-            Dq = ((first >> k) & 1u) ? dvk : fmin(fmax(Dq, A.v_lo), A.v_hi) + (A.v_k + dvk);
+            Dq = ((first >> k) & 1u) ? dvk : vd_min(vd_max(Dq, A.v_lo), A.v_hi) + (A.v_k + dvk);
             // a contig's last gene decides the end label: both of its "thresholds" are 0 (maps 3 / 0)
             const bool lst = (last >> k) & 1u;
             const double thi = lst ? 0.0 : A.v_hi, tlo = lst ? 0.0 : A.v_lo;
