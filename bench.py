@@ -373,7 +373,7 @@ def main() -> None:
             "traffic_source": pmc_pipe.get("source") or "no counter profile of this kernel source in profiles/pmc_traffic.json",
             "traffic_note": "counter traffic holds what the algorithmic bytes leave out: the hand-over between launches (8 B/gene "
                             "written by the tiles + 8 B/gene read by the Viterbi workgroups = 32 MB on C3), partial-line writes of "
-                            "the write-through stores (+13 MB in WRITE_SIZE) and the tiles' halo; no array is read twice (DESIGN.md 6)",
+                            "the write-through stores (+9...13 MB in WRITE_SIZE) and the tiles' halo; no array is read twice (DESIGN.md 6)",
             "algorithmic_bytes_per_launch": pipe_alg,
             "kernel_ms": pipe_ms,
             "kernel_ms_note": "HIP events around back-to-back launches on ONE stream: includes the boundary between launches; with "
