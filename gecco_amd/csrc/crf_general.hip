@@ -142,8 +142,8 @@ __global__ void __launch_bounds__(kGT) gl_windowed(GenArgs a) {
     }
 }
 
-// ---- rows A/B, P, W for a handful of labels (3 or 4): the two-label kernel's design ---------------------------------
-// One LANE per window start, everything of the window in its registers (crf_kernels.hip): with L <= 4 the vectors are
+// ---- rows A/B, P, W for a handful of labels (up to 8): the two-label kernel's design ---------------------------------
+// One LANE per window start, everything of the window in its registers (crf_kernels.hip): with L <= 8 the vectors are
 // L doubles, a step is L*L FMAs + L multiplications, and a group of lanes exchanging vector components through LDS --
 // the kernel above, written for up to 32 labels -- spends most of its time on that exchange (1.6 G genes/s at L = 3).
 //   * un-normalised recurrences on max-normalised factors (exp(state - max state): gl_state; exp(trans - max trans)):
@@ -163,7 +163,7 @@ __device__ __forceinline__ double gl_wave_shr1_zero(double v) {  // lane l <- la
     return __hiloint2double(hi, lo);
 }
 struct SmallTrans {
-    double m[16];  // exp(trans - max), labels permuted (queried label first), row-major L x L
+    double m[64];  // exp(trans - max), labels permuted (queried label first), row-major L x L (L <= 8)
 };
 template <int L, int WMAX>
 __global__ void __launch_bounds__(kSmallNT) gl_windowed_small(GenArgs a, SmallTrans T, const int4 *__restrict__ tile_desc) {
@@ -901,10 +901,11 @@ hipError_t launch_any(int what, const GenArgs &a, hipStream_t stream) {
 hipError_t launch_gen_state(const GenArgs &a, hipStream_t stream) { return launch_any(0, a, stream); }
 int gen_small_tile_out(int W) { return kSmallNT - (W - 1); }
 
-// the lane-per-window kernel takes 3 or 4 labels, windows of up to 32 genes and transition weights whose spread
-// cannot take W - 1 un-normalised steps out of the range
+// the lane-per-window kernel takes 3 to 8 labels (2 too: tests), windows of up to 32 genes (20 beyond 4 labels: W doubles of
+// alpha per lane next to four L-vectors) and transition weights whose spread cannot take W - 1 un-normalised steps out
+// of the range
 bool gen_small_ok(int L, int W, const double *trans_host) {
-    if ((L != 3 && L != 4) || W < 1 || W > 32 || !trans_host) return false;
+    if (L < 2 || L > 8 || W < 1 || W > (L <= 4 ? 32 : 20) || !trans_host) return false;
     double lo = trans_host[0], hi = trans_host[0];
     for (int i = 0; i < L * L; ++i) {
         lo = trans_host[i] < lo ? trans_host[i] : lo;
@@ -920,20 +921,25 @@ hipError_t launch_gen_windowed_small(const GenArgs &a, const double *trans_host,
     SmallTrans T{};
     double mx = trans_host[0];
     for (int i = 0; i < L * L; ++i) mx = trans_host[i] > mx ? trans_host[i] : mx;
-    int perm[4];
+    int perm[8];
     perm[0] = a.label;
     for (int j = 1; j < L; ++j) perm[j] = j <= a.label ? j - 1 : j;
     for (int i = 0; i < L; ++i)
         for (int j = 0; j < L; ++j) T.m[i * L + j] = exp(trans_host[perm[i] * L + perm[j]] - mx);
     const dim3 grid(ntiles), block(kSmallNT);
-    if (L == 3 && a.W <= 20)
-        hipLaunchKernelGGL((gl_windowed_small<3, 20>), grid, block, 0, stream, a, T, d_tile_desc);
-    else if (L == 3)
-        hipLaunchKernelGGL((gl_windowed_small<3, 32>), grid, block, 0, stream, a, T, d_tile_desc);
-    else if (a.W <= 20)
-        hipLaunchKernelGGL((gl_windowed_small<4, 20>), grid, block, 0, stream, a, T, d_tile_desc);
-    else
-        hipLaunchKernelGGL((gl_windowed_small<4, 32>), grid, block, 0, stream, a, T, d_tile_desc);
+#define GL_SMALL(LL, WW) hipLaunchKernelGGL((gl_windowed_small<LL, WW>), grid, block, 0, stream, a, T, d_tile_desc)
+    const bool w20 = a.W <= 20;
+    switch (L) {
+    case 2: if (w20) GL_SMALL(2, 20); else GL_SMALL(2, 32); break;
+    case 3: if (w20) GL_SMALL(3, 20); else GL_SMALL(3, 32); break;
+    case 4: if (w20) GL_SMALL(4, 20); else GL_SMALL(4, 32); break;
+    case 5: GL_SMALL(5, 20); break;
+    case 6: GL_SMALL(6, 20); break;
+    case 7: GL_SMALL(7, 20); break;
+    case 8: GL_SMALL(8, 20); break;
+    default: return hipErrorNotSupported;
+    }
+#undef GL_SMALL
     return hipGetLastError();
 }
 

@@ -354,7 +354,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     if (p.stream_phases) {
         p.kernel_name = "crf_windowed_stream_l2<20>";
         p.tile_out = windowed_stream_tile_out(W, p.stream_phases);
-    } else if (p.general && gen_small_ok(m.L, W, m.trans.data()) && !std::getenv("GECCO_CRF_GENERAL_GROUPS")) {
+    } else if (p.general && m.L >= 3 && gen_small_ok(m.L, W, m.trans.data()) && !std::getenv("GECCO_CRF_GENERAL_GROUPS")) {
         // a handful of labels: one lane per window start (GECCO_CRF_GENERAL_GROUPS=1: the lane-group kernel, tests / A/B)
         p.kernel_name = "gl_windowed_small";
         p.gen_small = true;

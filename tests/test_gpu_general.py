@@ -87,9 +87,9 @@ def test_viterbi_ties_first_argmax(nat, L):
     assert np.array_equal(sc, esc)
 
 
-@pytest.mark.parametrize("L", [3, 4])
+@pytest.mark.parametrize("L", [3, 4, 5, 6, 7, 8])
 def test_lane_per_window_kernel(nat, L, monkeypatch):
-    """3 and 4 labels take `gl_windowed_small` (one lane per window start, un-normalised recurrences, DPP maximum over
+    """3 to 8 labels take `gl_windowed_small` (one lane per window start, un-normalised recurrences, DPP maximum over
     the covering windows): every label, windows from 1 to 32 genes, steps, unpadded short contigs (skipped: irregular
     tiles), against the oracle and against the lane-group kernel (GECCO_CRF_GENERAL_GROUPS=1)."""
     from oracle import crf_oracle as orc
@@ -101,8 +101,9 @@ def test_lane_per_window_kernel(nat, L, monkeypatch):
     cptr, gptr, attr = synth_contigs(rng, lengths, A)
     model = nat.Model.from_tables(w, trans)
     assert nat.Plan(model, cptr, 20, 1, True, device=0).kernel_name == "gl_windowed_small"
-    cases = [(20, 1, True, lab) for lab in range(L)] + [(1, 1, True, 0), (2, 1, True, 1), (21, 1, True, 2), (32, 1, True, L - 1),
-                                                         (20, 7, True, 1), (20, 1, False, 0), (32, 5, False, 2), (5, 4, False, 1)]
+    wide = [(21, 1, True, 2), (32, 1, True, L - 1), (32, 5, False, 2)] if L <= 4 else [(19, 1, True, 2), (20, 3, False, L - 1)]
+    cases = [(20, 1, True, lab) for lab in range(L)] + [(1, 1, True, 0), (2, 1, True, 1), (20, 7, True, 1), (20, 1, False, 0),
+                                                         (5, 4, False, 1)] + wide
     for W, step, pad, label in cases:
         got = model.windowed_marginals(cptr, gptr, attr, W, step, label, pad)
         exp = orc.windowed_marginals(w, trans, cptr, gptr, attr, W, step, label, pad)

@@ -110,15 +110,18 @@ def test_host_only_plan_layout(blob):
 def test_host_only_plan_dispatch_by_label_count(blob, monkeypatch):
     rng = np.random.default_rng(1)
     m3 = nat.Model.from_tables(rng.normal(size=(9, 3)), rng.normal(size=(3, 3)))
-    # 3 or 4 labels: one lane per window start, tiles of 256 - (W - 1) slots ...
+    # 3 to 8 labels: one lane per window start, tiles of 256 - (W - 1) slots ...
     p3 = nat.Plan(m3, [0, 5000], 20, device=-1)
     assert p3.kernel_name == "gl_windowed_small" and p3.num_tiles == -(-5000 // (256 - 19))
     assert nat.Plan(m3, [0, 50], 33, device=-1).kernel_name == "gl_windowed"  # ... windows of up to 32 genes ...
     wide = rng.normal(size=(3, 3))
     wide[0, 1] = wide.min() - 40.0  # ... and transition weights W - 1 un-normalised steps cannot take out of the range
     assert nat.Plan(nat.Model.from_tables(rng.normal(size=(9, 3)), wide), [0, 50], 20, device=-1).kernel_name == "gl_windowed"
-    m5 = nat.Model.from_tables(rng.normal(size=(9, 5)), rng.normal(size=(5, 5)))
-    assert nat.Plan(m5, [0, 50], 20, device=-1).kernel_name == "gl_windowed"
+    m8 = nat.Model.from_tables(rng.normal(size=(9, 8)), rng.normal(size=(8, 8)))  # ... up to 8 labels at windows of up to 20
+    assert nat.Plan(m8, [0, 50], 20, device=-1).kernel_name == "gl_windowed_small"
+    assert nat.Plan(m8, [0, 50], 21, device=-1).kernel_name == "gl_windowed"
+    m9 = nat.Model.from_tables(rng.normal(size=(9, 9)), rng.normal(size=(9, 9)))
+    assert nat.Plan(m9, [0, 50], 20, device=-1).kernel_name == "gl_windowed"
     monkeypatch.setenv("GECCO_CRF_GENERAL_GROUPS", "1")
     assert nat.Plan(m3, [0, 50], 20, device=-1).kernel_name == "gl_windowed"
     monkeypatch.delenv("GECCO_CRF_GENERAL_GROUPS")

@@ -38,7 +38,7 @@ def main():
     d_gp = torch.from_numpy(gptr).to(dev)
     d_at = torch.from_numpy(attr).to(dev)
     only = [int(v) for v in sys.argv[1:]]  # label counts to run (all, plus the long-contig cases, when none is given)
-    for L in only or (2, 3, 4, 8, 32):
+    for L in only or (2, 3, 4, 6, 8, 16, 32):
         if L == 2:
             w, trans = synth.synth_model(A, rng)
             os.environ["GECCO_CRF_FORCE_GENERAL"] = "1"
