@@ -408,8 +408,10 @@ def main() -> None:
             "genes_on_rank0": shard.n_genes, "scaling": "strong",
             # what the launch law of the window kernel (T = 6.5 us + 6.35 us per 1000 workgroups, measured at
             # N = 1) plus a launch-bound Viterbi kernel (~5 us + its share of the 11 us at full size) predicts for a shard
-            # (pipelined schedule: ONE launch of tiles + ~genes / 2000 Viterbi workgroups on the same law)
-            "predicted_ms_per_step": ((6.5 + 6.35 * (shard.plan.num_tiles + shard.n_genes / 2000.0) / 1000.0 + 1.5) if pipelined else
+            # (pipelined schedule: ONE launch of tiles + ~genes / 2000 Viterbi workgroups on the same law; a shard's launch
+            # leaves most of the chip idle, so two decode streams run two of them side by side)
+            "predicted_ms_per_step": ((6.5 + 6.35 * (shard.plan.num_tiles + shard.n_genes / 2000.0) / 1000.0 + 1.5) / min(n_lanes, 2)
+                                      if pipelined else
                                       (6.5 + 6.35 * shard.plan.num_tiles / 1000.0 + 5.0 + 6.0 * shard.n_genes / 2.0e6)) * 1e-3,
             "speedup_vs_one_device": (out["ms_per_step"] / (el / args.steps * 1e3)) if out.get("ms_per_step") else None,
         }
