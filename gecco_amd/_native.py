@@ -618,6 +618,28 @@ def pinned_copy(a, dtype=None) -> np.ndarray:
     return out
 
 
+class DecodeStream:
+    """The pipelined decode (`gecco_crf_plan_run_decode_pipelined`) over a sequence of resident batches on one HIP stream:
+    `submit` enqueues the window marginals of a batch and the Viterbi labels of the batch submitted before it (one launch
+    when both qualify), `flush` the labels of the last one.  Two of these on two streams, batches alternating between
+    them, keep two launches in flight (bench.py's schedule).  The caller keeps a batch's device arrays alive until the
+    next `submit` / `flush` has been enqueued."""
+
+    def __init__(self, stream: int = 0):
+        self.stream = stream
+        self._prev = None  # (plan, address of its label buffer)
+
+    def submit(self, plan: "Plan", d_gene_ptr: int, d_attr_id: int, d_p_out: int, d_y_out: int, label: int = 1) -> None:
+        prev_plan, prev_y = self._prev if self._prev is not None else (None, 0)
+        plan.run_decode_pipelined(d_gene_ptr, d_attr_id, d_p_out, prev_plan, prev_y, label, self.stream)
+        self._prev = (plan, d_y_out)
+
+    def flush(self) -> None:
+        if self._prev is not None:
+            self._prev[0].flush_decode_pipelined(self._prev[1], self.stream)
+            self._prev = None
+
+
 def degree_bytes(gene_ptr) -> np.ndarray:
     """The wire format of `Session.windowed_marginals(degree=...)`: domain counts of the genes as bytes."""
     d = np.diff(np.asarray(gene_ptr, dtype=np.int64))

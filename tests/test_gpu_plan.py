@@ -309,3 +309,32 @@ def test_two_pipelined_decode_streams_side_by_side(nat, real, oracle_model):
     torch.cuda.synchronize()
     for k in range(6):
         assert np.array_equal(outs[k][0].cpu().numpy(), exp[k][0]) and np.array_equal(outs[k][1].cpu().numpy(), exp[k][1]), k
+
+
+def test_decode_stream_helper(nat, real, oracle_model):
+    """`_native.DecodeStream`: submit / flush bookkeeping of the pipelined decode; two of them side by side."""
+    rng = np.random.default_rng(515)
+    A = oracle_model["state"].shape[0]
+    batches = [synth_contigs(rng, list(rng.integers(20, 300, size=200)), A) for _ in range(5)]
+    devb = [_dev(g, a) for _, g, a in batches]
+    plans = [nat.Plan(real, c, 20, 1, True, device=0) for c, _, _ in batches]
+    outs = [(torch.zeros(int(c[-1]), dtype=torch.float64, device="cuda:0"), torch.full((int(c[-1]),), 5, dtype=torch.int8, device="cuda:0"))
+            for c, _, _ in batches]
+    exp = []
+    for k, (c, _, _) in enumerate(batches):
+        p = torch.zeros(int(c[-1]), dtype=torch.float64, device="cuda:0")
+        y = torch.zeros(int(c[-1]), dtype=torch.int8, device="cuda:0")
+        nat.Plan(real, c, 20, 1, True, device=0).run_decode(devb[k][0].data_ptr(), devb[k][1].data_ptr(), p.data_ptr(), y.data_ptr())
+        torch.cuda.synchronize()
+        exp.append((p.cpu().numpy(), y.cpu().numpy()))
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(2)]
+    ds = [nat.DecodeStream(s.cuda_stream) for s in streams]
+    torch.cuda.synchronize()
+    for k in range(5):
+        ds[k % 2].submit(plans[k], devb[k][0].data_ptr(), devb[k][1].data_ptr(), outs[k][0].data_ptr(), outs[k][1].data_ptr())
+    for d in ds:
+        d.flush()
+        d.flush()  # (nothing left: a no-op)
+    torch.cuda.synchronize()
+    for k in range(5):
+        assert np.array_equal(outs[k][0].cpu().numpy(), exp[k][0]) and np.array_equal(outs[k][1].cpu().numpy(), exp[k][1]), k
