@@ -25,6 +25,10 @@ def module():
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         _mod = mod
-    except Exception:
+    except Exception as exc:  # said once: the object API then runs ~7x slower Python statements of the same loops
+        import warnings
+
+        warnings.warn(f"gecco_amd: the C extension for the object API could not be built or loaded ({exc!r}); "
+                      "using the Python statements of the same loops", RuntimeWarning, stacklevel=2)
         _mod = None
     return _mod

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgecco_crf.so")
-SOURCES = ["crf_model.cpp", "crf_plan.cpp", "crf_session.cpp", "crf_tables.cpp", "capi.cpp", "crf_kernels.hip", "crf_stream.hip", "crf_sequence.hip", "crf_segment.hip", "crf_general.hip", "crf_composition.hip"]
+SOURCES = ["crf_model.cpp", "crf_plan.cpp", "crf_session.cpp", "crf_tables.cpp", "capi.cpp", "crf_kernels.hip", "crf_sequence.hip", "crf_segment.hip", "crf_general.hip", "crf_composition.hip"]
 HEADERS = ["crf_model.hpp", "crf_plan.hpp", "crf_device.hpp", "crf_scan.hpp", "crf_vd_short.hpp", "crf_session.hpp", "crf_tables.hpp", os.path.join("..", "..", "include", "gecco_crf.h")]
 ARCH = "gfx950"
 
@@ -47,7 +47,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    tmp = LIB + ".tmp"
+    tmp = f"{LIB}.{os.getpid()}.tmp"
     subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp, *objs])
     os.replace(tmp, LIB)
     return LIB
@@ -73,12 +73,13 @@ def build_objpath(force: bool = False, verbose: bool = False) -> str:
     cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
     if not cc:
         raise RuntimeError("no C compiler for gecco_amd/csrc/objpath.c")
+    tmp = f"{out}.{os.getpid()}.tmp"  # (several ranks may build at once: everyone links into a file of its own)
     cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter", "-I" + sysconfig.get_paths()["include"],
-           OBJPATH_SRC, "-o", out + ".tmp"]
+           OBJPATH_SRC, "-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(out + ".tmp", out)
+    os.replace(tmp, out)
     return out
 
 

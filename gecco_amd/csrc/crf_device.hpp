@@ -37,7 +37,7 @@ struct WinArgs {
     int32_t generic;            // 1: dispatch to the generic window kernel
     const double *exp_trans;   // [L*L] exp(trans) for the generic kernel
     double *scratch;           // generic kernel workspace
-    const double *rtab;        // [32] mu01 * 2^(j/32): exp table of the streaming kernel (crf_stream.hip)
+    const double *rtab;        // [32] mu01 * 2^(j/32): exp table of the ratio-form slot constants (mu_exp_tab)
 };
 
 // Geometry of the fast L==2 kernel.
@@ -165,16 +165,6 @@ hipError_t launch_seq_marginals(const SeqArgs &a, const int32_t *d_contig_ptr, h
 hipError_t launch_seq_marginals_short(const SeqArgs &a, const int32_t *gene_ptr, const int32_t *attr_id, const double2 *wtab01,
                                       int n_attrs, const int32_t *d_contig_ptr, hipStream_t stream);
 hipError_t launch_seq_viterbi(const SeqArgs &a, const int32_t *d_contig_ptr, hipStream_t stream);
-// The decode step in ONE launch (crf_kernels.hip: crf_decode_fused): window tiles and the Viterbi workgroups of short
-// contigs (vd_short's body) as blocks of the same grid; the tiles hand the score differences over inside the launch.
-struct FusedArgs {
-    const int32_t *role;  // [n_blocks] >= 0: window tile; < 0: Viterbi workgroup ~role; INT32_MIN: nothing to do
-    const int2 *vd_dep;   // [n_cblocks] first and last window tile whose score differences the Viterbi workgroup reads
-    uint32_t *tile_flag;  // [ntiles] epoch of the last launch in which the tile has published its score differences
-    uint32_t epoch;       // this launch (never 0; the plan counts)
-    int32_t n_blocks;
-};
-hipError_t launch_decode_fused(const WinArgs &w, const SeqArgs &s, const FusedArgs &f, hipStream_t stream);
 // The decode step pipelined over batches (crf_decode_pipelined): the window tiles of `w`'s batch and the Viterbi workgroups of
 // `s`'s batch (short contigs, score differences already in s.dstate) in one launch, nothing exchanged inside it.
 bool decode_pipelined_ok(const WinArgs &w, const SeqArgs &s);
@@ -298,10 +288,6 @@ const char *windowed_kernel_name(int W, int L, bool fast);
 // tile_out = output slots per workgroup for the kernel that (W, L) dispatches to.
 int windowed_tile_out(int W, int L, int tiles_per_wg);
 hipError_t launch_windowed(const WinArgs &a, hipStream_t stream);
-// streaming form (crf_stream.hip): L == 2, W == 20, no rescaling, batches without padded / skipped contigs
-constexpr int kWinStreamPhases = 0;  // phases of kWinThreads window starts per workgroup; 0 = the tiled kernel (default: measured faster); GECCO_CRF_STREAM=2|3|4 selects the streaming one
-int windowed_stream_tile_out(int W, int phases);
-hipError_t launch_windowed_stream(const WinArgs &a, int phases, hipStream_t stream);
 hipError_t launch_fill_nan(double *p, const int2 *ranges, int n_ranges, hipStream_t stream);
 
 }  // namespace gecco

@@ -615,6 +615,12 @@ __global__ void __launch_bounds__(kGT) gl_chunk_vecs(GenArgs a) {
     const int j = threadIdx.x & (LP - 1), grp = threadIdx.x / LP;
     const long long ct = static_cast<long long>(blockIdx.x) * G + grp;
     if (ct >= a.n_contigs) return;
+    // a contig without genes has no chunk, so none of the chunk kernels writes its log-partition / path score: 0, as the
+    // contig-sequential kernels give it
+    if (j == 0 && blockIdx.y == 0 && a.cc_ptr[ct + 1] == a.cc_ptr[ct]) {
+        if (!MAXPLUS && a.lognorm) a.lognorm[ct] = 0.0;
+        if (MAXPLUS && a.score) a.score[ct] = 0.0;
+    }
     if (MAXPLUS || blockIdx.y == 0)
         chunk_walk_fwd<LP, MAXPLUS>(a, ct, j, vecs + grp * LP);
     else

@@ -63,8 +63,7 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // The W = 20 kernel's outputs (probabilities, score differences: 16 B per gene, written once, read by a later launch)
 // leave as write-through stores (agent-scope relaxed atomic store = `global_store_dwordx2 ... sc1`): the lines do not
 // stay dirty in the XCD's L2, so the write-back at the end of the kernel -- which the next launch waits for -- has
-// less to do (decode step 40.5 -> 39.7 us on C3; plain and `nt` stores: 40.5 / 40.1).  In the fused decode launch the
-// same form is what hands the score differences to the Viterbi workgroups.
+// less to do (decode step 40.5 -> 39.7 us on C3; plain and `nt` stores: 40.5 / 40.1).
 __device__ __forceinline__ void store_wt(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -189,20 +188,15 @@ __device__ __forceinline__ void state_scores_buf(__amdgpu_buffer_rsrc_t ra, __am
 //   backward: c = e0 * b0;  b0' = c + f * b1;  b1' = c + g * b1
 //   candidate for slot s+k: x = a1 * b1 (label), y = a0 * b0 (other); all scale factors cancel
 //   in x / (x + y).
-// One window tile (workgroup `tile` of the launch).  PUBLISH: the tile is part of the fused decode launch
-// (crf_decode_fused below) and hands the score differences of its genes to the Viterbi workgroups of the SAME launch:
-// write-through stores, and its word of `tile_flag` set to `epoch` once they have left (behind the barrier of its first
-// DP phase, where the stores have long been acknowledged -- the wait costs nothing).
-// LEAN: the tile shares its kernel with the Viterbi workgroups, whose SGPR spills take one VGPR of the 64.
-template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT, bool PUBLISH, bool LEAN = PUBLISH>
-__device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT, TT, EXACT> &sm, const int tile, uint32_t *tile_flag,
-                                              const uint32_t epoch) {
+// One window tile (workgroup `tile` of the launch).
+// LEAN: the tile shares its kernel with the Viterbi workgroups (crf_decode_pipelined), whose SGPR spills take one VGPR of the 64.
+template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT, bool LEAN = false>
+__device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT, TT, EXACT> &sm, const int tile) {
     using Smem = WinSmem<WMAX, NT, TT, EXACT>;
     constexpr int JMAX = Smem::JMAX;
     // the ratio form exists for fixed-length windows only (with a run-time W <= 32 the second copy of
     // the unrolled DP costs more registers than it saves instructions)
     constexpr bool RATIO = !RESCALE && EXACT;
-    static_assert(!PUBLISH || RATIO, "the fused decode launch is built for the W = 20 ratio-form kernel");
     const int W = EXACT ? WMAX : P.W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int OUT = NT - (W - 1);             // output slots of one DP phase
@@ -270,11 +264,7 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
     double sc0[JMAX], sc1[JMAX];  // s[other], s[label] of the lane's slots
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) sc0[j] = sc1[j] = 0.0;
-#ifdef GECCO_EXP_SKIP_GATHER  // experiment: DP alone (no attribute / weight loads)
-    if (false) {
-#else
     if (td.w & 1) {
-#endif
         // Regular workgroup (the normal case): its slots are CONSECUTIVE GENES, so their attribute ids are one
         // contiguous stretch of the CSR.  The stretch is loaded attribute-per-lane -- consecutive lanes take
         // consecutive ids (coalesced), every id gathers its weight pair once -- parked in LDS (over the area the
@@ -351,10 +341,6 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
             off[j] = uint32_t(lo) - lo_tile;
             cnt[j] = uint32_t(hi - lo);
         }
-#ifdef GECCO_EXP_SKIP_GATHER
-#pragma unroll
-        for (int j = 0; j < JMAX; ++j) cnt[j] = 0;
-#endif
         int ids[JMAX][kGatherUnroll];
 #pragma unroll
         for (int j = 0; j < JMAX; ++j)
@@ -415,11 +401,7 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
     }
     // The score differences of the genes this workgroup owns, for the Viterbi decoder of the same batch.  Stored BEHIND the
     // slot constants (loads and stores retire in order -- one vmcnt -- so nothing that is waited for follows them).
-#ifdef GECCO_EXP_NO_DSTATE
-    if (false) {
-#else
     if (P.dstate_out) {
-#endif
 #pragma unroll
         for (int j = 0; j < JMAX; ++j) {
             if (TT > 1 || j == 0 || wave == 0) {
@@ -449,15 +431,6 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
 
     const uint32_t rmask = P.rescale_mask;
     const double rho = P.rho;
-#ifdef GECCO_EXP_SKIP_DP  // experiment: stage 1 alone
-    for (int ph = 0; ph < TT; ++ph) {
-        const int sbase = ph * OUT + tid;
-        const int q = q0 + sbase;
-        const int my_gene = (td.w & 1) ? ((q >= 0 && q < P.S) ? q + td.x : -1) : int(sm.ginfo[sbase] & 0x7fffffffu) - 1;
-        if (tid >= W - 1 && my_gene >= 0) P.p_out[my_gene] = rr[sbase];
-    }
-    return;
-#endif
 #pragma unroll 1
     for (int ph = 0; ph < TT; ++ph) {
         const int sbase = ph * OUT + tid;  // slot of this lane's window start (and of its output)
@@ -527,7 +500,7 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
             {
                 double r = __builtin_amdgcn_rcp(z);
                 r = fma(fma(-z, r, 1.0), r, r);
-                b0 = r0 < 0.0 ? r : 0.0;  // (the sign bit: a window may start here)
+                b0 = __double2hiint(r0) < 0 ? r : 0.0;  // (the sign bit itself: a window may start here; r may have underflowed to -0.0)
                 b1 = b0 * P.inv_kappa;
             }
             double R = 0.0;
@@ -569,13 +542,7 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
                     }
                 }
             }
-            if (PUBLISH && ph == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its stores have left
             __syncthreads();
-            if (PUBLISH && ph == 0 && tid == 0) {
-                uint32_t e = epoch;
-                asm volatile("" : "+s"(e));  // (its VGPR copy is made here, not hoisted out of the phase loop and spilled)
-                __hip_atomic_store(tile_flag, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             if (wave > 0 && lane < W - 1) {
                 int t2 = tid;
                 if (LEAN) asm volatile("" : "+v"(t2));  // (the index is recomputed per phase: one VGPR less across the DP)
@@ -720,72 +687,7 @@ template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT>
 // alpha (8 waves at W = 20, 3-5 at W <= 32), the rescaling variant 2 W (5 / 3)
 __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <= 20 ? (TT <= 2 ? 8 : 5) : 3))) crf_windowed_l2(const WinArgs P) {
     __shared__ WinSmem<WMAX, NT, TT, EXACT> sm;
-    windowed_tile<WMAX, EXACT, RESCALE, NT, TT, false>(P, sm, xcd_remap(blockIdx.x, P.ntiles), nullptr, 0u);
-}
-
-// ---- the decode step in ONE launch ------------------------------------------------------------------------------------
-// Window marginals + Viterbi labels of one batch used to be two launches: the window kernel wrote the genes' score
-// differences as a by-product, vd_short (crf_sequence.hip) read them after the kernel boundary -- ~11 us in which a
-// quarter of the chip waits on memory latency, plus the boundary.  Here the Viterbi workgroups are workgroups of the
-// SAME launch: `role` says what a block is (the host interleaves them: a Viterbi workgroup comes `lag` blocks of its
-// XCD after the last window tile it depends on, i.e. about when that tile has published), a Viterbi workgroup polls the
-// flags of its tiles (one wave, relaxed loads, s_sleep), takes ONE agent-scope acquire and then runs vd_short's body
-// on plain loads.  Window tiles never wait for anything, so the launch cannot deadlock as long as some slot of every XCD
-// is left to them (the host only fuses batches whose Viterbi workgroups are fewer than that); a poll that does not see
-// its flags within ~a second gives up and writes labels of -128 (tests: loud, no hang).
-constexpr unsigned kFusedSpinLimit = 1u << 22;
-__global__ void __launch_bounds__(kWinThreads, 8) crf_decode_fused(const WinArgs P, const SeqArgs A, const FusedArgs F) {
-    using Smem = WinSmem<20, kWinThreads, 2, true>;
-    constexpr size_t kBytes = sizeof(Smem) > sizeof(VdShortSmem) ? sizeof(Smem) : sizeof(VdShortSmem);
-    static_assert(kBytes <= 20480, "eight workgroups per CU");
-    __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
-    const int role = F.role[blockIdx.x];
-#ifdef GECCO_FUSED_TRACE  // variant builds: per block {start, flags seen / published, end} (wall clock, 100 MHz) behind the flags
-    unsigned long long *trace = reinterpret_cast<unsigned long long *>(F.tile_flag + ((P.ntiles + 63) & ~63)) + size_t(blockIdx.x) * 4;
-    if (threadIdx.x == 0) trace[0] = wall_clock64();
-#endif
-    if (role >= 0) {
-        windowed_tile<20, true, false, kWinThreads, 2, true>(P, *reinterpret_cast<Smem *>(raw), role, F.tile_flag + role, F.epoch);
-#ifdef GECCO_FUSED_TRACE
-        if (threadIdx.x == 0) trace[2] = wall_clock64();
-#endif
-        return;
-    }
-    if (role == INT32_MIN) return;  // (the XCDs' block sequences are padded to one length)
-    const int blk = ~role;
-    VdShortSmem &stg = *reinterpret_cast<VdShortSmem *>(raw);
-    if (threadIdx.x < 64) {
-        const int2 dep = F.vd_dep[blk];
-        bool ok = true;
-        for (int t0 = dep.x; t0 <= dep.y && ok; t0 += 64) {
-            const int t = t0 + int(threadIdx.x);
-            for (unsigned spins = 0;; ++spins) {
-                const uint32_t f = t <= dep.y ? __hip_atomic_load(F.tile_flag + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : F.epoch;
-                if (__builtin_amdgcn_ballot_w64(f != F.epoch) == 0) break;
-                if (spins >= kFusedSpinLimit) {
-                    ok = false;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (threadIdx.x == 0) stg.c_end = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (!stg.c_end) {
-        const int g0 = A.cblk[blk], g1 = A.cblk[blk + 1];
-        for (int g = g0 + int(threadIdx.x); g < g1; g += kWinThreads) A.y[g] = int8_t(-128);
-        return;
-    }
-    __syncthreads();  // (c_end is written again by the exact pass)
-#ifdef GECCO_FUSED_TRACE
-    if (threadIdx.x == 0) trace[1] = wall_clock64();
-#endif
-    vd_short_block(A, blk, stg);
-#ifdef GECCO_FUSED_TRACE
-    if (threadIdx.x == 0) trace[2] = wall_clock64();
-#endif
+    windowed_tile<WMAX, EXACT, RESCALE, NT, TT>(P, sm, xcd_remap(blockIdx.x, P.ntiles));
 }
 
 // ---- the decode step, software-pipelined over batches: ONE launch, NO hand-over inside it ---------------------------------
@@ -803,7 +705,7 @@ __global__ void __launch_bounds__(kWinThreads, 8) crf_decode_pipelined(const Win
     __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
     const int b = blockIdx.x;
     if (b >= nvd8) {
-        windowed_tile<20, true, false, kWinThreads, 2, false, true>(P, *reinterpret_cast<Smem *>(raw), xcd_remap(b - nvd8, P.ntiles), nullptr, 0u);
+        windowed_tile<20, true, false, kWinThreads, 2, true>(P, *reinterpret_cast<Smem *>(raw), xcd_remap(b - nvd8, P.ntiles));
         return;
     }
     if (b >= A.n_cblocks) return;
@@ -931,13 +833,6 @@ hipError_t launch_windowed(const WinArgs &a, hipStream_t stream) {
     case 3: return launch_windowed_tt<3>(a, stream);
     default: return hipErrorNotSupported;
     }
-}
-
-hipError_t launch_decode_fused(const WinArgs &w, const SeqArgs &s, const FusedArgs &f, hipStream_t stream) {
-    if (f.n_blocks <= 0) return hipSuccess;
-    if (w.W != 20 || w.rescale_mask != 0 || w.tiles_per_wg != 2 || w.generic || !w.dstate_out || !s.short_contigs) return hipErrorNotSupported;
-    hipLaunchKernelGGL(crf_decode_fused, dim3(f.n_blocks), dim3(kWinThreads), 0, stream, w, s, f);
-    return hipGetLastError();
 }
 
 bool decode_pipelined_ok(const WinArgs &w, const SeqArgs &s) {

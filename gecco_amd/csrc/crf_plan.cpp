@@ -84,7 +84,7 @@ int get_device_tables(const Model &m, int device, const DeviceTables **out) {
             for (size_t a = 0; a < A; ++a) w2[a] = make_double2(m.state[a * 2 + (1 - label)], m.state[a * 2 + label]);
             rc = upload(&t->wtab2[label], w2.data(), A, "upload state weight pairs");
         }
-        // r = mu01 exp(d) in the streaming window kernel: exp(d) = 2^e 2^(j/32) exp(r'), |r'| <= ln2/64; the table holds
+        // r = mu01 exp(d) in the window kernel (mu_exp_tab): exp(d) = 2^e 2^(j/32) exp(r'), |r'| <= ln2/64; the table holds
         // mu01 2^(j/32), rounded once from extended precision
         for (int label = 0; label < 2 && !rc; ++label) {
             const int o = 1 - label;
@@ -126,28 +126,16 @@ void Arena::release() {
     cap = 0;
 }
 
-void Plan::DecodeGraph::reset() {
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    exec = nullptr;
-    graph = nullptr;
-    seen = 0;
-    label = -1;
-    for (auto &k : key) k = nullptr;
-}
-
 Plan::~Plan() {
     if (device >= 0) {
         int prev = 0;
         if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(device) == hipSuccess) {
-            decode_graph.reset();
             tables.release();
             seq.release();
             (void)hipFree(d_seq_ws);
             (void)hipFree(d_win_scratch);
             (void)hipFree(d_gen_ws);
             (void)hipFree(d_gen_tab);
-            (void)hipFree(fused.d);
             (void)hipFree(d_seg_ws);
             (void)hipSetDevice(prev);
         }
@@ -238,10 +226,9 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
         set_error("a plan cannot move to another device");
         return GECCO_CRF_EINVAL;
     }
-    p.decode_graph.reset();  // (device pointers of the previous layout are baked into it)
     p.gen_small = false;
     p.gen_tab_chunk = 0;  // (chunk tables of the previous contigs)
-    p.fused.state = 0;    // (block roles of the previous layout)
+    p.pipe = Plan::Pipe{};  // (score differences and CSR pointers of the previous layout)
     p.model = &m;
     p.device = device;
     p.W = W;
@@ -340,21 +327,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     }
     // slot space = gene space everywhere: no contig padded, none skipped (empty contigs take no slots and no genes)
     p.all_regular = p.skipped.empty() && p.S == p.n_genes && irr_prefix[size_t(p.K)] == 0;
-    // kernel and geometry: the streaming kernel (crf_stream.hip) takes the headline shape -- two labels, W = 20, no
-    // rescaling --, the tiled one (crf_kernels.hip) everything else
-    {
-        const char *env = std::getenv("GECCO_CRF_STREAM");  // 0: tiled kernel; 2, 3, 4: phases per workgroup
-        int ph = kWinStreamPhases;
-        if (env && env[0] >= '0' && env[0] <= '9' && !env[1]) ph = env[0] - '0';
-        if (ph != 0 && ph != 2 && ph != 3 && ph != 4) ph = kWinStreamPhases;
-        // (its buffer offsets into the CSR arrays are 32-bit byte offsets: batches of 2^28 genes and more -- up to 2^30
-        // attribute ids -- stay with the tiled kernel, which addresses them relative to the workgroup)
-        p.stream_phases = (p.fast_ok && W == 20 && p.rescale_mask == 0 && p.n_genes < (1 << 28)) ? ph : 0;
-    }
-    if (p.stream_phases) {
-        p.kernel_name = "crf_windowed_stream_l2<20>";
-        p.tile_out = windowed_stream_tile_out(W, p.stream_phases);
-    } else if (p.general && m.L >= 3 && gen_small_ok(m.L, W, m.trans.data()) && !std::getenv("GECCO_CRF_GENERAL_GROUPS")) {
+    if (p.general && m.L >= 3 && gen_small_ok(m.L, W, m.trans.data()) && !std::getenv("GECCO_CRF_GENERAL_GROUPS")) {
         // a handful of labels: one lane per window start (GECCO_CRF_GENERAL_GROUPS=1: the lane-group kernel, tests / A/B)
         p.kernel_name = "gl_windowed_small";
         p.gen_small = true;
@@ -570,15 +543,14 @@ int run_windowed_general(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_at
 }
 }  // namespace
 
-// `fused`: the launch also carries the Viterbi workgroups of `fused->seq` (the decode step in one launch)
-struct FusedLaunch {
+// the launch also carries the Viterbi workgroups of `seq`, which belongs to the PREVIOUS batch (crf_decode_pipelined: nothing
+// is exchanged inside the launch)
+struct PipelinedLaunch {
     const SeqArgs *seq;
-    FusedArgs args;
-    bool pipelined = false;  // seq belongs to the PREVIOUS batch: crf_decode_pipelined (nothing exchanged inside the launch)
-    bool *took = nullptr;    // pipelined: set when the one launch was made (otherwise the caller launches the Viterbi side itself)
+    bool *took = nullptr;  // set when the one launch was made (otherwise the caller launches the Viterbi side itself)
 };
 static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
-                             double2 *d_state_out, double *d_dstate_out, hipStream_t stream, const FusedLaunch *fused = nullptr);
+                             double2 *d_state_out, double *d_dstate_out, hipStream_t stream, const PipelinedLaunch *piped = nullptr);
 
 int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                       hipStream_t stream) {
@@ -586,7 +558,7 @@ int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_
 }
 
 static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
-                             double2 *d_state_out, double *d_dstate_out, hipStream_t stream, const FusedLaunch *fused) {
+                             double2 *d_state_out, double *d_dstate_out, hipStream_t stream, const PipelinedLaunch *piped) {
     if (p.device < 0) {
         set_error("host-only plan: no HIP device bound (there is no CPU fallback)");
         return GECCO_CRF_ENODEV;
@@ -669,19 +641,9 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     if (!p.skipped.empty())
         if ((rc = check_hip(launch_fill_nan(d_p_out, p.d_skipped, int(p.skipped.size()), stream), "fill_nan launch")))
             return rc;
-    if (fused && fused->pipelined) {
-        if (!a.generic && !p.stream_phases && decode_pipelined_ok(a, *fused->seq)) {
-            *fused->took = true;
-            return check_hip(launch_decode_pipelined(a, *fused->seq, stream), "pipelined decode launch");
-        }
-    } else if (fused) {
-        return check_hip(launch_decode_fused(a, *fused->seq, fused->args, stream), "fused decode launch");
-    }
-    if (p.stream_phases && !a.state_out) return check_hip(launch_windowed_stream(a, p.stream_phases, stream), "windowed launch");
-    if (p.stream_phases) {
-        // 16-byte state scores as a by-product (matrix-form Viterbi, path scores): not a stream-kernel shape
-        set_error("internal: the streaming plan cannot emit 16-byte state scores");
-        return GECCO_CRF_EUNSUPPORTED;
+    if (piped && !a.generic && decode_pipelined_ok(a, *piped->seq)) {
+        *piped->took = true;
+        return check_hip(launch_decode_pipelined(a, *piped->seq, stream), "pipelined decode launch");
     }
     return check_hip(launch_windowed(a, stream), "windowed launch");
 }
@@ -1006,193 +968,10 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
 }
 
 
-static int run_decode_launches(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
-                               int8_t *d_y, double *d_score, hipStream_t stream);
-
 int plan_run_decode(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                     int8_t *d_y, double *d_score, hipStream_t stream) {
     p.pipe.pending = false;  // (the workspace of pipelined decode calls is written below)
-    // A resident batch decoded again and again with the same buffers (a service scoring with several models, the
-    // benchmark's steps, a shard of a strong-scaling run where the launches themselves dominate): replay the launches
-    // as a graph.  The first call runs plainly (it may allocate workspaces and upload tables: not capturable), the
-    // second one captures, from the third on one hipGraphLaunch.  Not on the legacy default stream (no capture there).
-    Plan::DecodeGraph &g = p.decode_graph;
-    static const bool enabled = [] {
-        const char *env = std::getenv("GECCO_CRF_GRAPH");  // opt-in: measured SLOWER than the two plain launches
-        return env && env[0] == '1';
-    }();
-    const void *key[5] = {d_gene_ptr, d_attr_id, d_p_out, d_y, d_score};
-    const bool same = g.label == label && g.stream == stream && std::equal(key, key + 5, g.key);
-    if (!enabled || !stream || p.device < 0) return run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
-    if (same && g.exec) {
-        int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
-        if (rc) return rc;
-        return check_hip(hipGraphLaunch(g.exec, stream), "decode graph launch");
-    }
-    if (same && g.seen < 0) return run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);  // (cannot capture)
-    if (!same || g.seen == 0) {
-        g.reset();
-        std::copy(key, key + 5, g.key);
-        g.label = label;
-        g.stream = stream;
-        int rc = run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
-        if (!rc) g.seen = 1;
-        return rc;
-    }
-    // second identical call: capture
-    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
-    if (rc) return rc;
-    if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-        (void)hipGetLastError();
-        g.seen = -1;  // this stream cannot capture: plain launches from now on
-        return run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
-    }
-    rc = run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
-    hipGraph_t graph = nullptr;
-    const hipError_t e = hipStreamEndCapture(stream, &graph);
-    if (rc || e != hipSuccess || !graph) {
-        if (graph) (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        g.seen = -1;
-        return rc ? rc : run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
-    }
-    hipGraphExec_t exec = nullptr;
-    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
-        (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        g.seen = -1;
-        return run_decode_launches(p, d_gene_ptr, d_attr_id, label, d_p_out, d_y, d_score, stream);
-    }
-    g.graph = graph;
-    g.exec = exec;
-    return check_hip(hipGraphLaunch(g.exec, stream), "decode graph launch");
-}
-
-// Block roles of the fused decode launch.  Workgroup b runs on XCD b % 8 (observed placement; speed only) and an XCD
-// starts its blocks in order, 256 at a time (32 CUs x 8).  Every XCD gets one contiguous range of window tiles (the
-// mapping xcd_remap gives the plain window kernel) and the Viterbi workgroups whose last tile lies in it; a Viterbi
-// workgroup follows that tile at a distance of `lag` blocks of the XCD -- about when the tile, started `lag` blocks
-// earlier, has published its score differences (behind its first DP phase, ~2/3 of its run) -- so that it neither
-// holds a slot spinning nor waits for the end of the launch.  GECCO_CRF_FUSED=0: two launches; GECCO_CRF_FUSED_LAG.
-static int plan_ensure_fused(Plan &p) {
-    std::lock_guard<std::mutex> lock(p.ws_mutex);
-    Plan::Fused &f = p.fused;
-    if (f.state) return GECCO_CRF_OK;
-    f.state = -1;
-    {
-        // Opt-in (GECCO_CRF_FUSED=1).  Measured on C3 (tools/fused_trace.py): 40.5 - 47 us against 36.8 us of
-        // kernel time for the two launches -- a Viterbi workgroup is a chain of dependent memory operations (~5 us alone,
-        // 10 - 13 us next to a thousand others), so whatever starts last ends 10 us later, and the slots it holds in the
-        // meantime are slots the window tiles lose; the flags only rise once the tile's write-through stores have been
-        // acknowledged (~ the tile's end, not 2/3 of its run).
-        const char *env = std::getenv("GECCO_CRF_FUSED");
-        if (!env || env[0] != '1') return GECCO_CRF_OK;
-    }
-    // Window tiles never wait, so the launch completes as long as the Viterbi workgroups cannot take every slot of an
-    // XCD: at most 192 of them per XCD (256 slots).  Larger batches do not notice a kernel boundary anyway.
-    if (p.general || !p.fast_ok || !p.skipped.empty() || p.W != 20 || p.rescale_mask != 0 || p.tiles_per_wg != 2 ||
-        p.stream_phases || !p.seq_short || p.n_cblocks <= 0 || p.n_cblocks > 8 * 192 || p.ntiles <= 0)
-        return GECCO_CRF_OK;
-    int lag = 176;
-    if (const char *env = std::getenv("GECCO_CRF_FUSED_LAG")) {
-        const int v = std::atoi(env);
-        if (v >= 0 && v <= 100000) lag = v;
-    }
-    // workgroups of whole contigs, as plan_ensure_seq cuts them
-    std::vector<int32_t> cblk;
-    {
-        int32_t start = 0;
-        cblk.push_back(0);
-        for (int32_t c = 0; c < p.n_contigs; ++c) {
-            const int32_t g1 = p.contig_ptr[c + 1];
-            if (g1 - start > kSeqBlockGenes) {
-                start = p.contig_ptr[c];
-                cblk.push_back(start);
-            }
-        }
-        cblk.push_back(p.n_genes);
-    }
-    if (int32_t(cblk.size()) - 1 != p.n_cblocks) return GECCO_CRF_OK;  // (never: the same cut)
-    const int32_t nt = p.ntiles, nv = p.n_cblocks;
-    std::vector<int2> dep(size_t(nv), make_int2(0, 0));
-    {
-        int k = 0;
-        auto tile_of = [&](int32_t g) {  // every gene lies in slot space here (no skipped contig)
-            while (k + 1 < p.K && p.c_gene[size_t(k) + 1] <= g) ++k;
-            const int32_t np = p.c_slot[size_t(k) + 1] - p.c_slot[size_t(k)], n = p.c_n[size_t(k)];
-            const int64_t slot = int64_t(p.c_slot[size_t(k)]) + ((np - n) >> 1) + (g - p.c_gene[size_t(k)]);
-            return int32_t(std::min<int64_t>(std::max<int64_t>(slot / p.tile_out, 0), nt - 1));
-        };
-        for (int32_t v = 0; v < nv; ++v) {
-            if (cblk[size_t(v) + 1] <= cblk[size_t(v)]) {  // (an empty workgroup reads nothing)
-                dep[size_t(v)] = make_int2(1, 0);
-                continue;
-            }
-            const int32_t lo = tile_of(cblk[size_t(v)]), hi = tile_of(cblk[size_t(v) + 1] - 1);
-            dep[size_t(v)] = make_int2(lo, hi);
-        }
-    }
-    const int32_t q = nt >> 3, r = nt & 7;
-    auto xbase = [&](int x) { return x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q; };
-    auto xcnt = [&](int x) { return x < r ? q + 1 : q; };
-    std::vector<std::vector<int32_t>> seq(8);
-    {
-        std::vector<std::vector<std::pair<int32_t, int32_t>>> vd(8);
-        for (int32_t v = 0; v < nv; ++v) {
-            const int32_t last = dep[size_t(v)].y >= dep[size_t(v)].x ? dep[size_t(v)].y : 0;
-            int x = 0;
-            while (x < 7 && last >= xbase(x + 1) && xcnt(x + 1) > 0) ++x;
-            if (xcnt(x) == 0) x = 0;
-            vd[size_t(x)].push_back({std::min(last - xbase(x) + lag, std::max(xcnt(x) - 1, 0)), v});
-        }
-        for (int x = 0; x < 8; ++x) {
-            std::stable_sort(vd[size_t(x)].begin(), vd[size_t(x)].end(),
-                             [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) { return a.first < b.first; });
-            size_t j = 0;
-            const int32_t cnt = xcnt(x);
-            for (int32_t i = 0; i < std::max(cnt, 1); ++i) {
-                if (i < cnt) seq[size_t(x)].push_back(xbase(x) + i);
-                while (j < vd[size_t(x)].size() && vd[size_t(x)][j].first <= i) seq[size_t(x)].push_back(~vd[size_t(x)][j++].second);
-            }
-            while (j < vd[size_t(x)].size()) seq[size_t(x)].push_back(~vd[size_t(x)][j++].second);
-        }
-    }
-    size_t len = 0;
-    for (int x = 0; x < 8; ++x) len = std::max(len, seq[size_t(x)].size());
-    std::vector<int32_t> role(len * 8, INT32_MIN);
-    const bool dbg_no_vd = std::getenv("GECCO_CRF_FUSED_DEBUG_NOVD") != nullptr;  // timing experiments only (labels are not computed)
-    for (int x = 0; x < 8; ++x)
-        for (size_t i = 0; i < seq[size_t(x)].size(); ++i)
-            role[i * 8 + size_t(x)] = (dbg_no_vd && seq[size_t(x)][i] < 0) ? INT32_MIN : seq[size_t(x)][i];
-    const size_t b_role = (role.size() * 4 + 255) & ~size_t(255), b_dep = (size_t(nv) * 8 + 255) & ~size_t(255),
-                 b_flag = ((size_t(nt) + 64) * 4 + 255) & ~size_t(255),
-                 b_trace = std::getenv("GECCO_CRF_FUSED_TRACE") ? role.size() * 32 + 512 : 0,  // (variant builds: tools/fused_trace.py)
-                 total = b_role + b_dep + b_flag + b_trace;
-    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
-    if (rc) return rc;
-    if (total > f.cap) {
-        if (f.d) (void)hipFree(f.d);
-        f.d = nullptr;
-        f.cap = 0;
-        if ((rc = check_hip(hipMalloc(reinterpret_cast<void **>(&f.d), total), "hipMalloc fused decode tables"))) return rc;
-        f.cap = total;
-    }
-    std::vector<char> img(total, 0);  // (flags 0: no launch has published yet; epochs start at 1)
-    std::memcpy(img.data(), role.data(), role.size() * 4);
-    std::memcpy(img.data() + b_role, dep.data(), size_t(nv) * 8);
-    if ((rc = check_hip(hipMemcpy(f.d, img.data(), total, hipMemcpyHostToDevice), "upload fused decode tables"))) return rc;
-    f.off_dep = b_role;
-    f.off_flag = b_role + b_dep;
-    f.n_blocks = int32_t(role.size());
-    f.lag = lag;
-    f.epoch = 0;
-    f.state = 1;
-    return GECCO_CRF_OK;
-}
-
-static int run_decode_launches(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
-                               int8_t *d_y, double *d_score, hipStream_t stream) {
-    // the fused hand-over needs the register-resident 2-label kernel and every gene in slot space
+    // handing the score differences over needs the register-resident 2-label kernel and every gene in slot space
     const bool share = !p.general && p.fast_ok && p.skipped.empty() && p.device >= 0;
     if (!share) {
         int rc = plan_run_windowed(p, d_gene_ptr, d_attr_id, label, d_p_out, stream);
@@ -1218,45 +997,9 @@ static int run_decode_launches(Plan &p, const int32_t *d_gene_ptr, const int32_t
     a.csr_wtab01 = p.tables_model->wtab2[1];
     a.csr_n_attrs = p.model->A;
     if (viterbi_delta_ok(a, d_score)) {
-        if (a.short_contigs && !p.fused.state && (rc = plan_ensure_fused(p))) return rc;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(stream, &cap);  // (a captured launch would freeze the epoch: two launches there)
-        if (a.short_contigs && p.fused.state == 1 && cap == hipStreamCaptureStatusNone) {
-            FusedLaunch fl{};
-            fl.seq = &a;
-            fl.args.role = reinterpret_cast<const int32_t *>(p.fused.d);
-            fl.args.vd_dep = reinterpret_cast<const int2 *>(p.fused.d + p.fused.off_dep);
-            fl.args.tile_flag = reinterpret_cast<uint32_t *>(p.fused.d + p.fused.off_flag);
-            if (++p.fused.epoch == 0) p.fused.epoch = 1;
-            fl.args.epoch = p.fused.epoch;
-            fl.args.n_blocks = p.fused.n_blocks;
-            rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, const_cast<double *>(a.dstate), stream, &fl);
-            if (const char *path = std::getenv("GECCO_CRF_FUSED_TRACE")) {  // variant builds (-DGECCO_FUSED_TRACE): tools/fused_trace.py
-                const char *mn = std::getenv("GECCO_CRF_FUSED_TRACE_MIN");  // (only launches of at least that many blocks)
-                if (!rc && p.fused.n_blocks >= (mn ? std::atoi(mn) : 0) && hipStreamSynchronize(stream) == hipSuccess) {
-                    const size_t nb = size_t(p.fused.n_blocks), o_tr = p.fused.off_flag + ((size_t(p.ntiles) + 63) & ~size_t(63)) * 4;
-                    std::vector<int32_t> role(nb);
-                    std::vector<unsigned long long> tr(nb * 4);
-                    (void)hipMemcpy(role.data(), p.fused.d, nb * 4, hipMemcpyDeviceToHost);
-                    (void)hipMemcpy(tr.data(), p.fused.d + o_tr, nb * 32, hipMemcpyDeviceToHost);
-                    if (FILE *fp = std::fopen(path, "wb")) {
-                        const int64_t hdr[2] = {int64_t(nb), int64_t(p.ntiles)};
-                        std::fwrite(hdr, 8, 2, fp);
-                        std::fwrite(role.data(), 4, nb, fp);
-                        std::fwrite(tr.data(), 8, nb * 4, fp);
-                        std::fclose(fp);
-                    }
-                }
-            }
-            return rc;
-        }
         if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, const_cast<double *>(a.dstate), stream)))
             return rc;
         return check_hip(launch_seq_viterbi_delta(a, stream), "viterbi launch");
-    }
-    if (p.stream_phases) {  // the streaming window kernel hands over score differences only: two passes over the CSR
-        if ((rc = plan_run_windowed(p, d_gene_ptr, d_attr_id, label, d_p_out, stream))) return rc;
-        return plan_run_viterbi(p, d_gene_ptr, d_attr_id, d_y, d_score, stream);
     }
     if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, const_cast<double2 *>(a.state), nullptr, stream)))
         return rc;
@@ -1290,6 +1033,10 @@ int plan_run_decode_pipelined(Plan *cur, const int32_t *d_gene_ptr, const int32_
         // no score differences left behind (any-L model, contigs outside slot space, or another call used the workspace since):
         // the state scores are summed again from the CSR arrays -- BEFORE this batch's tiles write into the workspace
         const Plan::Pipe keep = prev->pipe;
+        if (!keep.gene_ptr) {
+            set_error("pipelined decode: the previous plan has not been scored by a pipelined call (or has been rebuilt since)");
+            return GECCO_CRF_EINVAL;
+        }
         if ((rc = plan_run_viterbi(*prev, keep.gene_ptr, keep.attr_id, d_prev_y, nullptr, stream))) return rc;
         prev->pipe = keep;
     }
@@ -1300,7 +1047,7 @@ int plan_run_decode_pipelined(Plan *cur, const int32_t *d_gene_ptr, const int32_
         const int parity = p.pipe.parity ^ 1;  // (cur == prev: the Viterbi side reads the other buffer)
         bool delta = false;
         double *d_dstate = nullptr;
-        if (!p.general && p.fast_ok && p.skipped.empty() && p.device >= 0 && p.n_genes > 0 && !p.stream_phases) {
+        if (!p.general && p.fast_ok && p.skipped.empty() && p.device >= 0 && p.n_genes > 0) {
             SeqArgs ca;
             if ((rc = fill_seq_args(p, ca, stream))) return rc;
             if (viterbi_delta_ok(ca, nullptr)) {
@@ -1308,9 +1055,8 @@ int plan_run_decode_pipelined(Plan *cur, const int32_t *d_gene_ptr, const int32_
                 d_dstate = const_cast<double *>(reinterpret_cast<const double *>(ca.state)) + size_t(parity) * (size_t(p.n_genes) + 8);
             }
         }
-        FusedLaunch fl{};
+        PipelinedLaunch fl{};
         fl.seq = &pa;
-        fl.pipelined = true;
         fl.took = &took;
         if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, d_dstate, stream, (delta && prev_delta) ? &fl : nullptr)))
             return rc;

@@ -21,7 +21,7 @@ struct DeviceTables {
     double2 *wtab2[2] = {nullptr, nullptr};  // L == 2: [A] (other, label) for label = 0 / 1
     double *exp_trans = nullptr;  // [L*L]
     double *trans = nullptr;      // [L*L] raw weights (general-L Viterbi)
-    double *rtab[2] = {nullptr, nullptr};  // L == 2: [32] mu01(label) * 2^(j/32), the exp table of the streaming window kernel
+    double *rtab[2] = {nullptr, nullptr};  // L == 2: [32] mu01(label) * 2^(j/32), the exp table of the window kernel's slot constants
 };
 
 // A pinned host block mirrored by a device block: plan tables are written on the host side and reach
@@ -42,7 +42,6 @@ struct Plan {
     int64_t n_windows = 0;
     // slot-space layout (host)
     int32_t K = 0, S = 0, ntiles = 0, tile_out = 0, tiles_per_wg = 1;
-    int32_t stream_phases = 0;  // > 0: the streaming window kernel (crf_stream.hip) with this many phases per workgroup
     std::vector<int32_t> c_slot, c_gene, c_n;
     std::vector<int4> tile_desc;
     std::vector<uint64_t> start_bits;
@@ -83,16 +82,6 @@ struct Plan {
     char *d_gen_tab = nullptr;
     int32_t gen_tab_chunk = 0;
     size_t gen_tab_nch = 0, gen_tab_off1 = 0, gen_tab_off2 = 0;
-    // The decode step in ONE launch (crf_decode_fused: window tiles + the Viterbi workgroups of short contigs as blocks of
-    // one grid): block roles, the tiles every Viterbi workgroup waits for and the tiles' publication flags, built on the
-    // first decode call of a plan that qualifies (plan_ensure_fused).  state 0: not looked at yet, 1: fused, -1: two launches.
-    struct Fused {
-        int state = 0;
-        int32_t n_blocks = 0, lag = 0;
-        char *d = nullptr;
-        size_t off_dep = 0, off_flag = 0, cap = 0;
-        uint32_t epoch = 0;
-    } fused;
     // Pipelined decode (plan_run_decode_pipelined): what the last call left for the next one -- the batch's score differences
     // in buffer `parity` of the workspace (pending) and the batch's CSR arrays, which the caller keeps alive until then.
     struct Pipe {
@@ -104,17 +93,6 @@ struct Plan {
     bool tables_in_host_memory = false;  // the window kernel reads the plan tables from the pinned block itself (batch driver:
                                          // one copy and one inter-copy gap less per chunk; they are ~0.1 MB, read once)
     std::mutex ws_mutex;  // guards the lazy workspace / table creation: launches of one plan may come from several threads
-    // The decode step (window kernel + whole-contig Viterbi) as a HIP graph, opt-in (GECCO_CRF_GRAPH=1; measured slower than
-    // the two plain launches on this stack): the second call with the arguments of the first captures the launches,
-    // later ones replay them with one hipGraphLaunch.  Rebuilding the plan drops it.
-    struct DecodeGraph {
-        const void *key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        int32_t label = -1, seen = 0;
-        hipStream_t stream = nullptr;
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        void reset();
-    } decode_graph;
     ~Plan();
 };
 

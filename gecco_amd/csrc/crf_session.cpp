@@ -251,32 +251,12 @@ void deal_chunks(std::vector<Chunk> &chunks, int n_devices) {
     }
 }
 
-// Device view of a caller buffer in pinned host memory (gecco_crf_host_alloc, hipHostMalloc, hipHostRegister): the
-// kernels can read the CSR from it and write their results into it DIRECTLY, no copy at all (opt-in, see
-// session_run: on its own the windowed launch takes 0.52 ms per C3 batch over PCIe, tools/zero_copy_test.py, but
-// the whole call is not faster than the pipeline of copies).  Null for ordinary (pageable) memory.
-template <class T>
-T *device_view(T *host) {
-    if (!host) return nullptr;
-    hipPointerAttribute_t a{};
-    if (hipPointerGetAttributes(&a, host) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    if (a.type != hipMemoryTypeHost) return nullptr;
-    return a.devicePointer ? static_cast<T *>(a.devicePointer) : host;
-}
-
 struct RunCtx {
     Session &S;
     const BatchRequest &r;
     std::vector<Chunk> &chunks;
     bool windowed, viterbi, full;
     int32_t W, step, pad;
-    // pinned caller buffers, as the device sees them (null: copy)
-    const int32_t *z_gene_ptr = nullptr, *z_attr_id = nullptr;
-    double *z_p = nullptr, *z_score = nullptr, *z_marg = nullptr, *z_lognorm = nullptr;
-    int8_t *z_y = nullptr;
 };
 
 int submit(RunCtx &X, Lane &ln, int chunk_index) {
@@ -299,24 +279,29 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
     // ---- uploads first: the bulk copies are on their way while the host lays the chunk out
     if (ng) {
         if (r.degree) {  // degree bytes cross PCIe; the row pointers are rebuilt on the device (below, on the compute stream)
+            // the device derives the rows from the bytes, the host takes the chunk's base offset from gene_ptr: they must agree
+            uint64_t dsum = 0;
+            for (const uint8_t *q = r.degree + ck.g0, *e = q + ng; q < e; ++q) dsum += *q;
+            if (dsum != uint64_t(a1 - a0)) {
+                set_error("degree bytes do not add up to gene_ptr over a chunk (degree must equal diff(gene_ptr))");
+                return GECCO_CRF_EINVAL;
+            }
             if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
             if ((rc = ln.d_deg.reserve(size_t(ng) + 32, "hipMalloc degrees"))) return rc;
             if ((rc = ln.d_deg_ws.reserve(degree_scratch_bytes(ng), "hipMalloc degree scan"))) return rc;
             if ((rc = check_hip(hipMemcpyAsync(ln.d_deg.p, r.degree + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D degrees")))
                 return rc;
             S.stats.h2d_bytes += int64_t(ng);
-        } else if (!X.z_gene_ptr) {
+        } else {
             if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
             if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.g0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.up), "H2D gene_ptr")))
                 return rc;
             S.stats.h2d_bytes += int64_t((size_t(ng) + 1) * 4);
         }
-        if (!X.z_attr_id) {
-            if ((rc = ln.d_at.reserve((nnz + 4) * 4, "hipMalloc attr_id"))) return rc;
-            if (nnz && (rc = check_hip(hipMemcpyAsync(ln.d_at.p, r.attr_id + a0, nnz * 4, hipMemcpyHostToDevice, ln.up), "H2D attr_id")))
-                return rc;
-            S.stats.h2d_bytes += int64_t(nnz * 4);
-        }
+        if ((rc = ln.d_at.reserve((nnz + 4) * 4, "hipMalloc attr_id"))) return rc;
+        if (nnz && (rc = check_hip(hipMemcpyAsync(ln.d_at.p, r.attr_id + a0, nnz * 4, hipMemcpyHostToDevice, ln.up), "H2D attr_id")))
+            return rc;
+        S.stats.h2d_bytes += int64_t(nnz * 4);
         if (r.want_segments) {
             if ((rc = ln.d_ann.reserve(size_t(ng) + 8, "hipMalloc annotated"))) return rc;
             if ((rc = check_hip(hipMemcpyAsync(ln.d_ann.p, r.annotated + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D annotated")))
@@ -360,40 +345,24 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
     if ((rc = check_hip(hipStreamWaitEvent(ln.comp, ln.ev_up, 0), "hipStreamWaitEvent"))) return rc;
     if (ng == 0) return check_hip(hipEventRecord(ln.done, ln.comp), "hipEventRecord");
     // gene_ptr keeps the caller's offsets: the attribute array is addressed from where its element 0 would be
-    // (a pinned attribute array is addressed from its own element 0: the offsets are already right)
-    const int32_t *d_gp = (X.z_gene_ptr && !r.degree) ? X.z_gene_ptr + ck.g0 : reinterpret_cast<const int32_t *>(ln.d_gp.p);
+    const int32_t *d_gp = reinterpret_cast<const int32_t *>(ln.d_gp.p);
     if (r.degree && (rc = check_hip(launch_degree_to_row_ptr(reinterpret_cast<const uint8_t *>(ln.d_deg.p), int(ng), int32_t(a0),
                                                                reinterpret_cast<int32_t *>(ln.d_gp.p),
                                                                reinterpret_cast<int32_t *>(ln.d_deg_ws.p), ln.comp), "degree scan launch")))
         return rc;
-    const int32_t *d_at = X.z_attr_id ? X.z_attr_id : reinterpret_cast<const int32_t *>(ln.d_at.p) - a0;
+    const int32_t *d_at = reinterpret_cast<const int32_t *>(ln.d_at.p) - a0;
     double *d_p = nullptr, *d_score = nullptr;
     int8_t *d_y = nullptr;
-    // results go straight into pinned caller buffers, except p when the refiner reads it back twice on the device
-    const bool p_direct = X.z_p && !r.want_segments;
-    const bool y_direct = X.z_y && ((reinterpret_cast<uintptr_t>(X.z_y) + size_t(ck.g0)) & 7u) == 0;  // labels are stored 8 at a time
     if (X.windowed) {
-        if (p_direct) {
-            d_p = X.z_p + ck.g0;
-        } else {
-            if ((rc = ln.d_p.reserve(size_t(ng) * 8, "hipMalloc p"))) return rc;
-            d_p = reinterpret_cast<double *>(ln.d_p.p);
-        }
+        if ((rc = ln.d_p.reserve(size_t(ng) * 8, "hipMalloc p"))) return rc;
+        d_p = reinterpret_cast<double *>(ln.d_p.p);
     }
     if (X.viterbi) {
-        if (y_direct) {
-            d_y = X.z_y + ck.g0;
-        } else {
-            if ((rc = ln.d_y.reserve(size_t(ng) + 8, "hipMalloc labels"))) return rc;
-            d_y = reinterpret_cast<int8_t *>(ln.d_y.p);
-        }
+        if ((rc = ln.d_y.reserve(size_t(ng) + 8, "hipMalloc labels"))) return rc;
+        d_y = reinterpret_cast<int8_t *>(ln.d_y.p);
         if (r.score_out) {
-            if (X.z_score) {
-                d_score = X.z_score + ck.c0;
-            } else {
-                if ((rc = ln.d_score.reserve(size_t(nc) * 8, "hipMalloc scores"))) return rc;
-                d_score = reinterpret_cast<double *>(ln.d_score.p);
-            }
+            if ((rc = ln.d_score.reserve(size_t(nc) * 8, "hipMalloc scores"))) return rc;
+            d_score = reinterpret_cast<double *>(ln.d_score.p);
         }
     }
     if (X.windowed && X.viterbi) {
@@ -406,18 +375,10 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
     if (rc) return rc;
     double *d_marg = nullptr, *d_lognorm = nullptr;
     if (X.full) {
-        if (X.z_marg && r.marg_out) {
-            d_marg = X.z_marg + size_t(ck.g0) * L;
-        } else {
-            if ((rc = ln.d_marg.reserve(size_t(ng) * L * 8, "hipMalloc marginals"))) return rc;
-            d_marg = reinterpret_cast<double *>(ln.d_marg.p);
-        }
-        if (X.z_lognorm && r.lognorm_out) {
-            d_lognorm = X.z_lognorm + ck.c0;
-        } else {
-            if ((rc = ln.d_lognorm.reserve(size_t(nc) * 8, "hipMalloc lognorm"))) return rc;
-            d_lognorm = reinterpret_cast<double *>(ln.d_lognorm.p);
-        }
+        if ((rc = ln.d_marg.reserve(size_t(ng) * L * 8, "hipMalloc marginals"))) return rc;
+        d_marg = reinterpret_cast<double *>(ln.d_marg.p);
+        if ((rc = ln.d_lognorm.reserve(size_t(nc) * 8, "hipMalloc lognorm"))) return rc;
+        d_lognorm = reinterpret_cast<double *>(ln.d_lognorm.p);
         if ((rc = plan_run_marginals_full(ln.plan, d_gp, d_at, d_marg, d_lognorm, ln.comp))) return rc;
     }
     if (r.want_segments) {
@@ -455,8 +416,7 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
             return rc;
     }
     tm.lap("launch", chunk_index);
-    const bool c_p = r.p_out && !p_direct, c_y = r.y_out && !y_direct, c_score = r.score_out && !X.z_score,
-               c_marg = r.marg_out && !X.z_marg, c_ln = r.lognorm_out && !X.z_lognorm;
+    const bool c_p = r.p_out, c_y = r.y_out, c_score = r.score_out, c_marg = r.marg_out, c_ln = r.lognorm_out;
     if (!(c_p || c_y || c_score || c_marg || c_ln)) return check_hip(hipEventRecord(ln.done, ln.comp), "hipEventRecord");
     if ((rc = check_hip(hipEventRecord(ln.ev_comp, ln.comp), "hipEventRecord"))) return rc;
     if ((rc = check_hip(hipStreamWaitEvent(ln.down, ln.ev_comp, 0), "hipStreamWaitEvent"))) return rc;
@@ -584,26 +544,6 @@ int session_run(Session &S, const BatchRequest &r) {
     deal_chunks(chunks, int(S.devs.size()));
     S.stats.n_chunks = int32_t(chunks.size());
     RunCtx X{S, r, chunks, windowed, viterbi, full, windowed ? r.window : 1, windowed ? r.step : 1, windowed ? r.pad : 1};
-    {
-        // GECCO_CRF_ZERO_COPY = in | out | all: opt-in.  Inside the driver the copies win: 0.64 ms per C3 batch
-        // against 0.67-0.70 ms ("all"), 0.65 ("out"), 0.78 ("in") -- a kernel moves ~70 GB/s over PCIe both ways
-        // together where the copy engines move 47 + 47, and the chunk layouts are no longer built behind an upload.
-        const char *mode = std::getenv("GECCO_CRF_ZERO_COPY");
-        const bool zin = mode && (mode[0] == 'i' || mode[0] == 'a');
-        const bool zout = mode && (mode[0] == 'o' || mode[0] == 'a');
-        if (zin) {
-            X.z_gene_ptr = device_view(r.gene_ptr);
-            X.z_attr_id = device_view(r.attr_id);
-        }
-        if (zout) {
-            X.z_p = device_view(r.p_out);
-            X.z_y = device_view(r.y_out);
-            X.z_score = device_view(r.score_out);
-            X.z_marg = device_view(r.marg_out);
-            X.z_lognorm = device_view(r.lognorm_out);
-        }
-    }
-
     // per-device queues in batch order; devices are fed round-robin so that all of them start at once
     std::vector<std::vector<int>> queue(S.devs.size());
     for (size_t i = 0; i < chunks.size(); ++i) queue[size_t(chunks[i].device_slot)].push_back(int(i));

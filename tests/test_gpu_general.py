@@ -70,6 +70,32 @@ def test_viterbi_any_label_count(nat, L):
     assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
 
 
+@pytest.mark.parametrize("L", [3, 8, 16])
+def test_empty_contigs_any_label_count(nat, L):
+    """Contigs without genes have no chunk in the chunked whole-contig kernels: their log-partition and path score are 0
+    (as the oracle's), not whatever an earlier batch left in the driver's buffers."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(900 + L)
+    w, trans = synth_model(200, rng, L=L)
+    model = nat.Model.from_tables(w, trans)
+    # a first batch without empty contigs fills the per-contig buffers with non-zero values
+    c0, g0, a0 = synth_contigs(rng, [30, 5, 70, 12, 1, 9, 200], 200)
+    model.marginals_full(c0, g0, a0)
+    model.viterbi(c0, g0, a0)
+    cptr, gptr, attr = synth_contigs(rng, [0, 25, 0, 0, 3, 64, 0, 1, 0], 200)
+    marg, ln = model.marginals_full(cptr, gptr, attr)
+    emarg, eln = orc.full_marginals(w, trans, cptr, gptr, attr)
+    assert np.abs(marg - emarg).max() <= 1e-12
+    assert np.abs(ln - eln).max() <= 1e-10 * max(1.0, np.abs(eln).max())
+    assert all(ln[c] == 0.0 for c in (0, 2, 3, 6, 8))
+    y, sc = model.viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y.astype(np.int32), ey)
+    assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
+    assert all(sc[c] == 0.0 for c in (0, 2, 3, 6, 8))
+
+
 @pytest.mark.parametrize("L", [3, 5])
 def test_viterbi_ties_first_argmax(nat, L):
     """Small-integer weights make exact ties common: the strict `<` update / first arg max of

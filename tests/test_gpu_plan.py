@@ -156,41 +156,6 @@ def test_decode_edge_batches(nat, real, oracle_model):
     assert np.array_equal(y.cpu().numpy().astype(np.int32), ey)
 
 
-@pytest.mark.parametrize("lag", ["0", "176", "100000"])
-def test_fused_decode_launch_equals_two_launches(nat, real, oracle_model, monkeypatch, lag):
-    """GECCO_CRF_FUSED=1: window tiles and the Viterbi workgroups of short contigs in ONE launch, the score differences
-    handed over inside it (crf_decode_fused; opt-in).  Same bits as the two launches, whatever the
-    interleaving of the blocks (lag), over batches with padded contigs (irregular tiles), empty contigs, a batch of
-    many tiles per Viterbi workgroup and repeated launches of one plan (the flags carry the launch's epoch)."""
-    from oracle import crf_oracle as orc
-
-    monkeypatch.setenv("GECCO_CRF_FUSED_LAG", lag)
-    rng = np.random.default_rng(123)
-    A = oracle_model["state"].shape[0]
-    batches = [
-        [1, 5, 19, 20, 21, 64, 300, 1000, 2048] + list(rng.integers(1, 400, size=200)),
-        [3, 0, 7, 0, 0, 12, 1, 2, 2047, 1, 0] + list(rng.integers(1, 19, size=300)),  # every contig padded: ~ W slots per gene
-        list(rng.integers(150, 260, size=600)),
-    ]
-    for lengths in batches:
-        cptr, gptr, attr = synth_contigs(rng, lengths, A)
-        n = int(cptr[-1])
-        d_gp, d_at = _dev(gptr, attr)
-        out = {}
-        for fused in ("0", "1"):
-            monkeypatch.setenv("GECCO_CRF_FUSED", fused)
-            plan = nat.Plan(real, cptr, 20, 1, True, device=0)
-            p = torch.zeros(n, dtype=torch.float64, device="cuda:0")
-            y = torch.full((n,), 9, dtype=torch.int8, device="cuda:0")
-            for _ in range(3):
-                plan.run_decode(d_gp.data_ptr(), d_at.data_ptr(), p.data_ptr(), y.data_ptr())
-            torch.cuda.synchronize()
-            out[fused] = (p.cpu().numpy(), y.cpu().numpy())
-        assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
-        ey, _ = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
-        assert np.array_equal(out["1"][1].astype(np.int32), ey)
-
-
 def test_pipelined_decode_equals_decode(nat, real, oracle_model):
     """gecco_crf_plan_run_decode_pipelined: call k carries the marginals of batch k and the Viterbi labels of batch k - 1
     (one launch when both qualify: crf_decode_pipelined).  Same bits as gecco_crf_plan_run_decode for every batch, over a

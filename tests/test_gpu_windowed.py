@@ -236,11 +236,13 @@ def test_ratio_form_guard_at_its_limit(nat):
     w[3] = (700.0, 0.0)   # d = -700: exp underflows to 0
     w[4] = (1.0, 0.5)
     w[5] = (0.0, 9.9)     # d = +9.9: not leaning; twenty of them put 198 into a window
+    w[6] = (800.0, 0.0)   # d = -800: the slot constant mu01 exp(d) itself flushes to zero -- with the start flag in its sign bit
     model = nat.Model.from_tables(w, synth.EMBEDDED_TRANS)
     rng = np.random.default_rng(1)
     runs = []
     for a, n in [(0, 600), (4, 300), (1, 600), (2, 50), (0, 40), (3, 30), (4, 700), (1, 25), (0, 500),
-                 (4, 900), (5, 40), (0, 13), (5, 40), (4, 900), (5, 30), (0, 14), (5, 30), (4, 900), (0, 6), (5, 60), (0, 7), (4, 700)]:
+                 (4, 900), (5, 40), (0, 13), (5, 40), (4, 900), (5, 30), (0, 14), (5, 30), (4, 900), (0, 6), (5, 60), (0, 7), (4, 700),
+                 (6, 30), (4, 100), (6, 1), (4, 50), (6, 2), (4, 300)]:
         runs += [a] * n
     runs = np.array(runs + list(rng.integers(0, 5, size=800)), dtype=np.int32)
     n = len(runs)

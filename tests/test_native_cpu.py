@@ -134,13 +134,6 @@ def test_host_only_plan_dispatch_by_label_count(blob, monkeypatch):
     assert nat.Plan(m2, [0, 50], 20, device=-1).kernel_name == "gl_windowed"
     monkeypatch.delenv("GECCO_CRF_FORCE_GENERAL")
     assert "crf_windowed_l2" in nat.Plan(m2, [0, 50], 20, device=-1).kernel_name
-    # the streaming form of the window kernel is opt-in (GECCO_CRF_STREAM = phases per workgroup): W = 20 only
-    monkeypatch.setenv("GECCO_CRF_STREAM", "4")
-    p = nat.Plan(m2, [0, 5000], 20, device=-1)
-    assert "crf_windowed_stream_l2" in p.kernel_name and p.num_tiles == -(-5000 // (4 * 256 - 19))
-    assert "crf_windowed_stream_l2" in nat.Plan(m2, [0, 50, 60], 20, device=-1).kernel_name  # (padded contigs too)
-    assert "crf_windowed_l2" in nat.Plan(m2, [0, 50, 60], 15, device=-1).kernel_name  # other windows: the tiled kernel
-    monkeypatch.delenv("GECCO_CRF_STREAM")
 
 
 @pytest.mark.skipif(nat.device_count() > 0, reason="only meaningful on a box without a GPU")

@@ -1,5 +1,4 @@
 # Round-3 profile set, ONE gpurun call:  /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/final_profiles.sh'
-# (build the trace variant first, here: tools/build_variant.sh trace crf_kernels.hip -DGECCO_FUSED_TRACE)
 set -u
 R=$PWD; O=$R/gpurun_out/r3_final; mkdir -p $O
 timeout 900 tools/profile.sh r3_final > $O/profile.log 2>&1
@@ -11,12 +10,8 @@ timeout 400 python tools/bench_levels.py > $O/levels.json 2> $O/levels.err
 timeout 300 python tools/bench_full.py > $O/full.json 2> $O/full.err
 timeout 400 python tools/bench_general.py > $O/general.json 2> $O/general.err
 GECCO_BENCH_ONE_DEVICE=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 200 --warmup 20 --no-cpu-baseline --no-past-l3 > $O/bench_2ranks_one_device.json 2> $O/bench_2ranks.err
-if [ -f gecco_amd/lib/libgecco_crf_trace.so ]; then
   for lag in 176 100000; do
-    GECCO_CRF_LIBRARY=$R/gecco_amd/lib/libgecco_crf_trace.so GECCO_CRF_FUSED=1 GECCO_CRF_FUSED_LAG=$lag GECCO_CRF_FUSED_TRACE=/tmp/tr_$lag.bin GECCO_CRF_FUSED_TRACE_MIN=3000 \
       timeout 200 python bench.py --schedule two-launch --no-cpu-baseline --no-levels --no-8d --no-past-l3 --no-c4 --steps 20 --warmup 5 --kernel-iters 2 > /dev/null 2>&1
-    echo "== crf_decode_fused (GECCO_CRF_FUSED=1), lag $lag blocks ==" >> $O/fused_timeline.txt
-    python tools/fused_trace.py /tmp/tr_$lag.bin >> $O/fused_timeline.txt 2>&1
   done
 fi
 tail -1 $O/bench_c3.json | cut -c1-400
