@@ -80,10 +80,13 @@ def main() -> None:
                     help="steps are plain windowed launches (for PMC passes: one kind of dispatch)")
     ap.add_argument("--preroll-ms", type=float, default=30.0,
                     help="untimed device pre-roll before the warmup steps: the GPU needs ~10 ms of sustained work to reach steady clocks")
-    ap.add_argument("--synth", default="genome", choices=["genome", "8d"],
-                    help="weight law of the synthetic model: 'genome' (default, most genes lean to label 0) or SURVEY.md 8d to the letter")
+    ap.add_argument("--synth", default="8d", choices=["genome", "8d"],
+                    help="weight law of the synthetic model: SURVEY.md 8d to the letter (default) or 'genome' (weights shifted so that "
+                         "most genes lean to label 0, as under GECCO's embedded model: the side point `roofline_genome`)")
+    ap.add_argument("--min-region-ms", type=float, default=50.0,
+                    help="the K-step timed region is repeated until this much time has been measured; ms_per_step is the median region")
     ap.add_argument("--no-levels", action="store_true", help="skip the host-buffer / tables / object API levels (SURVEY.md 8d)")
-    ap.add_argument("--no-8d", action="store_true", help="skip the second roofline point on the 8d-exact weight law")
+    ap.add_argument("--no-8d", "--no-genome", dest="no_8d", action="store_true", help="skip the second roofline point on the other weight law")
     ap.add_argument("--no-c4", action="store_true", help="skip the 8-way shard point (profiles: keeps the per-kernel averages on one workload)")
     ap.add_argument("--streams", type=int, default=2,
                     help="pipelined schedule: independent decode streams (plan + HIP stream each) the batches alternate between")
@@ -110,7 +113,10 @@ def main() -> None:
     dist = None
     red_dev = dev
     backend = None
-    if world > 1:
+    # GECCO_BENCH_FORCE_DIST=1: the process group, its probe all-reduce and the gathers also at world size 1 (under
+    # `torch.distributed.run --nproc-per-node 1`): what a one-GPU box can exercise of the N > 1 code path, RCCL included
+    force_dist = os.environ.get("GECCO_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         # RCCL ("nccl") over xGMI when it comes up; gloo otherwise (the collectives here are a barrier and two scalar
@@ -216,6 +222,15 @@ def main() -> None:
                 elapsed = float(t.item())
             return elapsed
 
+        def timed_regions(self, steps, warmup, preroll_ms, min_ms, schedule=None):
+            """The K-step region above, repeated until `min_ms` have been measured (a 20-step region of this workload is
+            0.6 ms: too short to mean much on its own).  Every region is exactly `steps` steps between a barrier + device
+            synchronisation on both sides and starts from empty pipelines; every rank runs the same number of regions
+            (decided from the first region's max-over-ranks time).  Returns the list of region times (seconds)."""
+            first = self.timed(steps, warmup, preroll_ms, schedule)
+            more = int(min(200, max(0, np.ceil(min_ms * 1e-3 / max(first, 1e-9)) - 1)))
+            return [first] + [self.timed(steps, 0, 0.0, schedule) for _ in range(more)]
+
     def all_sum(v):
         if dist is None:
             return int(v)
@@ -238,7 +253,16 @@ def main() -> None:
     res = Resident(model, wl["contig_ptr"], wl["gene_ptr"], wl["attr_id"], lanes=n_lanes)
     n_genes, nnz = res.n_genes, res.nnz
 
-    elapsed = res.timed(args.steps, args.warmup, args.preroll_ms)
+    for ln in res.lanes:
+        ln["plan"].viterbi_stats(reset=True)
+    regions = res.timed_regions(args.steps, args.warmup, args.preroll_ms, args.min_region_ms)
+    elapsed = float(np.median(regions))
+    vstats = {}
+    if not args.windowed_only:  # what the Viterbi side met in those regions (crf_vd_short.hpp: the exactness margin)
+        for ln in res.lanes:
+            for k, v in ln["plan"].viterbi_stats(reset=True).items():
+                vstats[k] = vstats.get(k, 0) + v
+        vstats["batches"] = args.steps * len(regions) + args.warmup
     total_genes = all_sum(n_genes)
     pipelined = args.schedule == "pipelined" and not args.windowed_only
     # the other schedule next to the headline (a quarter of the steps)
@@ -267,6 +291,25 @@ def main() -> None:
         pipe_ms = res.plan.time_decode_pipelined(res.d_gp.data_ptr(), res.d_at.data_ptr(), res.d_p.data_ptr(), res.d_y.data_ptr(), LABEL,
                                                  res.stream, warmup=3, iters=args.kernel_iters)
         pipe_alg = alg_bytes + n_genes
+    # ... and what a launch lasts under the schedule that was timed: with two decode streams two launches are in flight,
+    # each of them longer than alone, while a batch leaves every ms_per_step.  HIP events on each lane's own stream, one
+    # pair per launch (the first event completes when the lane's previous launch has).
+    inflight_ms = None
+    if one_launch and len(res.lanes) > 1 and all("torch_stream" in ln for ln in res.lanes):
+        n_ev = 200
+        evs = []
+        for _ in range(20):
+            res.step()
+        for i in range(n_ev):
+            ln = res.lanes[res.turn % len(res.lanes)]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ln["torch_stream"])
+            res.step()
+            e1.record(ln["torch_stream"])
+            evs.append((e0, e1))
+        res.flush()
+        torch.cuda.synchronize(dev)
+        inflight_ms = float(np.mean([a.elapsed_time(b) for a, b in evs[len(res.lanes):]]))
     # PMC figures of this kernel on this workload, from the committed profile of the same command
     # (tools/profile.sh -> tools/pmc_to_json.py); null when there is none
     pmc = {}
@@ -283,7 +326,7 @@ def main() -> None:
             pmc_note = (f"profiles/pmc_traffic.json was taken with kernel source {pmc.get('kernel_source_sha16')}, this is "
                         f"{_kernel_source_sha16()}: counter figures dropped")
             pmc = {}
-        if pmc and args.synth != "genome":
+        if pmc and args.synth != "8d":
             pmc_note = "profiles/pmc_traffic.json was taken on the default weight law: counter figures dropped"
             pmc = {}
     pmc_pipe = {}
@@ -292,7 +335,7 @@ def main() -> None:
             pmc_pipe = json.load(open(pmc_path)).get(args.workload + ":pipelined", {}) or {}
         except Exception:
             pmc_pipe = {}
-        if pmc_pipe.get("kernel_source_sha16") != _kernel_source_sha16() or args.synth != "genome":
+        if pmc_pipe.get("kernel_source_sha16") != _kernel_source_sha16() or args.synth != "8d":
             pmc_pipe = {}
     traffic = pmc.get("hbm_bytes_per_launch")
     valu_insts = pmc.get("SQ_INSTS_VALU")  # wave-level VALU instructions of one launch
@@ -306,6 +349,12 @@ def main() -> None:
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_single_region": regions[0] / args.steps * 1e3,
+        "timed_regions": {"count": len(regions), "steps_each": args.steps, "min_total_ms": args.min_region_ms,
+                          "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
+                          "note": "every region = exactly `steps` steps between barrier + device synchronisation on both sides, "
+                                  "pipelines empty at its start and flushed at its end; ms_per_step / value = the MEDIAN region, "
+                                  "ms_per_step_single_region = the first one"},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -314,10 +363,9 @@ def main() -> None:
         "config": {
             "workload": f"{args.workload}: {res.n_contigs} contigs, {n_genes} genes, {nnz} domain hits per GPU; "
                         f"A=35000 synthetic 2-label model, window 20 step 1, pad.  " + (
-                            "Deviation from SURVEY.md 8d: weights ~ Laplace(-0.4, 1.7) (8d: location 0) and the Zipf head "
-                            "(ids < A/50) forced negative, so that most genes lean to label '0' as under the embedded model "
-                            "(mean w1-w0 = -0.76); `roofline_8d` carries the same kernel on the 8d-exact law"
-                            if args.synth == "genome" else "Weights exactly as SURVEY.md 8d: Laplace(0, 1.7), no forced head"),
+                            "Side point, not SURVEY.md 8d's law: weights ~ Laplace(-0.4, 1.7) and the Zipf head (ids < A/50) forced "
+                            "negative, so that most genes lean to label '0' as under the embedded model (mean w1-w0 = -0.76)"
+                            if args.synth == "genome" else "Weights exactly as SURVEY.md 8d: Laplace(0, 1.7) clipped to [-6.3, 12.7]"),
             "synth_law": args.synth,
             "genes_per_gpu": n_genes,
             "viterbi_in_step": not args.windowed_only,
@@ -354,6 +402,14 @@ def main() -> None:
             if args.workload != "Cinf" else None,
         },
     }
+    if vstats:
+        nb = max(1, vstats.pop("batches"))
+        out["viterbi_exactness"] = {
+            **{k + "_per_batch": v / nb for k, v in vstats.items()},
+            "note": "difference-form Viterbi: decisions within the coarse margin of a threshold (candidates), decisions inside the "
+                    "margin (4 r + 4) ulp(M) in which the labels are not provably CRFsuite's, and the contigs / genes decoded again "
+                    "with CRFsuite's own delta recursion because of them (DESIGN.md: exactness of V); averages per decoded batch",
+        }
     if pipelined:
         out["two_launch_ms_per_step"] = two_launch_ms
         out["one_stream_ms_per_step"] = one_stream_ms
@@ -380,6 +436,10 @@ def main() -> None:
                               "several decode streams two launches overlap, so a launch takes longer than this while a batch "
                               "takes less (ms_per_step)",
             "launches_in_flight": n_lanes,
+            "kernel_ms_in_flight": inflight_ms,
+            "kernel_ms_in_flight_note": "the same launch under the schedule that was timed: mean over 200 launches of the interval "
+                                        "between two HIP events on the launch's own decode stream (the first completes when the "
+                                        "stream's previous launch has); two such launches overlap, so ms_per_step ~ half of it",
             "valu_insts_per_launch": vi,
             "valu_frac": (vi * 4.0 / (pipe_ms * 1e-3 * SIMDS * SCLK_HZ)) if vi else None,
             # the same at the rate batches leave the decode streams (launches overlap): how close the STEP is to the fp64
@@ -387,7 +447,7 @@ def main() -> None:
             "valu_frac_of_step": (vi * 4.0 / (out["ms_per_step"] * 1e-3 * SIMDS * SCLK_HZ)) if vi else None,
             "valu_frac_of_step_at_sustained_rate": (vi * VALU_SUSTAINED_CYCLES / (out["ms_per_step"] * 1e-3 * SIMDS * SCLK_HZ)) if vi else None,
         }
-    if world > 1:
+    if dist is not None:
         # who ran where: the process group that carried the timing barrier, and every rank's device
         devs = [None] * world
         dist.all_gather_object(devs, {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)})
@@ -449,17 +509,20 @@ def main() -> None:
         out["c4_shard_ms"] = out["c4_shard"]["c4_shard_ms"]
         del sh
 
-    # ---- the same kernel on SURVEY.md 8d's weight law to the letter (Laplace location 0, no forced head): more slots
-    # lean to the label, more workgroups leave the 3 + 3-op ratio form
-    if rank == 0 and world == 1 and args.workload == "C3" and args.synth == "genome" and not args.no_8d:
-        w8 = synth.workload("C3", seed=synth.SEED, law="8d")
+    # ---- the same kernel on the OTHER weight law of gecco_amd.synth (default run: 'genome', weights shifted so that most genes
+    # lean to label 0 as under GECCO's embedded model)
+    other = "genome" if args.synth == "8d" else "8d"
+    if rank == 0 and world == 1 and args.workload == "C3" and not args.no_8d:
+        w8 = synth.workload("C3", seed=synth.SEED, law=other)
         m8 = nat.Model.from_tables(w8["w"], w8["trans"])
         r8 = Resident(m8, w8["contig_ptr"], w8["gene_ptr"], w8["attr_id"], lanes=n_lanes)
         el8 = r8.timed(min(args.steps, 200), 20, 0.0)
         ms8 = r8.plan.time_windowed(r8.d_gp.data_ptr(), r8.d_at.data_ptr(), r8.d_p.data_ptr(), LABEL, r8.stream, warmup=3, iters=50)
         ab8 = _alg_bytes(r8.n_genes, r8.nnz, r8.n_contigs)
-        out["roofline_8d"] = {
-            "workload": f"C3 contigs, weights exactly as SURVEY.md 8d: {r8.n_genes} genes, {r8.nnz} domain hits",
+        out["roofline_" + other] = {
+            "workload": f"C3 contigs, weight law '{other}' ("
+                        + ("SURVEY.md 8d to the letter" if other == "8d" else "Laplace(-0.4, 1.7), Zipf head forced negative: most genes lean to label 0")
+                        + f"): {r8.n_genes} genes, {r8.nnz} domain hits",
             "kernel_ms": ms8, "achieved": ab8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": ab8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "ms_per_step": el8 / min(args.steps, 200) * 1e3,
             "ratio_form_fallback_frac": _ratio_form_fallback_fraction(w8, r8.plan.num_tiles, _tile_out(r8.plan, r8.n_genes)),

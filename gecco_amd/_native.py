@@ -147,6 +147,7 @@ SIGNATURES = {
     "gecco_crf_plan_time_decode_pipelined": (
         ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]
     ),
+    "gecco_crf_plan_viterbi_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32]),
 }
 
 _lib = None
@@ -705,10 +706,13 @@ class Session:
                                                     _ptr(out, _c_f64p)))
         return out[:n]
 
-    def decode(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True):
+    def decode(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True, out_p=None, out_y=None):
+        """Windowed marginals + whole-contig Viterbi labels of a batch in host memory; `out_p` / `out_y`: caller buffers
+        (pinned ones make the downloads asynchronous)."""
         contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
-        p = np.empty(max(n, 1), dtype=np.float64)
-        y = np.empty(max(n, 1), dtype=np.int8)
+        p = np.empty(max(n, 1), dtype=np.float64) if out_p is None else out_p
+        y = np.empty(max(n, 1), dtype=np.int8) if out_y is None else out_y
+        assert p.dtype == np.float64 and y.dtype == np.int8 and p.size >= n and y.size >= n
         _check(self._lib.gecco_crf_session_decode(self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p),
                                                   _ptr(attr_id, _c_i32p), int(window), int(step), int(label), int(bool(pad)),
                                                   _ptr(p, _c_f64p), _ptr(y, _c_i8p)))
@@ -829,6 +833,14 @@ class Plan:
         _check(self._lib.gecco_crf_plan_time_decode_pipelined(self._h, d_gene_ptr, d_attr_id, int(label), d_p_out, d_y, stream or None,
                                                               int(warmup), int(iters), ctypes.byref(ms)))
         return ms.value
+
+    def viterbi_stats(self, reset=True) -> dict:
+        """What the 2-label Viterbi decoder met since the last reset: decisions inside the coarse margin (`candidates`),
+        inside the margin where the difference form is not provably CRFsuite's (`inside_margin`), and the contigs / genes
+        decoded again with CRFsuite's own recursion because of them.  Waits for the device."""
+        out = (ctypes.c_int64 * 4)()
+        _check(self._lib.gecco_crf_plan_viterbi_stats(self._h, out, int(bool(reset))))
+        return {"candidates": int(out[0]), "inside_margin": int(out[1]), "contigs_redecoded": int(out[2]), "genes_redecoded": int(out[3])}
 
     def time_windowed(self, d_gene_ptr: int, d_attr_id: int, d_p_out: int, label=1, stream: int = 0, warmup=2, iters=10) -> float:
         ms = ctypes.c_float(0)

@@ -270,6 +270,14 @@ GECCO_API int gecco_crf_plan_time_decode_pipelined(gecco_crf_plan *p, const int3
     GECCO_GUARD_END
 }
 
+GECCO_API int gecco_crf_plan_viterbi_stats(gecco_crf_plan *p, int64_t out[4], int32_t reset) {
+    if (!p || !out) return GECCO_CRF_EINVAL;
+    DeviceGuard guard;
+    GECCO_GUARD_BEGIN
+    return plan_viterbi_stats(p->p, out, reset != 0);
+    GECCO_GUARD_END
+}
+
 GECCO_API int gecco_crf_plan_run_decode(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                                         int32_t label, double *d_p_out, int8_t *d_y, double *d_score, void *stream) {
     if (!p) return GECCO_CRF_EINVAL;

@@ -138,6 +138,21 @@ struct SeqArgs {
     double mx;                  // max(trans)
     double v_lo, v_hi, v_k;     // difference-form Viterbi: t01-t11, t00-t10, t11-t00
     int32_t v_exact;            // 1: decisions within rounding noise of a threshold are re-derived sequentially (GECCO_CRF_VD_EXACT=0: A/B runs)
+    // What bounds CRFsuite's accumulated scores, for the margin inside which a decision of the difference form is not
+    // PROVABLY crf1dc_viterbi's (crf_vd_short.hpp): |delta_t| <= nnz * max|w| + n * max|trans| over a contig of n genes and
+    // nnz attribute entries.  v_wmax2 = 2 max_a max_y |w[a][y]| (the factor 2 also covers |s[1] - s[0]|), v_tmax = max |trans|.
+    double v_wmax2, v_tmax;
+    int32_t v_nmax;             // genes of the batch's longest contig (flat layout: one bound for the whole batch)
+    // flat layout: candidates for that margin (lanes with a decision within the coarse margin; waves without any reset),
+    // written by vd_replay, judged by vd_refine: {lane | bit 31: "wave without reset", 0, Delta entering the lane}
+    struct VdCand {
+        uint32_t lane, pad;
+        double d_enter;
+    };
+    VdCand *vCand;              // [lanes + 4 * workgroups]
+    unsigned long long *vBound; // [0]: bit pattern of the largest per-contig bound (vd_fold); [1] low word: number of candidates
+    uint32_t *vd_stats;         // [4] or null, accumulated over launches: coarse candidates, decisions inside the margin,
+                                // contigs decoded again with CRFsuite's recursion, their genes
     // CSR of the batch + weight pairs (w[a][0], w[a][1]): contigs with such a decision are decoded again with
     // CRFsuite's own delta recursion on freshly summed state scores (null: no such pass)
     const int32_t *csr_gene_ptr, *csr_attr_id;

@@ -34,6 +34,10 @@
 namespace gecco {
 namespace {
 
+// 16-byte LDS/global accesses must stay single b128 instructions: a struct double2 gets
+// scalarised and re-paired by the compiler into bank-conflicting ds_read2_b64.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
 // lane l receives lane l-1's value; lane 0 receives +0.0 (DPP wave_shr:1, bound_ctrl:1).
 __device__ __forceinline__ double wave_shr1_zero(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -69,6 +73,55 @@ __device__ __forceinline__ void store_wt(double *p, double v) {
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A slot constant of the ratio form, read as ONE ds_read_b64: as plain loads the compiler pairs neighbouring reads into
+// ds_read2_b64, which occupies the LDS array for 8 cycles per wave where two ds_read_b64 take 2 + 2 (MI355X_MICROARCH.md, LDS
+// table; measured: SQ_LDS_IDX_ACTIVE -17 %, window kernel 25.05 -> 24.3 us, profiles/r04_diag_lds_ab.txt).  A relaxed
+// workgroup-scope atomic load is never merged -- and never moved by the scheduler either: the DP requests its constants
+// one step ahead by itself.
+__device__ __forceinline__ double lds_read1(const double *p) {
+    return __longlong_as_double(static_cast<long long>(
+        __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
+}
+
+// lane l receives lane l+1's value; lane 63 receives +0.0 (DPP wave_shl:1, bound_ctrl:1).
+__device__ __forceinline__ double wave_shl1_zero(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Write-through stores of a run of CONSECUTIVE doubles, one per lane (lane l: base[idx], lane l + 1: base[idx + 1] where both
+// are valid): a lane whose address is 16-byte aligned takes its right neighbour's value along and stores both with one
+// `global_store_dwordx4 ... sc1`, the neighbour stores nothing; lanes without a partner store 8 bytes as before.  A `dwordx2
+// sc1` store is one fabric write of half a 32-byte sector (MI355X_MICROARCH.md prices it at 2.7x the per-byte cost of
+// `dwordx4`), and the kernel issues half as many store instructions.
+#ifndef GECCO_PAIRED_STORES
+#define GECCO_PAIRED_STORES 1
+#endif
+__device__ __forceinline__ void store_wt_run(double *base, int idx, double v, bool valid) {
+#if GECCO_PAIRED_STORES
+    const double vn = wave_shl1_zero(v);
+    double *p = base + idx;
+    // 16-byte alignment of the lane's address, from the (wave-uniform) base and the index: 32-bit arithmetic only
+    const bool even = (((static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base)) >> 3) + static_cast<uint32_t>(idx)) & 1u) == 0;
+    // the neighbours' `valid` by DPP as well (lane 63 has nothing to its right in this wave, lane 0 nothing to its left)
+    const int vi = valid ? 1 : 0;
+    const bool vnext = __builtin_amdgcn_update_dpp(0, vi, 0x130, 0xF, 0xF, true) != 0;
+    const bool vprev = __builtin_amdgcn_update_dpp(0, vi, 0x138, 0xF, 0xF, true) != 0;
+    if (valid && even && vnext) {
+        const f64x2 pr = {v, vn};
+        // (s_nop: the hazard recogniser does not look into inline asm -- a store of more than 8 bytes must not be followed
+        // at once by a VALU write of its data registers)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(pr) : "memory");
+    } else if (valid && (even || !vprev)) {
+        store_wt(p, v);
+    }
+#else
+    if (valid) store_wt(base + idx, v);
+#endif
+}
+
 __device__ __forceinline__ void rescale_pair(double &u, double &v) {
     int ex;
     (void)frexp(fmax(u, v), &ex);
@@ -76,9 +129,6 @@ __device__ __forceinline__ void rescale_pair(double &u, double &v) {
     v = ldexp(v, -ex);
 }
 
-// 16-byte LDS/global accesses must stay single b128 instructions: a struct double2 gets
-// scalarised and re-paired by the compiler into bank-conflicting ds_read2_b64.
-typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kGatherUnroll = 8;  // attribute loads in flight per slot before the first use
 
@@ -406,10 +456,13 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
         for (int j = 0; j < JMAX; ++j) {
             if (TT > 1 || j == 0 || wave == 0) {
                 const int sl = tid + j * NT;
-                if (sl >= W - 1 && sl < TT * OUT + (W - 1) && gene[j] >= 0) {
-                    const double d = sc1[j] - sc0[j];
-                    // (s[1] - s[0] = d or -d: one XOR on the sign word)
-                    const double dd = __hiloint2double(__double2hiint(d) ^ (P.label ? 0 : int(0x80000000u)), __double2loint(d));
+                const bool mine = sl >= W - 1 && sl < TT * OUT + (W - 1) && gene[j] >= 0;
+                const double d = sc1[j] - sc0[j];
+                // (s[1] - s[0] = d or -d: one XOR on the sign word)
+                const double dd = __hiloint2double(__double2hiint(d) ^ (P.label ? 0 : int(0x80000000u)), __double2loint(d));
+                if (td.w & 1) {  // regular tile: consecutive lanes hold consecutive genes
+                    store_wt_run(P.dstate_out, gene[j], dd, mine);
+                } else if (mine) {
                     store_wt(P.dstate_out + gene[j], dd);
                 }
             }
@@ -451,13 +504,13 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
         if constexpr (RATIO) {
             const double *rrs = rr + sbase;
             double A1[WMAX];
-            const double r0 = rrs[0];
+            const double r0 = lds_read1(rrs);
             double a0 = 1.0, a1 = fabs(r0) * P.kappa_over_mu01;
             A1[0] = a1;
 #pragma unroll
             for (int k = 1; k < WMAX; ++k) {
                 if (EXACT || k < W) {
-                    const double r = fabs(rrs[k]);
+                    const double r = fabs(lds_read1(rrs + k));
                     const double t = a0 + a1;
                     a1 = fma(a1, rho, a0) * r;
                     a0 = t;
@@ -506,9 +559,12 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
             double R = 0.0;
             double *carry = reinterpret_cast<double *>(&sm.carry[0][0]);
             if (!renorm) {
+                double rcur = W > 1 ? lds_read1(rrs + (W - 1)) : 0.0;  // (the constant of a step is requested one step ahead)
 #pragma unroll
                 for (int k = WMAX - 1; k >= 0; --k) {
                     if (EXACT || k < W) {
+                        double rnext = 0.0;
+                        if (k > 1) rnext = lds_read1(rrs + (k - 1));
                         const double cand = A1[k] * b1;
                         if (k < W - 1) {
                             if (lane == 63 && wave < NT / 64 - 1) carry[wave * WMAX + k] = R;
@@ -516,10 +572,11 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
                         }
                         R = max_nocanon(R, cand);
                         if (k > 0) {
-                            const double u = fabs(rrs[k]) * b1;
+                            const double u = fabs(rcur) * b1;
                             b1 = fma(u, rho, b0);
                             b0 = b0 + u;
                         }
+                        rcur = rnext;
                     }
                 }
             } else {
@@ -549,7 +606,11 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
                 R = fmax(R, carry[((t2 >> 6) - 1) * WMAX + (t2 & 63)]);
             }
             R = fmin(R, 1.0);
-            if (tid >= W - 1 && my_gene >= 0) store_wt(P.p_out + my_gene, R);
+            if (td.w & 1) {  // regular tile: consecutive lanes hold consecutive genes
+                store_wt_run(P.p_out, my_gene, R, tid >= W - 1 && my_gene >= 0);
+            } else if (tid >= W - 1 && my_gene >= 0) {
+                store_wt(P.p_out + my_gene, R);
+            }
         } else if constexpr (!RESCALE) {
             // ---- stage 2a: forward recursion.  Without rescaling the un-normalised vectors satisfy
             //   alpha_k[0] beta_k[0] + alpha_k[1] beta_k[1] = Z   at EVERY position k of the window

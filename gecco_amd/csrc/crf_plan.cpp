@@ -75,6 +75,8 @@ int get_device_tables(const Model &m, int device, const DeviceTables **out) {
     const size_t A = size_t(m.A), L = size_t(m.L);
     std::vector<double> et(L * L);
     for (size_t i = 0; i < L * L; ++i) et[i] = std::exp(m.trans[i]);
+    for (double v : m.state) t->wmax_abs = std::max(t->wmax_abs, std::fabs(v));
+    for (double v : m.trans) t->tmax_abs = std::max(t->tmax_abs, std::fabs(v));
     rc = upload(&t->wtab, m.state.data(), A * L, "upload state weights");
     if (!rc) rc = upload(&t->exp_trans, et.data(), L * L, "upload transitions");
     if (!rc) rc = upload(&t->trans, m.trans.data(), L * L, "upload transitions");
@@ -251,12 +253,14 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     p.c_n.clear();
     p.skipped.clear();
     p.seq_ready = false;
+    p.n_max = 0;
     int64_t S = 0;
     p.n_windows = 0;
     if (n_contigs) p.contig_ptr[0] = 0;
     for (int32_t c = 0; c < n_contigs; ++c) {
         const int32_t g0 = int32_t(contig_ptr[c] - g_base), n = contig_ptr[c + 1] - contig_ptr[c];
         p.contig_ptr[size_t(c) + 1] = g0 + n;
+        p.n_max = std::max(p.n_max, n);
         if (n < 0) {
             set_error("contig_ptr must be non-decreasing");
             return GECCO_CRF_EINVAL;
@@ -655,7 +659,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 struct SeqLayout {
     size_t lanes, blocks, bytes;
     size_t off_state, off_alpha, off_tmp, off_vlane, off_vblock, off_vmaps, off_vlanemap, off_vblockmap, off_flane,
-        off_fblock, off_flanesuf, off_fblocksuf;
+        off_fblock, off_flanesuf, off_fblocksuf, off_cand, off_stats;
 };
 SeqLayout seq_layout(size_t n) {
     SeqLayout l{};
@@ -668,6 +672,7 @@ SeqLayout seq_layout(size_t n) {
         o += align256(bytes);
         return r;
     };
+    l.off_stats = take(64);  // (first: the decoder's counters keep their place when the batch size changes)
     l.off_state = take((n + kSeqGenesPerLane) * 16);
     l.off_alpha = take(n * 16);
     l.off_tmp = take(n * 16);
@@ -680,6 +685,7 @@ SeqLayout seq_layout(size_t n) {
     l.off_fblock = take(l.blocks * sizeof(FE));
     l.off_flanesuf = take(lanes_pad * sizeof(FE));
     l.off_fblocksuf = take(l.blocks * sizeof(FE));
+    l.off_cand = take((lanes_pad + 4 * l.blocks + 16) * sizeof(SeqArgs::VdCand));
     l.bytes = o + 256;
     return l;
 }
@@ -810,7 +816,11 @@ int ensure_seq(Plan &p, hipStream_t stream) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(p.ws_mutex);
     const SeqLayout l = seq_layout(size_t(p.n_genes));
-    return grow_ws(p.d_seq_ws, p.seq_ws_cap, l.bytes + align256(size_t(p.n_contigs) + 8), "hipMalloc scan workspace");
+    const bool fresh = !p.d_seq_ws || l.bytes + align256(size_t(p.n_contigs) + 24) > p.seq_ws_cap;
+    rc = grow_ws(p.d_seq_ws, p.seq_ws_cap, l.bytes + align256(size_t(p.n_contigs) + 24), "hipMalloc scan workspace");
+    // (the decoder's counters accumulate over launches: they start from zero in a new block)
+    if (!rc && fresh) rc = check_hip(hipMemsetAsync(p.d_seq_ws + l.off_stats, 0, 64, stream), "memset decoder counters");
+    return rc;
 }
 
 int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
@@ -838,7 +848,13 @@ int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
     a.fBlock = reinterpret_cast<FE *>(w + l.off_fblock);
     a.fLaneSuf = reinterpret_cast<FE *>(w + l.off_flanesuf);
     a.fBlockSuf = reinterpret_cast<FE *>(w + l.off_fblocksuf);
-    a.fix_flag = reinterpret_cast<uint8_t *>(w + l.bytes);
+    a.vCand = reinterpret_cast<SeqArgs::VdCand *>(w + l.off_cand);
+    a.vd_stats = reinterpret_cast<uint32_t *>(w + l.off_stats);
+    a.vBound = reinterpret_cast<unsigned long long *>(w + l.bytes);  // (16 bytes in front of the flags: one memset clears both)
+    a.fix_flag = reinterpret_cast<uint8_t *>(w + l.bytes + 16);
+    a.v_wmax2 = 2.0 * p.tables_model->wmax_abs;
+    a.v_tmax = p.tables_model->tmax_abs;
+    a.v_nmax = p.n_max;
     a.flags = p.d_seq_flags;
     a.lane_bits = p.d_seq_lane_bits;
     a.flat_bits = p.d_seq_flat_bits;
@@ -1069,6 +1085,21 @@ int plan_run_decode_pipelined(Plan *cur, const int32_t *d_gene_ptr, const int32_
         if ((rc = check_hip(launch_seq_viterbi_delta(pa, stream), "viterbi launch"))) return rc;
     if (prev && prev != cur) prev->pipe.pending = false;
     return GECCO_CRF_OK;
+}
+
+int plan_viterbi_stats(Plan &p, int64_t out[4], bool reset) {
+    for (int i = 0; i < 4; ++i) out[i] = 0;
+    std::lock_guard<std::mutex> lock(p.ws_mutex);
+    if (p.device < 0 || !p.d_seq_ws) return GECCO_CRF_OK;  // nothing has been decoded yet
+    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
+    if (rc) return rc;
+    if ((rc = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize"))) return rc;
+    uint32_t v[4] = {0, 0, 0, 0};
+    char *at = p.d_seq_ws + seq_layout(size_t(p.n_genes)).off_stats;
+    if ((rc = check_hip(hipMemcpy(v, at, sizeof(v), hipMemcpyDeviceToHost), "read decoder counters"))) return rc;
+    for (int i = 0; i < 4; ++i) out[i] = v[i];
+    if (reset) rc = check_hip(hipMemset(at, 0, sizeof(v)), "clear decoder counters");
+    return rc;
 }
 
 int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, const SegParams &params, int32_t *d_seg,

@@ -21,6 +21,7 @@ struct DeviceTables {
     double2 *wtab2[2] = {nullptr, nullptr};  // L == 2: [A] (other, label) for label = 0 / 1
     double *exp_trans = nullptr;  // [L*L]
     double *trans = nullptr;      // [L*L] raw weights (general-L Viterbi)
+    double wmax_abs = 0.0, tmax_abs = 0.0;  // largest |state weight| / |transition weight| (bounds of the Viterbi exactness margin)
     double *rtab[2] = {nullptr, nullptr};  // L == 2: [32] mu01(label) * 2^(j/32), the exp table of the window kernel's slot constants
 };
 
@@ -38,7 +39,7 @@ struct Plan {
     const Model *model = nullptr;
     int device = -1;  // -1: host-only plan (layout queries work, launches return ENODEV)
     int32_t W = 0, step = 1, pad = 1;
-    int32_t n_contigs = 0, n_genes = 0;
+    int32_t n_contigs = 0, n_genes = 0, n_max = 0;  // (n_max: genes of the longest contig)
     int64_t n_windows = 0;
     // slot-space layout (host)
     int32_t K = 0, S = 0, ntiles = 0, tile_out = 0, tiles_per_wg = 1;
@@ -121,6 +122,8 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
                             double *d_lognorm, hipStream_t stream);
 int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int8_t *d_y, double *d_score,
                      hipStream_t stream);
+// counters of the 2-label Viterbi decoder (crf_device.hpp: SeqArgs::vd_stats); waits for the device
+int plan_viterbi_stats(Plan &p, int64_t out[4], bool reset);
 // returns GECCO_CRF_* ; on HIP failure sets the error text
 int check_hip(hipError_t e, const char *what);
 int get_device_tables(const Model &m, int device, const DeviceTables **out);

@@ -480,6 +480,10 @@ __global__ void __launch_bounds__(kT) vd_exact_fix(const SeqArgs A) {
         if (!A.fix_flag[c]) continue;  // (workgroup-uniform)
         const int gs = A.contig_ptr[c], ge = A.contig_ptr[c + 1];
         if (ge <= gs) continue;
+        if (threadIdx.x == 0 && A.vd_stats) {
+            atomicAdd(A.vd_stats + 2, 1u);
+            atomicAdd(A.vd_stats + 3, uint32_t(ge - gs));
+        }
         uint32_t *bpc = exact_bp_words(A, gs);
         double d0 = 0.0, d1 = 0.0;  // delta of the last gene walked so far (every lane holds a copy)
         exact_states(A, gs, min(kFixChunk, ge - gs), fx[0], 0);
@@ -549,6 +553,19 @@ __global__ void __launch_bounds__(kT) vd_fold(const SeqArgs A) {
     const CE excl = block_scan_exclusive<COp, false>(P, lds, &total);
     reinterpret_cast<CE *>(A.vLane)[blockIdx.x * kT + threadIdx.x] = excl;
     if (threadIdx.x == 0) reinterpret_cast<CE *>(A.vBlock)[blockIdx.x] = total;
+    // the largest bound on CRFsuite's accumulated scores over the batch's contigs (crf_vd_short.hpp: vd_bound), for the
+    // margins of vd_replay / vd_refine: a contig per lane, one atomic per wave
+    if (A.fix_flag && A.csr_gene_ptr) {
+        double mx = 0.0;
+        for (int c = blockIdx.x * kT + threadIdx.x; c < A.n_contigs; c += gridDim.x * kT) {
+            const int gs = A.contig_ptr[c], ge = A.contig_ptr[c + 1];
+            if (ge > gs) mx = fmax(mx, vd_bound(A, double(A.csr_gene_ptr[ge] - A.csr_gene_ptr[gs]), double(ge - gs)));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0 && mx > 0.0)
+            atomicMax(A.vBound, static_cast<unsigned long long>(__double_as_longlong(mx)));  // (non-negative: bit patterns order like values)
+    }
 }
 
 __global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
@@ -559,9 +576,16 @@ __global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
     const CE M = COp::combine(lookback_prefix(reinterpret_cast<const CE *>(A.vBlock), blockIdx.x),
                               reinterpret_cast<const CE *>(A.vLane)[blockIdx.x * kT + slot]);
     double D = M.L;  // the map entering a lane is constant once a contig has started
+    const double d_enter = D;
     uint32_t maps = 0, lane_map = MapOp::identity();
-    const double margin = 1e-6 * fmax(1.0, fmax(fabs(A.v_lo), fabs(A.v_hi)));
-    bool sensitive = false;  // some decision of this lane lies within the noise of its threshold
+    // Coarse margin (crf_vd_short.hpp): (4 R + 4) ulp(M) with M the batch's largest per-contig bound (vd_fold) and R = 1023,
+    // which holds as long as every wave (512 genes) contains a reset -- a contig's first gene or a decision that saturates
+    // for certain; a wave without one is reported like a candidate.  `sat8`: which of the lane's genes saturate for certain.
+    const bool exact = A.v_exact && A.fix_flag && A.csr_gene_ptr;
+    const double margin = exact ? vd_margin(1023.0, __longlong_as_double(static_cast<long long>(A.vBound[0])) * kVdEps)
+                                : 1e-6 * fmax(1.0, fmax(fabs(A.v_lo), fabs(A.v_hi)));
+    bool sensitive = false;  // some decision of this lane lies within the coarse margin of its threshold
+    uint32_t sat8 = 0;
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
         D = ((L.first >> k) & 1u) ? L.d[k] : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + L.d[k]);
@@ -571,22 +595,84 @@ __global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
         const double thi = lst ? 0.0 : A.v_hi, tlo = lst ? 0.0 : A.v_lo;
         maps |= ((D > thi ? 1u : 0u) | (D > tlo ? 2u : 0u)) << (2 * k);
         if (k < L.cnt) sensitive |= fabs(D - thi) <= margin || fabs(D - tlo) <= margin;
+        sat8 |= ((D >= A.v_hi + margin || D <= A.v_lo - margin) ? 1u : 0u) << k;
     }
-    if (sensitive && A.v_exact && A.fix_flag) {
-        // the contigs of the lane's genes are decoded again with CRFsuite's own recursion (vd_exact_fix)
-        int lo = 0, hi = A.n_contigs - 1;  // largest c with contig_ptr[c] <= g0
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (A.contig_ptr[mid] <= L.g0) lo = mid; else hi = mid - 1;
+    if (exact) {
+        // candidates go to vd_refine (next launch), which finds their distance to the last reset and judges them
+        if (sensitive) {
+            const uint32_t at = atomicAdd(reinterpret_cast<uint32_t *>(A.vBound + 1), 1u);
+            A.vCand[at] = SeqArgs::VdCand{uint32_t(blockIdx.x * kT + slot), 0u, d_enter};
         }
-        for (int c = lo; c < A.n_contigs && A.contig_ptr[c] < L.g0 + L.cnt; ++c) A.fix_flag[c] = 1;
+        const bool none = __builtin_amdgcn_ballot_w64((sat8 | L.first) != 0u) == 0ull;  // (positions past the batch count as contig starts)
+        if (none && (slot & 63) == 0) {
+            const uint32_t at = atomicAdd(reinterpret_cast<uint32_t *>(A.vBound + 1), 1u);
+            A.vCand[at] = SeqArgs::VdCand{uint32_t(blockIdx.x * kT + slot) | 0x80000000u, 0u, 0.0};
+        }
     }
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
-    A.vMaps[blockIdx.x * kT + slot] = maps;
+    A.vMaps[blockIdx.x * kT + slot] = maps | (sat8 << 16);  // (v_labels reads the low 16 bits)
     uint32_t total;
     A.vLaneMap[blockIdx.x * kT + slot] = block_scan_exclusive_back<MapOp>(lane_map, lds, &total);
     if (slot == 0) A.vBlockMap[blockIdx.x] = total;
+}
+
+// flat layout: the candidates of vd_replay, one per lane of this (small) launch.  A candidate lane learns r -- the genes since
+// the last reset before its first gene -- from the reset bits of the lanes to its left (vMaps, flat_bits), repeats its
+// eight steps from the Delta that entered it and tests every decision against the margin of ITS r (vd_margin); only a
+// decision inside that margin sends its contig to CRFsuite's own recursion (vd_exact_fix).
+__device__ __forceinline__ void vd_flag_contigs(const SeqArgs &A, int g_lo, int g_hi) {  // contigs with a gene in [g_lo, g_hi)
+    int lo = 0, hi = A.n_contigs - 1;  // largest c with contig_ptr[c] <= g_lo
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (A.contig_ptr[mid] <= g_lo) lo = mid; else hi = mid - 1;
+    }
+    for (int c = lo; c < A.n_contigs && A.contig_ptr[c] < g_hi; ++c) A.fix_flag[c] = 1;
+}
+__global__ void __launch_bounds__(kT) vd_refine(const SeqArgs A) {
+    const uint32_t count = *reinterpret_cast<const uint32_t *>(A.vBound + 1);
+    const double ulpM = __longlong_as_double(static_cast<long long>(A.vBound[0])) * kVdEps;
+    const double margin = vd_margin(1023.0, ulpM);
+    for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
+        const SeqArgs::VdCand rec = A.vCand[i];
+        const int lane = int(rec.lane & 0x7fffffffu), g0 = lane * kGPL;
+        if (rec.lane & 0x80000000u) {  // 512 genes without a reset: r is not bounded by 1023 there
+            vd_flag_contigs(A, g0, min(g0 + 64 * kGPL, A.n_genes));
+            if (A.vd_stats) atomicAdd(A.vd_stats + 1, 1u);
+            continue;
+        }
+        const int cnt = min(kGPL, A.n_genes - g0);
+        const uint32_t bits = A.flat_bits[lane], first = bits & 0xffu, last = bits >> 8;
+        // r of the gene before the lane's first: its distance to the last gene s that starts a contig or saturates for certain
+        int r = 0;
+        if (!(first & 1u)) {
+            int l = lane - 1;
+            uint32_t reset = 0;
+            for (; l >= 0; --l) {  // (gene 0 of the batch starts a contig)
+                reset = ((A.vMaps[l] >> 16) | A.flat_bits[l]) & 0xffu;
+                if (reset) break;
+            }
+            const int s_gene = l * kGPL + (31 - __builtin_clz(reset));
+            r = g0 - 1 - s_gene;
+        }
+        double D = rec.d_enter;
+        bool flagged = false;
+        for (int k = 0; k < cnt; ++k) {
+            const double dk = A.dstate[g0 + k];
+            const bool fst = (first >> k) & 1u;
+            r = fst ? 0 : ((D >= A.v_hi + margin || D <= A.v_lo - margin) ? 1 : r + 1);
+            D = fst ? dk : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dk);
+            const bool lst = (last >> k) & 1u;
+            const double thi = lst ? 0.0 : A.v_hi, tlo = lst ? 0.0 : A.v_lo;
+            const double mr = vd_margin(double(r), ulpM);
+            flagged |= fabs(D - thi) <= mr || fabs(D - tlo) <= mr;
+        }
+        if (A.vd_stats) atomicAdd(A.vd_stats + 0, 1u);
+        if (flagged) {
+            vd_flag_contigs(A, g0, g0 + cnt);
+            if (A.vd_stats) atomicAdd(A.vd_stats + 1, 1u);
+        }
+    }
 }
 
 // short contigs: ONE launch per decoder (crf_vd_short.hpp)
@@ -1002,12 +1088,13 @@ hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream) {
     const bool exact = a.v_exact && a.csr_gene_ptr && a.fix_flag;
     SeqArgs b = a;
     if (!exact) b.fix_flag = nullptr;
-    if (exact) {
-        const hipError_t e = hipMemsetAsync(a.fix_flag, 0, size_t(a.n_contigs), stream);
+    if (exact) {  // (the bound and the candidate counter sit in the 16 bytes in front of the flags)
+        const hipError_t e = hipMemsetAsync(a.vBound, 0, 16 + size_t(a.n_contigs), stream);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(vd_fold, dim3(nb), dim3(kT), 0, stream, b);
     hipLaunchKernelGGL(vd_replay, dim3(nb), dim3(kT), 0, stream, b);
+    if (exact) hipLaunchKernelGGL(vd_refine, dim3(8), dim3(kT), 0, stream, b);
     hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, b);
     // contigs that vd_replay flagged (a decision inside the rounding margin): CRFsuite's own recursion
     if (exact) hipLaunchKernelGGL(vd_exact_fix, dim3(min(a.n_contigs, 1024)), dim3(kT), 0, stream, b);

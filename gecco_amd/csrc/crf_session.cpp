@@ -113,6 +113,9 @@ struct DeviceCtx {
     hipStream_t up = nullptr, comp = nullptr, down = nullptr;
     Lane lanes[kLanes];
     int next_lane = 0;
+    // decode calls (marginals + labels): the launch of chunk k carries the Viterbi workgroups of the device's chunk k - 1
+    // (plan_run_decode_pipelined), so that chunk's labels are downloaded -- and its lane is `done` -- behind the NEXT launch
+    Lane *pending = nullptr;
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -251,6 +254,26 @@ void deal_chunks(std::vector<Chunk> &chunks, int n_devices) {
     }
 }
 
+// sum of n bytes, eight at a time: neighbouring bytes are added into 16-bit fields of a 64-bit word, 127 rounds of which
+// cannot overflow (127 * 510 < 65536)
+uint64_t byte_sum(const uint8_t *p, size_t n) {
+    constexpr uint64_t kLow = 0x00FF00FF00FF00FFull;
+    uint64_t total = 0;
+    size_t i = 0;
+    while (i + 8 <= n) {
+        uint64_t acc = 0;
+        const size_t rounds = std::min<size_t>((n - i) / 8, 127);
+        for (size_t k = 0; k < rounds; ++k, i += 8) {
+            uint64_t x;
+            std::memcpy(&x, p + i, 8);
+            acc += (x & kLow) + ((x >> 8) & kLow);
+        }
+        total += (acc & 0xFFFF) + ((acc >> 16) & 0xFFFF) + ((acc >> 32) & 0xFFFF) + (acc >> 48);
+    }
+    for (; i < n; ++i) total += p[i];
+    return total;
+}
+
 struct RunCtx {
     Session &S;
     const BatchRequest &r;
@@ -259,7 +282,32 @@ struct RunCtx {
     int32_t W, step, pad;
 };
 
-int submit(RunCtx &X, Lane &ln, int chunk_index) {
+// labels of the device's pending chunk: its Viterbi workgroups have just been launched on `comp` and `down` waits for them
+int finish_pending(RunCtx &X, DeviceCtx &D) {
+    Lane &pl = *D.pending;
+    D.pending = nullptr;
+    const Chunk &pk = X.chunks[pl.chunk];
+    const size_t ng = size_t(pk.g1 - pk.g0);
+    X.S.stats.d2h_bytes += int64_t(ng);
+    int rc = check_hip(hipMemcpyAsync(X.r.y_out + pk.g0, pl.d_y.p, ng, hipMemcpyDeviceToHost, pl.down), "D2H labels");
+    if (rc) return rc;
+    return check_hip(hipEventRecord(pl.done, pl.down), "hipEventRecord");
+}
+
+// the labels of the last chunk a device scored in a decode call: a launch of Viterbi workgroups only
+int flush_pending(RunCtx &X, DeviceCtx &D) {
+    if (!D.pending) return GECCO_CRF_OK;
+    Lane &pl = *D.pending;
+    int rc = check_hip(hipSetDevice(pl.device), "hipSetDevice");
+    if (rc) return rc;
+    if ((rc = plan_run_decode_pipelined(nullptr, nullptr, nullptr, X.r.label, nullptr, &pl.plan, reinterpret_cast<int8_t *>(pl.d_y.p), pl.comp)))
+        return rc;
+    if ((rc = check_hip(hipEventRecord(pl.ev_comp, pl.comp), "hipEventRecord"))) return rc;
+    if ((rc = check_hip(hipStreamWaitEvent(pl.down, pl.ev_comp, 0), "hipStreamWaitEvent"))) return rc;
+    return finish_pending(X, D);
+}
+
+int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
     Session &S = X.S;
     const BatchRequest &r = X.r;
     Chunk &ck = X.chunks[chunk_index];
@@ -279,13 +327,6 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
     // ---- uploads first: the bulk copies are on their way while the host lays the chunk out
     if (ng) {
         if (r.degree) {  // degree bytes cross PCIe; the row pointers are rebuilt on the device (below, on the compute stream)
-            // the device derives the rows from the bytes, the host takes the chunk's base offset from gene_ptr: they must agree
-            uint64_t dsum = 0;
-            for (const uint8_t *q = r.degree + ck.g0, *e = q + ng; q < e; ++q) dsum += *q;
-            if (dsum != uint64_t(a1 - a0)) {
-                set_error("degree bytes do not add up to gene_ptr over a chunk (degree must equal diff(gene_ptr))");
-                return GECCO_CRF_EINVAL;
-            }
             if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
             if ((rc = ln.d_deg.reserve(size_t(ng) + 32, "hipMalloc degrees"))) return rc;
             if ((rc = ln.d_deg_ws.reserve(degree_scratch_bytes(ng), "hipMalloc degree scan"))) return rc;
@@ -326,6 +367,12 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
         }
     }
     tm.lap("h2d csr", chunk_index);
+    // the device derives the rows from the degree bytes, the host takes the chunk's base offset from gene_ptr: they must agree
+    // (checked while the copies above are under way)
+    if (ng && r.degree && byte_sum(r.degree + ck.g0, size_t(ng)) != uint64_t(a1 - a0)) {
+        set_error("degree bytes do not add up to gene_ptr over a chunk (degree must equal diff(gene_ptr))");
+        return GECCO_CRF_EINVAL;
+    }
     const double t0 = now_s();
     {
         // marginals (and labels) only: the window kernel reads the plan tables (~0.1 MB per chunk, each word once) from the
@@ -364,6 +411,22 @@ int submit(RunCtx &X, Lane &ln, int chunk_index) {
             if ((rc = ln.d_score.reserve(size_t(nc) * 8, "hipMalloc scores"))) return rc;
             d_score = reinterpret_cast<double *>(ln.d_score.p);
         }
+    }
+    const bool piped = X.windowed && X.viterbi && !r.score_out && !X.full && !r.want_segments;
+    if (piped) {
+        // ONE launch per chunk: this chunk's window tiles + the Viterbi workgroups of the chunk this device scored before
+        Lane *prev = D.pending;
+        rc = plan_run_decode_pipelined(&ln.plan, d_gp, d_at, r.label, d_p, prev ? &prev->plan : nullptr,
+                                       prev ? reinterpret_cast<int8_t *>(prev->d_y.p) : nullptr, ln.comp);
+        if (rc) return rc;
+        if ((rc = check_hip(hipEventRecord(ln.ev_comp, ln.comp), "hipEventRecord"))) return rc;
+        if ((rc = check_hip(hipStreamWaitEvent(ln.down, ln.ev_comp, 0), "hipStreamWaitEvent"))) return rc;
+        if (prev && (rc = finish_pending(X, D))) return rc;
+        S.stats.d2h_bytes += int64_t(ng) * 8;
+        if ((rc = check_hip(hipMemcpyAsync(r.p_out + ck.g0, d_p, size_t(ng) * 8, hipMemcpyDeviceToHost, ln.down), "D2H p"))) return rc;
+        D.pending = &ln;  // (its labels and its `done` come with the device's next launch, or with the flush)
+        tm.lap("launch", chunk_index);
+        return GECCO_CRF_OK;
     }
     if (X.windowed && X.viterbi) {
         rc = plan_run_decode(ln.plan, d_gp, d_at, r.label, d_p, d_y, d_score, ln.comp);
@@ -558,8 +621,12 @@ int session_run(Session &S, const BatchRequest &r) {
             Lane &ln = D.lanes[D.next_lane];
             D.next_lane = (D.next_lane + 1) % kLanes;
             if ((rc = retire(X, ln))) break;
-            rc = submit(X, ln, queue[d][head[d]++]);
+            rc = submit(X, D, ln, queue[d][head[d]++]);
         }
+    }
+    for (auto &d : S.devs) {
+        if (!rc) rc = flush_pending(X, *d);
+        d->pending = nullptr;
     }
     // drain (also after an error: nothing of this call may still be in flight when it returns)
     for (auto &d : S.devs)

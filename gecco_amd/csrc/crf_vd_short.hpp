@@ -42,11 +42,28 @@ struct COp {
     }
 };
 
+// ---- when is a decision of the difference form PROVABLY crf1dc_viterbi's? -----------------------------------------
+// CRFsuite compares fl(delta_t[0] + T[0][j]) with fl(delta_t[1] + T[1][j]) on accumulated scores of magnitude up to
+//   M = nnz max|w| + n max|trans|        (a contig of n genes and nnz attribute entries; vd_bound),
+// every step of which rounds twice (<= ulp(M) per step).  But the two paths it compares share their history up to the last
+// gene u at which BOTH labels took the same predecessor -- a decision beyond [lo, hi], where the clamp of the difference
+// form saturates -- or up to the contig's first gene, where delta = state exactly: from there on both computed scores are
+// x + (exact terms) + (at most r ulp(M) of rounding each), r = genes since u, with the SAME x.  So its decision at gene t
+// equals the real-arithmetic one -- which the difference form evaluates with an error far below ulp(M) per step -- whenever
+//   |Delta_t - threshold| > (4 r_t + 4) ulp(M)                                                      (vd_margin)
+// (2 r + 1 for CRFsuite's two scores and its two additions, as much again for the difference form's own roundings and
+// the rounded thresholds).  r_t <= n, so a first test against the coarse margin (4 n + 4) ulp(M) -- which also defines
+// "saturates for certain" -- finds the candidates (about one gene in 10^8 on metagenome-sized contigs); a candidate's
+// lane then finds its r_t by walking back to the last certain saturation and tests again.  Only a decision inside THAT
+// margin -- exact ties of integer-valued models; otherwise practically never -- sends its contig to CRFsuite's own
+// recursion below.  (Until round 4 the margin was a flat 1e-6: 10^5 times too wide for 200-gene contigs, and on C5 it
+// sent two 50 000-gene contigs per launch through the sequential walk: 1.27 ms per step instead of 0.09.)
+__device__ __forceinline__ double vd_bound(const SeqArgs &A, double nnz, double n) { return nnz * A.v_wmax2 + (n + 2.0) * A.v_tmax; }
+constexpr double kVdEps = 2.220446049250313e-16;  // 2^-52: ulp(M) <= M * 2^-52
+__device__ __forceinline__ double vd_margin(double r, double ulpM) { return (4.0 * r + 4.0) * ulpM; }
+
 // ---- CRFsuite's own recursion for the contigs that need it ------------------------------------------------
-// The difference form decides like [EXT] crf1dc_viterbi wherever a decision keeps its distance from its threshold: both
-// evaluate the same real quantity, the rounding noise of either (accumulated scores of n genes: ~ n |score| 2^-53, 1e-11
-// for 50 000 genes) is far below the margin of 1e-6.  A contig with a decision INSIDE the margin -- exact ties of
-// integer-valued models included -- is decoded again here, the way CRFsuite does it: state scores summed attribute by
+// A contig with a decision INSIDE the margin is decoded again here, the way CRFsuite does it: state scores summed attribute by
 // attribute, delta_t[j] = max_i(delta_{t-1}[i] + trans[i][j]) + state_t[j] with the strict-< first-arg-max update, one
 // gene after the other from the contig's first (oracle_viterbi_seq is this recursion).  The workgroup computes the state
 // scores of 1024 genes at a time in parallel (LDS), one lane walks them; back-pointers go to a byte per gene in global
@@ -291,7 +308,13 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     // to its contig's first gene) and re-runs the recursion sequentially from there -- a few genes on
     // average -- and the decisions below are those of the strictly sequential difference recursion, bit for
     // bit, independent of lane and workgroup boundaries (oracle_viterbi_delta is that recursion).
-    const double margin = 1e-6 * fmax(1.0, fmax(fabs(A.v_lo), fabs(A.v_hi)));
+    // coarse margin of the workgroup: (4 n + 4) ulp(M) with n, nnz of all its (whole) contigs together; without the CSR
+    // arrays (no exact pass possible) the flat 1e-6 of rounds 2 and 3
+    double ulpM = 0.0, margin = 1e-6 * fmax(1.0, fmax(fabs(A.v_lo), fabs(A.v_hi)));
+    if (A.csr_gene_ptr) {
+        ulpM = vd_bound(A, double(A.csr_gene_ptr[g0 + n] - A.csr_gene_ptr[g0]), double(n)) * kVdEps;
+        margin = vd_margin(double(n), ulpM);
+    }
     uint32_t maps = 0, lane_map = MapOp::identity();
     bool sensitive = false;  // some decision of this lane lies within the noise of its threshold
     {
@@ -332,8 +355,11 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     // values differ from the sequential ones by less than the margin at every gene: the clamp does not amplify, the
     // additions are the same).  Any other lane (ties of integer-weight models; otherwise one gene in a million)
     // rebuilds its entering value sequentially and decides again.
+    bool lane_flagged = false;  // a decision of this lane lies inside the margin of ITS distance r to the last certain saturation
     if (sensitive && cnt > 0) {
         double D = 0.0;  // Delta of the gene before the lane's first, rebuilt sequentially
+        int r = 0;       // genes since both labels last shared a predecessor for certain (0: a contig's first gene)
+        auto certain = [&](double x) { return x >= A.v_hi + margin || x <= A.v_lo - margin; };
         if (!(first & 1u)) {
             // nearest restart at or before gene t0 - 1: a contig's first gene, or a gene whose predecessor is marked
             const int t0 = slot * kGPL;  // local index of the lane's first gene (> 0 here: gene 0 starts a contig)
@@ -342,29 +368,47 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
             for (;; --p) {
                 if (A.flags[g0 + p] & 1u) {
                     D = dval(p);
+                    r = 0;
                     break;
                 }
                 // p >= 1: local gene 0 is a contig's first
                 const uint32_t c = reinterpret_cast<const uint8_t *>(&stg.st[((p - 1) / kGPL) * (kGPL + 1) + kGPL])[(p - 1) % kGPL];
                 if (c) {
                     D = (c == 1u ? A.v_hi : A.v_lo) + (A.v_k + dval(p));
+                    r = 1;
                     break;
                 }
             }
-            for (int t = p + 1; t < t0; ++t) D = fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dval(t));
+            for (int t = p + 1; t < t0; ++t) {
+                r = certain(D) ? 1 : r + 1;
+                D = fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dval(t));
+            }
         }
         maps = 0;
 #pragma unroll
         for (int k = 0; k < kGPL; ++k) {
             if (k < cnt) {
                 const double dvk = row[k];
-                D = ((first >> k) & 1u) ? dvk : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dvk);
+                const bool fst = (first >> k) & 1u;
+                r = fst ? 0 : (certain(D) ? 1 : r + 1);
+                D = fst ? dvk : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dvk);
                 const bool lst = (last >> k) & 1u;
-                maps |= ((D > (lst ? 0.0 : A.v_hi) ? 1u : 0u) | (D > (lst ? 0.0 : A.v_lo) ? 2u : 0u)) << (2 * k);
+                const double thi = lst ? 0.0 : A.v_hi, tlo = lst ? 0.0 : A.v_lo;
+                maps |= ((D > thi ? 1u : 0u) | (D > tlo ? 2u : 0u)) << (2 * k);
+                const double mr = vd_margin(double(r), ulpM);
+                lane_flagged |= fabs(D - thi) <= mr || fabs(D - tlo) <= mr;
             }
         }
+        if (A.vd_stats) {
+            atomicAdd(A.vd_stats + 0, 1u);
+            if (lane_flagged) atomicAdd(A.vd_stats + 1, 1u);
+        }
     }
-    __syncthreads();  // values and marks have been read: the label bytes go over the first rows of `st` below
+    // values and marks have been read: the label bytes go over the first rows of `st` below.  (One barrier either way; a
+    // workgroup with candidates learns here whether any of them stayed inside its own margin.)
+    bool wg_flagged = false;
+    if (wg_sensitive) wg_flagged = __syncthreads_or(lane_flagged ? 1 : 0);
+    else __syncthreads();
     uint8_t *yb = reinterpret_cast<uint8_t *>(stg.st);
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k)
@@ -388,13 +432,13 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     }
     // ---- contigs with a decision inside the margin: CRFsuite's own recursion decides (exact_delta_contig).  The
     // sensitive lanes mark the first genes of the contigs they touch; the workgroup then takes the marked contigs one by one.
-    if (wg_sensitive && A.csr_gene_ptr) {
+    if (wg_flagged && A.csr_gene_ptr) {
         uint32_t *mark = stg.mark;  // kBlockGenes bits
         int *c_end = &stg.c_end;
         __syncthreads();  // (drains the label stores above: the exact pass overwrites some of them)
         if (slot < kBlockGenes / 32) mark[slot] = 0;
         __syncthreads();
-        if (lane_sensitive) {
+        if (lane_flagged) {
             int prev = -1;
             for (int k = 0; k < cnt; ++k) {
                 int t = slot * kGPL + k;
@@ -421,6 +465,10 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
                 __syncthreads();
                 const int ce = *c_end;
                 __syncthreads();
+                if (slot == 0 && A.vd_stats) {
+                    atomicAdd(A.vd_stats + 2, 1u);
+                    atomicAdd(A.vd_stats + 3, uint32_t(ce - cs));
+                }
                 exact_delta_contig(A, g0 + cs, g0 + ce, st2);
             }
         }

@@ -40,6 +40,14 @@ def host_buffer_levels(model, wl, devices=(0,), reps=5, W=20):
     out["one_shot_pinned_degree_bytes"] = {"ms": dt * 1e3, "genes_per_s": n / dt, "h2d_mb": st["h2d_bytes"] / 1e6,
                                            "note": "the same with one degree byte per gene on the wire instead of a 4-byte row pointer "
                                                    "(gecco_crf_session_windowed_degrees); row pointers rebuilt on the device"}
+    outy = nat.pinned_empty(n, np.int8)
+    dt = _timed(lambda: ses.decode(cp, gp, at, W, out_p=outp, out_y=outy), reps)
+    st = ses.stats()
+    out["decode_pinned"] = {"ms": dt * 1e3, "genes_per_s": n / dt, "chunks": st["n_chunks"], "h2d_mb": st["h2d_bytes"] / 1e6,
+                            "d2h_mb": st["d2h_bytes"] / 1e6,
+                            "note": "the metric's own step at this level (gecco_crf_session_decode): windowed marginals + Viterbi labels, "
+                                    "pinned buffers in and out; one pipelined launch per chunk (window tiles + the Viterbi workgroups "
+                                    "of the chunk before), a flush at the end"}
     ann = nat.pinned_copy((np.diff(wl["gene_ptr"]) > 0).astype(np.uint8))
     dt = _timed(lambda: ses.clusters(cp, gp, at, ann, W, want_p=False, want_seg_p=True), reps)
     seg = ses.clusters(cp, gp, at, ann, W, want_p=False, want_seg_p=True)[0]

@@ -212,6 +212,11 @@ int gecco_crf_plan_time_windowed(gecco_crf_plan *p, const int32_t *d_gene_ptr, c
 int gecco_crf_plan_time_decode_pipelined(gecco_crf_plan *p, const int32_t *d_gene_ptr, const int32_t *d_attr_id,
                                          int32_t label, double *d_p_out, int8_t *d_y, void *stream, int32_t warmup,
                                          int32_t iters, float *ms_per_launch);
+/* What the 2-label Viterbi decoder of this plan has met since the last call with reset != 0 (waits for the device):
+ * out[0] decisions inside the coarse margin of their threshold (candidates), out[1] decisions inside the margin in which the
+ * difference form is not provably [EXT] crf1dc_viterbi's, out[2] contigs decoded again with CRFsuite's own recursion
+ * because of those, out[3] the genes of these contigs.  All zero for models the any-label kernels serve. */
+int gecco_crf_plan_viterbi_stats(gecco_crf_plan *p, int64_t out[4], int32_t reset);
 
 /* ---- batch driver: host buffers in, host buffers out, one or several devices ----------------
  * What `gecco run` reaches through ClusterCRF.predict_probabilities (gecco/crf/__init__.py:244-258:

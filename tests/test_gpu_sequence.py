@@ -349,7 +349,9 @@ def test_viterbi_labels_are_crfsuites_on_planted_ties(nat):
     from oracle import crf_oracle as orc
 
     trans = np.array([[2.669891070463728, -2.599571900486168], [-2.6019205422130995, 2.5683226020688488]])
-    for lengths in ([200] * 300, [50000, 177, 50000, 50000, 23, 50000]):
+    import torch
+
+    for lengths in ([200] * 300, [50000, 177, 50000, 50000, 23, 50000], [300000, 61, 300000]):
         rng = np.random.default_rng(len(lengths))
         n = sum(lengths)
         w = np.zeros((n, 2))
@@ -371,3 +373,48 @@ def test_viterbi_labels_are_crfsuites_on_planted_ties(nat):
         # round the same way in both forms
         yd = orc.viterbi_delta(w, trans, cptr, gptr, attr)
         assert (yd != ey).any() or len(lengths) < 10
+        # what the decoder says it did: every planted end lies inside the margin of its distance to the last saturation,
+        # so every contig went through CRFsuite's recursion -- and nothing else did (real-valued weights elsewhere)
+        plan = nat.Plan(model, cptr, 20, 1, True, device=0)
+        d_gp, d_at = torch.from_numpy(gptr).cuda(), torch.from_numpy(attr).cuda()
+        d_y = torch.zeros(n, dtype=torch.int8, device="cuda:0")
+        plan.viterbi_stats(reset=True)
+        plan.run_viterbi(d_gp.data_ptr(), d_at.data_ptr(), d_y.data_ptr())
+        st = plan.viterbi_stats()
+        np.testing.assert_array_equal(d_y.cpu().numpy().astype(np.int32), ey)
+        assert st["contigs_redecoded"] == len(lengths) and st["genes_redecoded"] == n, st
+        assert len(lengths) <= st["inside_margin"] <= st["candidates"], st
+
+
+def test_viterbi_margin_is_rigorous_and_rarely_met(nat):
+    """The margin inside which a decision of the difference form is not provably CRFsuite's is (4 r + 4) ulp(M), r = genes
+    since both labels last shared a predecessor for certain, M = bound on the contig's accumulated scores
+    (crf_vd_short.hpp).  On real-valued models it is practically never met: no contig of a C2-shaped batch, nor of five
+    30 000-gene contigs, is decoded again -- and the labels are the oracle's delta recursion's (= [EXT] crf1dc_viterbi).
+    A model with small integer weights ties exactly all the time: there the second pass does run."""
+    import torch
+    from oracle import crf_oracle as orc
+    from tests.helpers import synth_contigs, synth_model
+
+    rng = np.random.default_rng(4242)
+    A = 3000
+    w, trans = synth_model(A, rng)
+    for lengths in (list(np.clip(np.round(rng.lognormal(np.log(200), 0.5, size=400)), 5, 2000).astype(int)), [30000] * 5):
+        cptr, gptr, attr = synth_contigs(rng, lengths, A)
+        n = int(cptr[-1])
+        ey, _ = orc.viterbi(w, trans, cptr, gptr, attr)
+        for ww, expect_redecode in ((w, False), (np.round(w), True)):
+            model = nat.Model.from_tables(ww, np.round(trans) if expect_redecode else trans)
+            plan = nat.Plan(model, cptr, 20, 1, True, device=0)
+            d_gp, d_at = torch.from_numpy(gptr).cuda(), torch.from_numpy(attr).cuda()
+            d_y = torch.zeros(n, dtype=torch.int8, device="cuda:0")
+            plan.viterbi_stats(reset=True)
+            plan.run_viterbi(d_gp.data_ptr(), d_at.data_ptr(), d_y.data_ptr())
+            st = plan.viterbi_stats()
+            if expect_redecode:
+                ey2, _ = orc.viterbi(np.round(w), np.round(trans), cptr, gptr, attr)
+                np.testing.assert_array_equal(d_y.cpu().numpy().astype(np.int32), ey2)
+                assert st["contigs_redecoded"] > 0, st
+            else:
+                np.testing.assert_array_equal(d_y.cpu().numpy().astype(np.int32), ey)
+                assert st["contigs_redecoded"] == 0 and st["inside_margin"] == 0, st

@@ -99,6 +99,31 @@ def test_session_decode_and_one_shot_agree(nat, real_model, oracle_model):
     assert np.abs(marg - em).max() <= TOL and np.abs(ln - eln).max() <= 1e-9
 
 
+@pytest.mark.parametrize("devices,chunk", [([0], 1500), ([0, 0], 4000), ([0, 0, 0], 1 << 19)])
+def test_session_decode_one_launch_per_chunk(nat, real_model, oracle_model, devices, chunk):
+    """gecco_crf_session_decode drives every device with the pipelined launch: chunk k's window tiles and the Viterbi
+    workgroups of the device's chunk k - 1 in one launch, a flush per device at the end.  Marginals and labels equal the
+    oracle's, whatever the chunking and however the chunks are dealt to the device entries -- over batches with empty
+    contigs, contigs shorter than the window, a contig longer than one scan block (that chunk takes separate launches
+    behind the same call) and pad=False (skipped contigs: NaN marginals, labels all the same)."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(77 + len(devices))
+    lengths = list(rng.integers(1, 400, size=250)) + [0, 0, 1, 2, 19, 20, 21, 0, 3000, 5, 2048, 2049, 7]
+    rng.shuffle(lengths)
+    cptr, gptr, attr = synth_contigs(rng, lengths, oracle_model["state"].shape[0])
+    ey, _ = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    ses = nat.Session(real_model, devices)
+    ses.set_chunk_genes(chunk)
+    for pad in (True, False):
+        ep = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, pad)
+        for _ in range(2):  # (twice: lanes and their plans are reused, pipelines start empty again)
+            p, y = ses.decode(cptr, gptr, attr, 20, pad=pad)
+            _same(p, ep)
+            np.testing.assert_array_equal(y.astype(np.int32), ey)
+        assert ses.stats()["n_chunks"] >= (3 if chunk < 100000 else 1)
+
+
 def test_session_unknown_attribute_ids_carry_no_weight(nat, real_model, oracle_model):
     """ids outside the model's dictionary count as unknown attributes ([EXT] CRFsuite drops unknown names)."""
     from oracle import crf_oracle as orc
