@@ -111,6 +111,11 @@ SIGNATURES = {
         [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, _c_u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
          _vp, _c_f64p, _c_i32p, ctypes.c_int32, _c_i32p, _c_f64p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)],
     ),
+    "gecco_crf_session_clusters_degrees": (
+        ctypes.c_int,
+        [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_u8p, _c_i32p, _c_u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+         _vp, _c_f64p, _c_i32p, ctypes.c_int32, _c_i32p, _c_f64p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)],
+    ),
     "gecco_crf_pack_columns": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp)]),
     "gecco_crf_packed_free": (None, [_vp]),
     "gecco_crf_packed_info": (
@@ -720,10 +725,10 @@ class Session:
 
     def clusters(self, contig_ptr, gene_ptr, attr_id, annotated, window, step=1, label=1, pad=True, threshold=0.8, n_cds=3,
                  edge_distance=0, trim=True, want_p=False, want_seg_p=True, p_out=None, criterion="gecco", n_biopfams=5,
-                 average_threshold=0.6, marker_ptr=None, marker_id=None):
+                 average_threshold=0.6, marker_ptr=None, marker_id=None, degree=None):
         """Windowed marginals + cluster calls in one pass; the probabilities stay on the device unless
         `want_p` / `p_out`.  Returns (seg rows (k, 4), seg_p, seg_off, p or None): `seg_p[seg_off[i]:seg_off[i+1]]`
-        are the probabilities of the genes of row i."""
+        are the probabilities of the genes of row i.  `degree` (uint8, = diff(gene_ptr)): the degree-byte wire format."""
         contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
         annotated = np.ascontiguousarray(annotated, dtype=np.uint8)
         if annotated.size == 0:
@@ -738,8 +743,11 @@ class Session:
         keep = []
         q = refine_params(criterion, threshold, n_cds, n_biopfams, average_threshold, edge_distance, trim, False, marker_ptr,
                           marker_id, keep)
-        _check(self._lib.gecco_crf_session_clusters_ex(
-            self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p), _ptr(attr_id, _c_i32p), _ptr(annotated, _c_u8p),
+        if degree is not None:
+            assert degree.dtype == np.uint8 and degree.size >= n
+        _check(self._lib.gecco_crf_session_clusters_degrees(
+            self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p), _ptr(degree, _c_u8p) if degree is not None else None,
+            _ptr(attr_id, _c_i32p), _ptr(annotated, _c_u8p),
             int(window), int(step), int(label), int(bool(pad)), ctypes.byref(q),
             _ptr(p_out, _c_f64p) if p_out is not None else None, _ptr(seg, _c_i32p), cap, ctypes.byref(n_seg),
             _ptr(seg_p, _c_f64p) if want_seg_p else None, max(n, 1), seg_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))

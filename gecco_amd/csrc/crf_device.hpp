@@ -231,20 +231,20 @@ struct SegArgs {
     int32_t max_seg;
     int32_t *seg_off;       // [max_seg+1] or null: gene offsets of the kept rows
     int32_t *total;
+    double *gout;           // [gcap] or null: probabilities of the genes of the kept rows, row after row
+    int32_t gcap;
 };
 size_t segment_workspace_bytes(int n_genes, int n_contigs);
+// d_gather (may be null; needs d_seg_off): the probabilities of the rows' genes, row after row.  d_seg / d_seg_off / d_total /
+// d_gather may live in pinned host memory (they are only written).
 hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t *d_flags, const int32_t *d_cptr,
                           int n_genes, int n_contigs, const SegParams &params, int32_t *d_seg, int max_seg,
-                          int32_t *d_seg_off, int32_t *d_total, void *d_work, hipStream_t stream);
-// d_out (may be null): the probabilities of the rows' genes; x_*: copies of the rows, their offsets and their number
-// (null: none).  Inputs are read from device memory; the outputs may live in pinned host memory.
+                          int32_t *d_seg_off, int32_t *d_total, void *d_work, hipStream_t stream, double *d_gather = nullptr,
+                          int gather_cap = 0);
 // batch driver's wire format: degree bytes of a chunk's n genes -> its n + 1 row pointers (base + prefix sums); scratch of
 // degree_scratch_bytes(n); d_deg readable for 32 bytes past n
 size_t degree_scratch_bytes(int n);
 hipError_t launch_degree_to_row_ptr(const uint8_t *d_deg, int n, int32_t base, int32_t *d_row_ptr, int32_t *d_scratch, hipStream_t stream);
-hipError_t launch_segment_gather(const double *d_p, const int32_t *d_seg, const int32_t *d_seg_off, const int32_t *d_total,
-                                 int max_seg, double *d_out, int cap, hipStream_t stream, int32_t *x_seg = nullptr,
-                                 int32_t *x_off = nullptr, int32_t *x_total = nullptr);
 
 // ---- any number of labels (crf_general.hip) -------------------------------------------------
 constexpr int kGenMaxL = 32;  // labels: a group of next-pow2(L) lanes must fit in half a wave

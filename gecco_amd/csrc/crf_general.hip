@@ -270,6 +270,164 @@ __global__ void __launch_bounds__(kSmallNT) gl_windowed_small(GenArgs a, SmallTr
     if (tid >= W - 1 && my_gene >= 0) a.p_out[my_gene] = R;
 }
 
+// ---- rows A/B, P, W for 9 to 32 labels: sixteen windows per wave on the fp64 matrix cores -------------------------------
+// Above eight labels the L-vectors of a window no longer fit one lane's registers, and the lane-group kernel at the top of
+// this file pays for every step with L broadcast reads from LDS per lane (0.34 G genes/s at L = 16, 0.10 G at L = 32).
+// A step of the recurrences over SIXTEEN windows at once is a matrix product, alpha'^T = M^T alpha^T (labels x windows):
+//   v_mfma_f64_16x16x4_f64:  D (16 x 16) += A (16 x 4) B (4 x 16);  lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15] and
+//   D[(l >> 4) + 4 r][l & 15] in its result register r   (cdna_hip_programming.md, fragment layout of the f64 form).
+// With windows as columns, result register r of a lane IS its B operand of K-slice r in the next step (row (l >> 4) + 4 r of
+// D = row l >> 4 of slice r of B): alpha and beta never leave their registers, nothing crosses lanes between steps, the
+// slices of M^T (forward) and M (backward) are per-lane constants.  Per step and 16 windows: ceil(L / 16) * ceil(L / 4)
+// MFMAs + one multiplication by the emission per register.
+//   * formulation of gl_windowed_small: un-normalised recurrences on max-normalised factors, alpha_k . beta_k = Z at every
+//     position, 1 / Z folded into the initial beta, queried label permuted to component 0 (lanes 0-15 of a wave own its
+//     alpha_k: W doubles per lane), same range guard on the transition weights (gen_small_ok).  The summation order of a
+//     step differs from CRFsuite's (four terms per MFMA, in hardware order): results agree with the oracle to 1e-12, as
+//     the other kernels of this file do, not bit for bit.
+//   * the maximum over the windows that cover a gene: returnless LDS atomics (ds_max_u64 on the bit pattern of the
+//     non-negative candidate) on best[slot] -- sixteen lanes per step, next to 4-16 MFMAs: the LDS port is idle here (in
+//     the two-label kernel, where a step is seven VALU instructions, the same atomics lose: profiles/r04_window_kernel_ab.txt).
+//   * a workgroup = 256 window starts (4 waves x 4 batches of 16) owning 256 - (W - 1) output slots, emissions staged once
+//     in LDS, one row per label with a stride that keeps the 16 x 4 lanes of a read on distinct banks.
+typedef double gl_v4d __attribute__((ext_vector_type(4)));
+constexpr int kMfmaNT = 256;
+__host__ __device__ constexpr int gl_mfma_stride(int wmax) { return ((kMfmaNT + wmax - 1 + 15) / 32) * 32 + 16; }  // = 16 mod 32, >= slots
+template <int TILES, int NS, int WMAX>
+__global__ void __launch_bounds__(kMfmaNT) gl_windowed_mfma(GenArgs a, double tmax, const int4 *__restrict__ tile_desc) {
+    constexpr int NT = kMfmaNT, S = gl_mfma_stride(WMAX);
+    extern __shared__ double gl_dyn[];
+    const int L = a.L;
+    double *Es = gl_dyn;                                                       // [L][S] emissions, label-major
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(gl_dyn + size_t(L) * S);  // [NT + WMAX]
+    uint32_t *ginfo = reinterpret_cast<uint32_t *>(best + NT + WMAX);          // [NT + WMAX]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = lane & 15, g = lane >> 4;
+    const int W = a.W, OUT = NT - (W - 1), ns = NT + W - 1;
+    const int q0 = blockIdx.x * OUT - (W - 1);
+    const int4 td = tile_desc[blockIdx.x];
+    auto perm = [&](int j) { return j == 0 ? a.label : (j <= a.label ? j - 1 : j); };  // queried label first
+    // per-lane constants: slices of M^T (forward: row = output label, column = input label) and of M (backward)
+    double Af[TILES][NS], Ab[TILES][NS];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            const int row = 16 * t + w, col = 4 * sidx + g;  // (row: label on the matrix side of the product, col: the summed label)
+            const bool ok = row < L && col < L;
+            Af[t][sidx] = ok ? exp(a.trans[perm(col) * L + perm(row)] - tmax) : 0.0;  // M^T[row][col] = M[col][row]
+            Ab[t][sidx] = ok ? exp(a.trans[perm(row) * L + perm(col)] - tmax) : 0.0;
+        }
+    // ---- stage 1: slots -> genes, emissions -> LDS (consecutive lanes read consecutive doubles of the [gene][label] array)
+    for (int sl = tid; sl < NT + WMAX; sl += NT) {
+        const int q = q0 + sl;
+        int gene = -1;
+        bool start = false;
+        if (sl < ns && q >= 0 && q < a.S) {
+            start = (a.start_bits[q >> 6] >> (q & 63)) & 1ull;
+            if (td.w & 1) {
+                gene = q + td.x;
+            } else {
+                int lo = td.y, hi = td.z;  // largest k with c_slot[k] <= q among the contigs in reach
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (a.c_slot[mid] <= q) lo = mid; else hi = mid - 1;
+                }
+                const int pos = q - a.c_slot[lo], np = a.c_slot[lo + 1] - a.c_slot[lo], n = a.c_n[lo];
+                const int gl = pos - ((np - n) >> 1);  // delta // 2 empty items in front (crf/__init__.py:227)
+                if (gl >= 0 && gl < n) gene = a.c_gene[lo] + gl;
+            }
+        }
+        ginfo[sl] = (start ? 0x80000000u : 0u) | uint32_t(gene + 1);
+        best[sl] = 0ull;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ns * L; idx += NT) {
+        const int sl = idx / L, j = idx - sl * L;
+        const int gene = int(ginfo[sl] & 0x7fffffffu) - 1;
+        // (j-th label of the gene's row in memory = permuted component pj: component 0 is the queried label)
+        const int pj = j == a.label ? 0 : (j < a.label ? j + 1 : j);
+        Es[pj * S + sl] = gene >= 0 ? a.E[size_t(gene) * L + j] : 1.0;  // padding items have no attributes: exp(0 - 0) = 1
+    }
+    __syncthreads();
+    // the emission of (component of result register r of tile t, this lane's window, step k); components >= L: any finite
+    // number (their alpha / beta are exact zeros: the matrix rows are)
+    auto em = [&](int t, int r, int slot) { return Es[min(16 * t + 4 * r + g, L - 1) * S + slot]; };
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {
+        const int sl0 = wave * 64 + b * 16 + w;  // slot of this lane's window start
+        gl_v4d D[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) D[t][r] = (16 * t + 4 * r + g) < L ? em(t, r, sl0) : 0.0;
+        double A0[WMAX];
+        A0[0] = D[0][0];
+#pragma unroll
+        for (int k = 1; k < WMAX; ++k) {
+            if (k < W) {
+                gl_v4d N[TILES];
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    N[t] = gl_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int sidx = 0; sidx < NS; ++sidx)
+                        N[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t][sidx], D[sidx / 4][sidx % 4], N[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) D[t][r] = N[t][r] * em(t, r, sl0 + k);
+                A0[k] = D[0][0];
+            }
+        }
+        // Z of the lane's window: all components, i.e. all registers of the four lanes w, w + 16, w + 32, w + 48
+        double z = 0.0;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z += D[t][r];
+        z += __shfl_xor(z, 16);
+        z += __shfl_xor(z, 32);
+        double rz = __builtin_amdgcn_rcp(z);
+        rz = fma(fma(-z, rz, 1.0), rz, rz);
+        const bool my_start = ginfo[sl0] >> 31;
+        gl_v4d B[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) B[t][r] = (my_start && (16 * t + 4 * r + g) < L) ? rz : 0.0;  // beta_{W-1} = 1, times 1/Z
+#pragma unroll
+        for (int k = WMAX - 1; k >= 0; --k) {
+            if (k < W) {
+                const double cand = A0[k] * B[0][0];  // lanes 0-15: component 0 = the queried label
+                if (g == 0)
+                    (void)__hip_atomic_fetch_max(best + sl0 + k, static_cast<unsigned long long>(__double_as_longlong(cand)),
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (k > 0) {  // beta_{k-1} = M (E_k o beta_k)
+                    gl_v4d U[TILES], N[TILES];
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) U[t][r] = B[t][r] * em(t, r, sl0 + k);
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        N[t] = gl_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int sidx = 0; sidx < NS; ++sidx)
+                            N[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[t][sidx], U[sidx / 4][sidx % 4], N[t], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) B[t] = N[t];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int my_gene = int(ginfo[tid] & 0x7fffffffu) - 1;
+    // genes no window covers (step > 1) keep 0.0 like numpy.zeros (crf/__init__.py:251)
+    if (tid >= W - 1 && my_gene >= 0) a.p_out[my_gene] = fmin(__longlong_as_double(static_cast<long long>(best[tid])), 1.0);
+}
+
 // ---- row F: whole-contig marginals, one group per contig, CRFsuite's own sequential recursion ----
 template <int LP>
 __global__ void __launch_bounds__(kGT) gl_marginals_seq(GenArgs a) {
@@ -911,7 +1069,8 @@ int gen_small_tile_out(int W) { return kSmallNT - (W - 1); }
 // alpha per lane next to four L-vectors) and transition weights whose spread cannot take W - 1 un-normalised steps out
 // of the range
 bool gen_small_ok(int L, int W, const double *trans_host) {
-    if (L < 2 || L > 8 || W < 1 || W > (L <= 4 ? 32 : 20) || !trans_host) return false;
+    // (9 to 32 labels: the matrix-core kernel, same geometry and range guard, windows of up to 32 genes)
+    if (L < 2 || L > kGenMaxL || W < 1 || W > (L <= 4 || L > 8 ? 32 : 20) || !trans_host) return false;
     double lo = trans_host[0], hi = trans_host[0];
     for (int i = 0; i < L * L; ++i) {
         lo = trans_host[i] < lo ? trans_host[i] : lo;
@@ -927,6 +1086,31 @@ hipError_t launch_gen_windowed_small(const GenArgs &a, const double *trans_host,
     SmallTrans T{};
     double mx = trans_host[0];
     for (int i = 0; i < L * L; ++i) mx = trans_host[i] > mx ? trans_host[i] : mx;
+    if (L > 8) {  // sixteen windows per wave on the fp64 matrix cores
+        const int wmax = a.W <= 20 ? 20 : 32, ns = (L + 3) / 4;
+        const size_t lds = size_t(L) * gl_mfma_stride(wmax) * 8 + size_t(kMfmaNT + wmax) * 12;
+#define GL_MFMA(TT, NN)                                                                                                              \
+    do {                                                                                                                             \
+        if (wmax == 20) {                                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gl_windowed_mfma<TT, NN, 20>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)); \
+            hipLaunchKernelGGL((gl_windowed_mfma<TT, NN, 20>), dim3(ntiles), dim3(kMfmaNT), lds, stream, a, mx, d_tile_desc);        \
+        } else {                                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gl_windowed_mfma<TT, NN, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)); \
+            hipLaunchKernelGGL((gl_windowed_mfma<TT, NN, 32>), dim3(ntiles), dim3(kMfmaNT), lds, stream, a, mx, d_tile_desc);        \
+        }                                                                                                                            \
+    } while (0)
+        switch (ns) {
+        case 3: GL_MFMA(1, 3); break;
+        case 4: GL_MFMA(1, 4); break;
+        case 5: GL_MFMA(2, 5); break;
+        case 6: GL_MFMA(2, 6); break;
+        case 7: GL_MFMA(2, 7); break;
+        case 8: GL_MFMA(2, 8); break;
+        default: return hipErrorNotSupported;
+        }
+#undef GL_MFMA
+        return hipGetLastError();
+    }
     int perm[8];
     perm[0] = a.label;
     for (int j = 1; j < L; ++j) perm[j] = j <= a.label ? j - 1 : j;

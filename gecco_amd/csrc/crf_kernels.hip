@@ -67,7 +67,9 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // The W = 20 kernel's outputs (probabilities, score differences: 16 B per gene, written once, read by a later launch)
 // leave as write-through stores (agent-scope relaxed atomic store = `global_store_dwordx2 ... sc1`): the lines do not
 // stay dirty in the XCD's L2, so the write-back at the end of the kernel -- which the next launch waits for -- has
-// less to do (decode step 40.5 -> 39.7 us on C3; plain and `nt` stores: 40.5 / 40.1).
+// less to do (decode step 40.5 -> 39.7 us on C3; plain and `nt` stores: 40.5 / 40.1).  Pairing two genes per lane into one
+// 16-byte `sc1` store (the neighbour's value by DPP) was measured too: 28.3 against 27.7 us per step -- the epilogue's
+// extra VALU work costs more than the halved store count saves (profiles/r04_window_kernel_ab.txt).
 __device__ __forceinline__ void store_wt(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -81,45 +83,6 @@ __device__ __forceinline__ void store_wt(double *p, double v) {
 __device__ __forceinline__ double lds_read1(const double *p) {
     return __longlong_as_double(static_cast<long long>(
         __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
-}
-
-// lane l receives lane l+1's value; lane 63 receives +0.0 (DPP wave_shl:1, bound_ctrl:1).
-__device__ __forceinline__ double wave_shl1_zero(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-
-// Write-through stores of a run of CONSECUTIVE doubles, one per lane (lane l: base[idx], lane l + 1: base[idx + 1] where both
-// are valid): a lane whose address is 16-byte aligned takes its right neighbour's value along and stores both with one
-// `global_store_dwordx4 ... sc1`, the neighbour stores nothing; lanes without a partner store 8 bytes as before.  A `dwordx2
-// sc1` store is one fabric write of half a 32-byte sector (MI355X_MICROARCH.md prices it at 2.7x the per-byte cost of
-// `dwordx4`), and the kernel issues half as many store instructions.
-#ifndef GECCO_PAIRED_STORES
-#define GECCO_PAIRED_STORES 1
-#endif
-__device__ __forceinline__ void store_wt_run(double *base, int idx, double v, bool valid) {
-#if GECCO_PAIRED_STORES
-    const double vn = wave_shl1_zero(v);
-    double *p = base + idx;
-    // 16-byte alignment of the lane's address, from the (wave-uniform) base and the index: 32-bit arithmetic only
-    const bool even = (((static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base)) >> 3) + static_cast<uint32_t>(idx)) & 1u) == 0;
-    // the neighbours' `valid` by DPP as well (lane 63 has nothing to its right in this wave, lane 0 nothing to its left)
-    const int vi = valid ? 1 : 0;
-    const bool vnext = __builtin_amdgcn_update_dpp(0, vi, 0x130, 0xF, 0xF, true) != 0;
-    const bool vprev = __builtin_amdgcn_update_dpp(0, vi, 0x138, 0xF, 0xF, true) != 0;
-    if (valid && even && vnext) {
-        const f64x2 pr = {v, vn};
-        // (s_nop: the hazard recogniser does not look into inline asm -- a store of more than 8 bytes must not be followed
-        // at once by a VALU write of its data registers)
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(pr) : "memory");
-    } else if (valid && (even || !vprev)) {
-        store_wt(p, v);
-    }
-#else
-    if (valid) store_wt(base + idx, v);
-#endif
 }
 
 __device__ __forceinline__ void rescale_pair(double &u, double &v) {
@@ -456,13 +419,10 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
         for (int j = 0; j < JMAX; ++j) {
             if (TT > 1 || j == 0 || wave == 0) {
                 const int sl = tid + j * NT;
-                const bool mine = sl >= W - 1 && sl < TT * OUT + (W - 1) && gene[j] >= 0;
-                const double d = sc1[j] - sc0[j];
-                // (s[1] - s[0] = d or -d: one XOR on the sign word)
-                const double dd = __hiloint2double(__double2hiint(d) ^ (P.label ? 0 : int(0x80000000u)), __double2loint(d));
-                if (td.w & 1) {  // regular tile: consecutive lanes hold consecutive genes
-                    store_wt_run(P.dstate_out, gene[j], dd, mine);
-                } else if (mine) {
+                if (sl >= W - 1 && sl < TT * OUT + (W - 1) && gene[j] >= 0) {
+                    const double d = sc1[j] - sc0[j];
+                    // (s[1] - s[0] = d or -d: one XOR on the sign word)
+                    const double dd = __hiloint2double(__double2hiint(d) ^ (P.label ? 0 : int(0x80000000u)), __double2loint(d));
                     store_wt(P.dstate_out + gene[j], dd);
                 }
             }
@@ -606,11 +566,7 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
                 R = fmax(R, carry[((t2 >> 6) - 1) * WMAX + (t2 & 63)]);
             }
             R = fmin(R, 1.0);
-            if (td.w & 1) {  // regular tile: consecutive lanes hold consecutive genes
-                store_wt_run(P.p_out, my_gene, R, tid >= W - 1 && my_gene >= 0);
-            } else if (tid >= W - 1 && my_gene >= 0) {
-                store_wt(P.p_out + my_gene, R);
-            }
+            if (tid >= W - 1 && my_gene >= 0) store_wt(P.p_out + my_gene, R);
         } else if constexpr (!RESCALE) {
             // ---- stage 2a: forward recursion.  Without rescaling the un-normalised vectors satisfy
             //   alpha_k[0] beta_k[0] + alpha_k[1] beta_k[1] = Z   at EVERY position k of the window

@@ -333,7 +333,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     p.all_regular = p.skipped.empty() && p.S == p.n_genes && irr_prefix[size_t(p.K)] == 0;
     if (p.general && m.L >= 3 && gen_small_ok(m.L, W, m.trans.data()) && !std::getenv("GECCO_CRF_GENERAL_GROUPS")) {
         // a handful of labels: one lane per window start (GECCO_CRF_GENERAL_GROUPS=1: the lane-group kernel, tests / A/B)
-        p.kernel_name = "gl_windowed_small";
+        p.kernel_name = m.L > 8 ? "gl_windowed_mfma" : "gl_windowed_small";  // (9 to 32 labels: sixteen windows per wave on the matrix cores)
         p.gen_small = true;
         p.tile_out = gen_small_tile_out(W);
     } else {
@@ -1103,7 +1103,7 @@ int plan_viterbi_stats(Plan &p, int64_t out[4], bool reset) {
 }
 
 int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, const SegParams &params, int32_t *d_seg,
-                     int32_t max_seg, int32_t *d_seg_off, int32_t *d_total, hipStream_t stream) {
+                     int32_t max_seg, int32_t *d_seg_off, int32_t *d_total, hipStream_t stream, double *d_gather, int32_t gather_cap) {
     if (!d_total || max_seg < 0 || (max_seg > 0 && !d_seg)) {
         set_error("plan_run_segment: bad arguments");
         return GECCO_CRF_EINVAL;
@@ -1128,7 +1128,7 @@ int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, con
             return rc;
     }
     return check_hip(launch_segment(d_p, d_annotated, p.d_seq_flags, p.d_contig_ptr, p.n_genes, p.n_contigs, params, d_seg, max_seg,
-                                    d_seg_off, d_total, p.d_seg_ws, stream),
+                                    d_seg_off, d_total, p.d_seg_ws, stream, d_gather, gather_cap),
                      "segment launch");
 }
 

@@ -107,7 +107,8 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync = true);
 // row R chained behind the marginals on the same stream: d_p and d_annotated are device arrays over the
 // plan's genes; rows go to d_seg (device-accessible memory), their number to d_total
 int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, const SegParams &params, int32_t *d_seg,
-                     int32_t max_seg, int32_t *d_seg_off, int32_t *d_total, hipStream_t stream);
+                     int32_t max_seg, int32_t *d_seg_off, int32_t *d_total, hipStream_t stream, double *d_gather = nullptr,
+                     int32_t gather_cap = 0);
 int plan_run_windowed(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
                       hipStream_t stream);
 // windowed marginals + whole-contig Viterbi of the same batch in one pass over the CSR

@@ -16,14 +16,15 @@
 // is summarised by what it does to either entering state -- the state it leaves, how many runs it
 // starts -- plus its number of annotated genes (SegE, crf_scan.hpp); spans compose associatively:
 //   seg_fold     a lane folds 8 genes for both entering states; wave scan by DPP, wave totals in LDS
-//   seg_top      one workgroup scans the per-workgroup totals (the only serial step: n/2048 elements)
-//   seg_replay   every lane re-walks its 8 genes from its now known entering state: writes the
-//                prefix count of annotated genes pre[] and, at run starts / ends, the raw run table
-//                (runs are dense and ordered: row = number of runs started before)
+//   seg_replay   every workgroup first reduces the totals of the workgroups before it (n/2048 elements, 64 per step of a
+//                wave: no separate scan launch, nobody waits for anybody); every lane then re-walks its 8 genes from
+//                its now known entering state: writes the prefix count of annotated genes pre[] and, at run starts /
+//                ends, the raw run table (runs are dense and ordered: row = number of runs started before)
 //   seg_validate one lane per raw run: contig, cluster number, trimming and the annotated / edge
 //                counts by binary searches in pre[] (no walk over the run either)
-//   seg_kept_top + seg_compact   ordered compaction of the kept rows (+ gene offsets of the kept rows)
-// Bound: HBM, 2 x 10 B/gene read + 4 B/gene written; six short launches.
+//   seg_compact  ordered compaction of the kept rows (the counts of the tiles before a tile reduced the same way),
+//                their gene offsets and -- on request -- the probabilities of their genes (what a cluster table needs of p)
+// Bound: HBM, 2 x 10 B/gene read + 4 B/gene written; four short launches (round 3: six + the gather).
 #include <algorithm>
 
 #include "crf_device.hpp"
@@ -35,7 +36,6 @@ namespace {
 constexpr int kT = kScanThreads;
 constexpr int kGPL = 8;  // genes per lane
 constexpr int kBlockGenes = kT * kGPL;
-constexpr int kTopThreads = 1024;
 
 struct SegOp {
     static __device__ __forceinline__ SegE identity() { return SegE{2u, 0u, 0u, 0u}; }
@@ -118,29 +118,31 @@ __global__ void __launch_bounds__(kT) seg_fold(const SegArgs A) {
     if (threadIdx.x == 0) A.block[blockIdx.x] = total;
 }
 
-// exclusive scan in place over the per-workgroup elements; the grand total gives the number of raw runs
-__global__ void __launch_bounds__(kTopThreads) seg_top(const SegArgs A, int nb) {
-    __shared__ SegE lds[kTopThreads / 64];
-    SegE carry = SegOp::identity();
-    for (int base = 0; base < nb; base += kTopThreads) {
-        const int i = base + threadIdx.x;
-        const SegE mine = i < nb ? A.block[i] : SegOp::identity();
-        SegE total;
-        const SegE excl = block_scan_exclusive<SegOp, false, SegE, kTopThreads>(mine, lds, &total);
-        if (i < nb) A.block[i] = SegOp::combine(carry, excl);
-        carry = SegOp::combine(carry, total);
+// Product of the elements e[0 .. n) in order, by ONE wave (every wave of a workgroup for itself: no barrier): 64 at a time.
+__device__ __forceinline__ SegE wave_prefix_total(const SegE *__restrict__ e, int n) {
+    const int lane = threadIdx.x & 63;
+    SegE acc = SegOp::identity();
+    for (int base = 0; base < n; base += 64) {
+        const SegE mine = base + lane < n ? e[base + lane] : SegOp::identity();
+        const SegE inc = wave_scan_inclusive<SegOp, false>(mine);
+        auto bc = [](uint32_t v) { return uint32_t(__builtin_amdgcn_readlane(int(v), 63)); };
+        acc = SegOp::combine(acc, SegE{bc(inc.map), bc(inc.ng0), bc(inc.ng1), bc(inc.ann)});
     }
-    if (threadIdx.x == 0) {
-        *A.n_raw = int32_t(carry.ng0);  // the batch is entered "out"
-        A.pre[A.n_genes] = int32_t(carry.ann);
-    }
+    return acc;
 }
 
 __global__ void __launch_bounds__(kT) seg_replay(const SegArgs A) {
     __shared__ Stage stg;
     const LaneIn L = load_lane(A, stg);
+    // what the workgroups before this one do to the grouper (the only serial step of round 3, a launch of its own then)
+    const SegE B = wave_prefix_total(A.block, blockIdx.x);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const SegE all = SegOp::combine(B, A.block[blockIdx.x]);
+        *A.n_raw = int32_t(all.ng0);  // the batch is entered "out"
+        A.pre[A.n_genes] = int32_t(all.ann);
+    }
     if (L.cnt <= 0) return;
-    const SegE B = A.block[blockIdx.x], X = A.lane[blockIdx.x * kT + threadIdx.x];
+    const SegE X = A.lane[blockIdx.x * kT + threadIdx.x];
     const uint32_t sb = B.map & 1u;  // the batch is entered "out": evaluate every map at 0
     uint32_t st = (X.map >> sb) & 1u;
     uint32_t ng = B.ng0 + (sb ? X.ng1 : X.ng0);
@@ -266,69 +268,67 @@ __global__ void __launch_bounds__(kT) seg_validate(const SegArgs A) {
     }
 }
 
-__global__ void __launch_bounds__(kTopThreads) seg_kept_top(const SegArgs A) {
-    __shared__ U2 lds[kTopThreads / 64];
-    const int n_raw = *A.n_raw;
-    const int ntile = (n_raw + kT - 1) / kT;
-    U2 carry{0u, 0u};
-    for (int base = 0; base < ntile; base += kTopThreads) {
-        const int i = base + threadIdx.x;
-        const int2 v = i < ntile ? A.tile[i] : make_int2(0, 0);
-        U2 total;
-        const U2 excl = block_scan_exclusive<AddOp, false, U2, kTopThreads>(U2{uint32_t(v.x), uint32_t(v.y)}, lds, &total);
-        if (i < ntile) A.tile[i] = make_int2(int(carry.x + excl.x), int(carry.y + excl.y));
-        carry = AddOp::combine(carry, total);
-    }
-    if (threadIdx.x == 0) {
-        *A.total = int32_t(carry.x);
-        if (A.seg_off && int(carry.x) <= A.max_seg) A.seg_off[carry.x] = int32_t(carry.y);
-    }
-}
-
+// Ordered compaction of the kept rows.  A workgroup takes tiles t, t + G, ...; (rows, genes) kept in the tiles before
+// a tile are summed by every wave for itself (64 tiles per step), carried from the workgroup's previous tile.  Kept rows go
+// to A.seg, their gene offsets to A.seg_off; with A.gout the probabilities of a row's genes follow row after row (a wave
+// copies the rows of its 64 lanes one after the other, coalesced).  The batch driver points all three at pinned HOST memory:
+// everything is read from device memory and only written across PCIe (posted writes).
 __global__ void __launch_bounds__(kT) seg_compact(const SegArgs A) {
     __shared__ U2 lds[kT / 64];
     const int n_raw = *A.n_raw;
     const int ntile = (n_raw + kT - 1) / kT;
+    const int lane = threadIdx.x & 63;
+    auto range_sum = [&](int t0, int t1) {  // sum of tile[t0 .. t1)
+        uint32_t x = 0, y = 0;
+        for (int base = t0; base < t1; base += 64) {
+            const int2 v = base + lane < t1 ? A.tile[base + lane] : make_int2(0, 0);
+            x += uint32_t(v.x);
+            y += uint32_t(v.y);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            x += uint32_t(__shfl_xor(int(x), o));
+            y += uint32_t(__shfl_xor(int(y), o));
+        }
+        return U2{x, y};
+    };
+    if (blockIdx.x == 0 && ntile == 0 && threadIdx.x == 0) {
+        *A.total = 0;
+        if (A.seg_off) A.seg_off[0] = 0;
+    }
+    U2 before{0u, 0u};
+    int done = 0;  // tiles [0, done) are in `before`
     for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        before = AddOp::combine(before, range_sum(done, t));
         const int i = t * kT + threadIdx.x;
         int4 v = make_int4(-1, 0, 0, 0);
         if (i < n_raw) v = A.val[i];
         const bool kept = v.x >= 0;
         U2 total;
         const U2 excl = block_scan_exclusive<AddOp, false>(U2{kept ? 1u : 0u, kept ? uint32_t(v.w - v.z) : 0u}, lds, &total);
-        if (kept) {
-            const int2 base = A.tile[t];
-            const int o = base.x + int(excl.x);
-            if (o < A.max_seg) {
-                reinterpret_cast<int4 *>(A.seg)[o] = v;
-                if (A.seg_off) A.seg_off[o] = base.y + int(excl.y);
+        const int o = int(before.x + excl.x), off = int(before.y + excl.y);
+        const bool write = kept && o < A.max_seg;
+        if (write) {
+            reinterpret_cast<int4 *>(A.seg)[o] = v;
+            if (A.seg_off) A.seg_off[o] = off;
+        }
+        if (A.gout) {
+            unsigned long long m = __builtin_amdgcn_ballot_w64(write);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const int a = __builtin_amdgcn_readlane(v.z, src), b = __builtin_amdgcn_readlane(v.w, src),
+                          ro = __builtin_amdgcn_readlane(off, src);
+                for (int k = lane; k < b - a; k += 64)
+                    if (ro + k < A.gcap) A.gout[ro + k] = A.p[a + k];
             }
         }
-    }
-}
-
-// Probabilities of the genes of the kept rows, row after row (what cluster tables need of p), plus -- when the export
-// pointers are given -- the rows, their offsets and their number themselves.  The batch driver points `out` and the
-// export arrays at pinned HOST memory: everything is read from device memory and only written across PCIe (posted
-// writes).  (With the segmenter writing its rows straight into host memory this kernel READ them back from there, three
-// dependent PCIe round trips per row: 62 us per 1 M-gene chunk against 22 us for the window kernel.)
-__global__ void __launch_bounds__(kT) seg_gather(const double *__restrict__ p, const int32_t *__restrict__ seg,
-                                                 const int32_t *__restrict__ seg_off, const int32_t *__restrict__ total,
-                                                 int max_seg, double *__restrict__ out, int cap, int32_t *__restrict__ x_seg,
-                                                 int32_t *__restrict__ x_off, int32_t *__restrict__ x_total) {
-    const int n_all = *total, n = min(n_all, max_seg);
-    const int lane = threadIdx.x & 63, wave = (blockIdx.x * kT + threadIdx.x) >> 6, nwaves = (gridDim.x * kT) >> 6;
-    if (x_total) {
-        const int t = blockIdx.x * kT + threadIdx.x, nt = gridDim.x * kT;
-        if (t == 0) *x_total = n_all;
-        for (int i = t; i < 4 * n; i += nt) x_seg[i] = seg[i];
-        for (int i = t; i <= n; i += nt) x_off[i] = seg_off[i];
-    }
-    if (!out) return;
-    for (int r = wave; r < n; r += nwaves) {
-        const int a = seg[4 * r + 2], b = seg[4 * r + 3], off = seg_off[r];
-        for (int k = lane; k < b - a; k += 64)
-            if (off + k < cap) out[off + k] = p[a + k];
+        before = AddOp::combine(before, total);  // (total = this tile's own sums: tile[t])
+        done = t + 1;
+        if (t == ntile - 1 && threadIdx.x == 0) {
+            *A.total = int32_t(before.x);
+            if (A.seg_off && int(before.x) <= A.max_seg) A.seg_off[before.x] = int32_t(before.y);
+        }
     }
 }
 
@@ -353,7 +353,7 @@ size_t segment_workspace_bytes(int n_genes, int n_contigs) {
 // beyond are not written).
 hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t *d_flags, const int32_t *d_cptr,
                           int n_genes, int n_contigs, const SegParams &params, int32_t *d_seg, int max_seg,
-                          int32_t *d_seg_off, int32_t *d_total, void *d_work, hipStream_t stream) {
+                          int32_t *d_seg_off, int32_t *d_total, void *d_work, hipStream_t stream, double *d_gather, int gather_cap) {
     if (n_contigs <= 0 || n_genes <= 0) {
         if (d_seg_off) (void)hipMemsetAsync(d_seg_off, 0, 4, stream);
         return hipMemsetAsync(d_total, 0, 4, stream);
@@ -395,6 +395,8 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
     a.max_seg = max_seg;
     a.seg_off = d_seg_off;
     a.total = d_total;
+    a.gout = d_seg_off ? d_gather : nullptr;  // (the rows' probabilities are laid out by the rows' gene offsets)
+    a.gcap = gather_cap;
     if (!d_flags) {
         hipError_t e = hipMemsetAsync(own_flags, 0, n + 8, stream);
         if (e != hipSuccess) return e;
@@ -404,10 +406,8 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
     a.flags = d_flags;
     const int tiles_cap = int(std::min<size_t>(cap / kT + 1, 2048));
     hipLaunchKernelGGL(seg_fold, dim3(nb), dim3(kT), 0, stream, a);
-    hipLaunchKernelGGL(seg_top, dim3(1), dim3(kTopThreads), 0, stream, a, int(nb));
     hipLaunchKernelGGL(seg_replay, dim3(nb), dim3(kT), 0, stream, a);
     hipLaunchKernelGGL(seg_validate, dim3(tiles_cap), dim3(kT), 0, stream, a);
-    hipLaunchKernelGGL(seg_kept_top, dim3(1), dim3(kTopThreads), 0, stream, a);
     hipLaunchKernelGGL(seg_compact, dim3(tiles_cap), dim3(kT), 0, stream, a);
     return hipGetLastError();
 }
@@ -494,14 +494,6 @@ hipError_t launch_degree_to_row_ptr(const uint8_t *d_deg, int n, int32_t base, i
     hipLaunchKernelGGL(deg_block_sums, dim3(nb), dim3(kDegT), 0, stream, d_deg, n, d_scratch);
     hipLaunchKernelGGL(deg_scan_sums, dim3(1), dim3(kDegT), 0, stream, d_scratch, nb);
     hipLaunchKernelGGL(deg_row_ptr, dim3(nb), dim3(kDegT), 0, stream, d_deg, n, d_scratch, base, d_row_ptr);
-    return hipGetLastError();
-}
-
-hipError_t launch_segment_gather(const double *d_p, const int32_t *d_seg, const int32_t *d_seg_off, const int32_t *d_total,
-                                 int max_seg, double *d_out, int cap, hipStream_t stream, int32_t *x_seg, int32_t *x_off,
-                                 int32_t *x_total) {
-    hipLaunchKernelGGL(seg_gather, dim3(64), dim3(kT), 0, stream, d_p, d_seg, d_seg_off, d_total, max_seg, d_out, cap, x_seg, x_off,
-                       x_total);
     return hipGetLastError();
 }
 

@@ -223,25 +223,22 @@ __device__ __forceinline__ FE lookahead_suffix(const FE *__restrict__ totals, in
 // C3; this arrangement is the windowed kernel's stage 1 and takes about half.)
 // MODE 0: d = s[1] - s[0];  1: d and max(s[0], s[1]);  2: the pair (s[0], s[1]).
 constexpr int kStateGenes = 512, kStatePark = 1024;
-template <int MODE>
-__global__ void __launch_bounds__(kT) seq_state_blocks(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
-                                                        const double2 *__restrict__ wtab01, int n_attrs, int n_genes,
-                                                        double *__restrict__ out_d, double *__restrict__ out_m,
-                                                        double2 *__restrict__ out_s) {
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    __shared__ f64x2 park[kStatePark];
-    constexpr int GPLS = kStateGenes / kT;  // genes per lane, strided by the workgroup size (coalesced row pointers and outputs)
-    constexpr int APL = kStatePark / kT;
+typedef double st_f64x2 __attribute__((ext_vector_type(2)));
+typedef int st_i32x4 __attribute__((ext_vector_type(4)));
+// the sums of genes [g_first, g_end) of one workgroup: lane `tid` owns genes g_first + k kT + tid (coalesced row pointers
+// and outputs), PARK weight pairs are parked at a time
+template <int GPLS, int PARK>
+__device__ __forceinline__ void block_state_sums(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
+                                                 const double2 *__restrict__ wtab01, int n_attrs, int g_first, int g_end,
+                                                 st_f64x2 *park, double (&s0)[GPLS], double (&s1)[GPLS]) {
+    constexpr int APL = PARK / kT;
     const int tid = threadIdx.x;
-    const int g_first = blockIdx.x * kStateGenes, g_end = min(g_first + kStateGenes, n_genes);
     const uint32_t lo_tile = uint32_t(gene_ptr[g_first]), hi_tile = uint32_t(gene_ptr[g_end]);
     const uint32_t n_run = hi_tile - lo_tile;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(attr_id + lo_tile), 0, n_run << 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(wtab01), 0, uint32_t(n_attrs) << 4, 0x00020000);
     uint32_t lo[GPLS], hi[GPLS];
-    double s0[GPLS], s1[GPLS];
 #pragma unroll
     for (int k = 0; k < GPLS; ++k) {
         const int g = g_first + k * kT + tid;
@@ -253,30 +250,42 @@ __global__ void __launch_bounds__(kT) seq_state_blocks(const int32_t *__restrict
         s0[k] = s1[k] = 0.0;
     }
 #pragma unroll 1
-    for (uint32_t base = 0; base < n_run; base += kStatePark) {
+    for (uint32_t base = 0; base < n_run; base += PARK) {
         int id[APL];
 #pragma unroll
         for (int a = 0; a < APL; ++a) id[a] = __builtin_amdgcn_raw_buffer_load_b32(ra, int((base + a * kT + tid) << 2), 0, 0);
-        i32x4 w[APL];
+        st_i32x4 w[APL];
 #pragma unroll
         for (int a = 0; a < APL; ++a)  // ids outside the dictionary land outside the table and read (+0.0, +0.0)
             w[a] = __builtin_amdgcn_raw_buffer_load_b128(rw, int(min(uint32_t(id[a]), 0x0FFFFFFFu) << 4), 0, 0);
 #pragma unroll
-        for (int a = 0; a < APL; ++a) park[a * kT + tid] = f64x2{__hiloint2double(w[a].y, w[a].x), __hiloint2double(w[a].w, w[a].z)};
+        for (int a = 0; a < APL; ++a) park[a * kT + tid] = st_f64x2{__hiloint2double(w[a].y, w[a].x), __hiloint2double(w[a].w, w[a].z)};
         __syncthreads();
-        const uint32_t c0 = lo_tile + base, c1 = c0 + kStatePark;
+        const uint32_t c0 = lo_tile + base, c1 = c0 + PARK;
 #pragma unroll
         for (int k = 0; k < GPLS; ++k) {
             uint32_t q = max(lo[k], c0) - c0;
             const uint32_t e = min(hi[k], c1) - c0;
             for (; q < e && hi[k] > c0; ++q) {
-                const f64x2 v = park[q];
+                const st_f64x2 v = park[q];
                 s0[k] += v.x;
                 s1[k] += v.y;
             }
         }
-        if (base + kStatePark < n_run) __syncthreads();
+        if (base + PARK < n_run) __syncthreads();
     }
+}
+template <int MODE>
+__global__ void __launch_bounds__(kT) seq_state_blocks(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
+                                                        const double2 *__restrict__ wtab01, int n_attrs, int n_genes,
+                                                        double *__restrict__ out_d, double *__restrict__ out_m,
+                                                        double2 *__restrict__ out_s) {
+    __shared__ st_f64x2 park[kStatePark];
+    constexpr int GPLS = kStateGenes / kT;
+    const int tid = threadIdx.x;
+    const int g_first = blockIdx.x * kStateGenes, g_end = min(g_first + kStateGenes, n_genes);
+    double s0[GPLS], s1[GPLS];
+    block_state_sums<GPLS, kStatePark>(gene_ptr, attr_id, wtab01, n_attrs, g_first, g_end, park, s0, s1);
 #pragma unroll
     for (int k = 0; k < GPLS; ++k) {
         const int g = g_first + k * kT + tid;
@@ -869,18 +878,55 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     const int g0 = FLAT ? int(blockIdx.x) * kBlockGenes : A.cblk[blockIdx.x];
     const int n = FLAT ? min(kBlockGenes, A.n_genes - g0) : A.cblk[blockIdx.x + 1] - g0;
     constexpr bool want_z = WANT_Z;
+    if constexpr (MODE == 1) {
+        // the flat layout's first launch sums the state scores of its 2 048 genes itself (attribute per lane, the weight
+        // pairs parked over the stage, 2 048 at a time) and leaves s[1] - s[0] (and the maxima) for the second launch:
+        // the separate state kernel, its 8 (16) B/gene round trip and a kernel boundary are gone
+        static_assert(sizeof(stg.st) >= 2048 * sizeof(st_f64x2), "parking area");
+        double s0[kGPL], s1[kGPL];
+        block_state_sums<kGPL, 2048>(A.csr_gene_ptr, A.csr_attr_id, A.csr_wtab01, A.csr_n_attrs, g0, g0 + n,
+                                     reinterpret_cast<st_f64x2 *>(stg.st), s0, s1);
+        __syncthreads();  // (every lane has summed its runs: the stage takes the differences)
 #pragma unroll
-    for (int j = 0; j < kGPL; ++j) {
-        const int idx = j * kT + slot;
-        const bool ok = idx < n;
-        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] =
-            make_double2(ok ? A.dstate[g0 + idx] : 0.0, (ok && want_z) ? A.smax[g0 + idx] : 0.0);
+        for (int j = 0; j < kGPL; ++j) {
+            const int idx = j * kT + slot;
+            const bool ok = idx < n;
+            const double d = s1[j] - s0[j], m = fmax(s0[j], s1[j]);
+            if (ok) {
+                const_cast<double *>(A.dstate)[g0 + idx] = d;
+                if (want_z) const_cast<double *>(A.smax)[g0 + idx] = m;
+            }
+            stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = make_double2(ok ? d : 0.0, (ok && want_z) ? m : 0.0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kGPL; ++j) {
+            const int idx = j * kT + slot;
+            const bool ok = idx < n;
+            stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] =
+                make_double2(ok ? A.dstate[g0 + idx] : 0.0, (ok && want_z) ? A.smax[g0 + idx] : 0.0);
+        }
     }
     const int cnt = min(kGPL, n - slot * kGPL);
     // which of the lane's genes start / end a contig (host-packed; positions past the last gene: one-gene contigs)
     const uint32_t bits = FLAT ? A.flat_bits[blockIdx.x * kT + slot] : A.lane_bits[blockIdx.x * kT + slot];
     // flat layout: the gene behind the workgroup's last one (its emission enters the last lane's backward step)
-    const double d_next_block = (FLAT && g0 + kBlockGenes < A.n_genes) ? A.dstate[g0 + kBlockGenes] : 0.0;
+    double d_next_block = 0.0;
+    if (FLAT && g0 + kBlockGenes < A.n_genes) {
+        if constexpr (MODE == 1) {  // (the next workgroup's first gene: not summed by anybody yet -- one lane's worth of attributes)
+            const int g = g0 + kBlockGenes;
+            double t0 = 0.0, t1 = 0.0;
+            for (int q = A.csr_gene_ptr[g]; q < A.csr_gene_ptr[g + 1]; ++q) {
+                const int a = A.csr_attr_id[q];
+                const double2 w = unsigned(a) < unsigned(A.csr_n_attrs) ? A.csr_wtab01[a] : make_double2(0.0, 0.0);
+                t0 += w.x;
+                t1 += w.y;
+            }
+            d_next_block = t1 - t0;
+        } else {
+            d_next_block = A.dstate[g0 + kBlockGenes];
+        }
+    }
     __syncthreads();
     // the emission pair of every gene the lane touches (its own 8 and its right neighbour's first): ONE exp per gene,
     // used by the forward fold, the forward replay, the backward fold and the backward replay
@@ -1115,7 +1161,9 @@ hipError_t launch_seq_marginals_short(const SeqArgs &a, const int32_t *gene_ptr,
                                       int n_attrs, const int32_t *d_contig_ptr, hipStream_t stream) {
     if (a.n_contigs <= 0) return hipSuccess;
     if (a.n_genes > 0) {
-        if (a.lognorm)
+        if (!a.short_contigs) {
+            // contigs of any length, flat layout: the first launch sums the state scores itself
+        } else if (a.lognorm)
             hipLaunchKernelGGL(seq_state_blocks<1>, grid_for(a.n_genes, kStateGenes), dim3(kT), 0, stream, gene_ptr, attr_id, wtab01,
                                n_attrs, a.n_genes, const_cast<double *>(a.dstate), const_cast<double *>(a.smax), (double2 *)nullptr);
         else
@@ -1127,14 +1175,19 @@ hipError_t launch_seq_marginals_short(const SeqArgs &a, const int32_t *gene_ptr,
             else
                 hipLaunchKernelGGL((f_short<false, 0>), dim3(a.n_cblocks), dim3(kT), 0, stream, a);
         } else {
-            // contigs of any length, flat layout: the workgroups' products first, then the fused kernel looks them up
+            // contigs of any length, flat layout: state sums + the workgroups' products first, then the fused kernel looks them up
             const dim3 nb((a.n_genes + kBlockGenes - 1) / kBlockGenes);
+            SeqArgs b = a;
+            b.csr_gene_ptr = gene_ptr;
+            b.csr_attr_id = attr_id;
+            b.csr_wtab01 = wtab01;
+            b.csr_n_attrs = n_attrs;
             if (a.lognorm) {
-                hipLaunchKernelGGL((f_short<true, 1>), nb, dim3(kT), 0, stream, a);
-                hipLaunchKernelGGL((f_short<true, 2>), nb, dim3(kT), 0, stream, a);
+                hipLaunchKernelGGL((f_short<true, 1>), nb, dim3(kT), 0, stream, b);
+                hipLaunchKernelGGL((f_short<true, 2>), nb, dim3(kT), 0, stream, b);
             } else {
-                hipLaunchKernelGGL((f_short<false, 1>), nb, dim3(kT), 0, stream, a);
-                hipLaunchKernelGGL((f_short<false, 2>), nb, dim3(kT), 0, stream, a);
+                hipLaunchKernelGGL((f_short<false, 1>), nb, dim3(kT), 0, stream, b);
+                hipLaunchKernelGGL((f_short<false, 2>), nb, dim3(kT), 0, stream, b);
             }
         }
     }

@@ -88,7 +88,8 @@ struct Chunk {
     int32_t device_slot = 0;
     // segment rows of the chunk, translated to batch indices, and the probabilities of their genes
     std::vector<int32_t> rows;
-    std::vector<double> seg_p;
+    std::vector<double> seg_p;   // (only when the caller's seg_p_out is too small to stage the chunk at its gene offset)
+    int64_t seg_p_count = 0;     // probabilities of the chunk's rows, parked at seg_p_out + g0 until the final compaction
 };
 
 // Streams are per DIRECTION, not per chunk: all uploads of a device go through `up`, all kernels through
@@ -454,12 +455,8 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
         ln.o_p = ln.o_rows + align256(cap * 16);
         const size_t bytes = ln.o_p + (r.seg_p_out ? size_t(ng) * 8 : 0) + 256;
         if ((rc = ln.h_seg.reserve(bytes, "hipHostMalloc segments"))) return rc;
-        // the segmenter works in device memory; one last kernel exports rows, offsets, count and the rows'
-        // probabilities into the pinned block (written across PCIe, never read back across it)
-        const size_t v_off = 256, v_rows = v_off + align256((cap + 1) * 4);
-        if ((rc = ln.d_seg.reserve(v_rows + align256(cap * 16), "hipMalloc segments"))) return rc;
-        int32_t *v_total = reinterpret_cast<int32_t *>(ln.d_seg.p), *v_offp = reinterpret_cast<int32_t *>(ln.d_seg.p + v_off),
-                *v_rowsp = reinterpret_cast<int32_t *>(ln.d_seg.p + v_rows);
+        // the segmenter's last launch writes rows, offsets, count and the rows' probabilities straight into the pinned block
+        // (written across PCIe, never read back across it)
         char *dp = ln.h_seg.dp;
         int32_t *d_total = reinterpret_cast<int32_t *>(dp), *d_off = reinterpret_cast<int32_t *>(dp + ln.o_off),
                 *d_rows = reinterpret_cast<int32_t *>(dp + ln.o_rows);
@@ -470,12 +467,8 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
             sp.bio_ptr = reinterpret_cast<const int32_t *>(ln.d_bp.p);
             sp.bio_id = reinterpret_cast<const int32_t *>(ln.d_bi.p) - b0;
         }
-        if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(ln.d_ann.p), sp, v_rowsp, int32_t(cap), v_offp, v_total,
-                                   ln.comp)))
-            return rc;
-        if ((rc = check_hip(launch_segment_gather(d_p, v_rowsp, v_offp, v_total, int32_t(cap),
-                                                  r.seg_p_out ? reinterpret_cast<double *>(dp + ln.o_p) : nullptr, ng, ln.comp, d_rows,
-                                                  d_off, d_total), "segment gather launch")))
+        if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(ln.d_ann.p), sp, d_rows, int32_t(cap), d_off, d_total,
+                                   ln.comp, r.seg_p_out ? reinterpret_cast<double *>(dp + ln.o_p) : nullptr, ng)))
             return rc;
     }
     tm.lap("launch", chunk_index);
@@ -523,8 +516,15 @@ int retire(RunCtx &X, Lane &ln) {
             ck.rows[4 * size_t(i) + 3] = rows[4 * i + 3] + ck.g0;
         }
         if (X.r.seg_p_out) {
+            // the rows' probabilities leave the pinned block ONCE: straight into the caller's array at the chunk's gene offset
+            // (never behind their final place: the chunks before hold at least as many genes as their rows do), closed up at
+            // the end of the call -- under SURVEY.md 8d's weight law nine genes in ten lie in a cluster, 14 MB per C3 batch
             const double *sp = reinterpret_cast<const double *>(hp + ln.o_p);
-            ck.seg_p.assign(sp, sp + off[total]);
+            ck.seg_p_count = off[total];
+            if (X.r.max_seg_genes >= int64_t(ck.g0) + ck.seg_p_count)
+                std::memcpy(X.r.seg_p_out + ck.g0, sp, size_t(ck.seg_p_count) * 8);
+            else
+                ck.seg_p.assign(sp, sp + off[total]);
         }
     }
     return GECCO_CRF_OK;
@@ -654,16 +654,16 @@ int session_run(Session &S, const BatchRequest &r) {
             const int64_t k = int64_t(ck.rows.size() / 4);
             if (k) std::memcpy(r.seg_out + 4 * row, ck.rows.data(), size_t(k) * 16);
             if (r.seg_p_out) {
-                size_t at = 0;
+                if (genes + ck.seg_p_count > r.max_seg_genes) {
+                    set_error("segments: seg_p_out too small");
+                    return GECCO_CRF_EINVAL;
+                }
+                if (!ck.seg_p.empty())
+                    std::memcpy(r.seg_p_out + genes, ck.seg_p.data(), size_t(ck.seg_p_count) * 8);
+                else if (genes != ck.g0 && ck.seg_p_count)
+                    std::memmove(r.seg_p_out + genes, r.seg_p_out + ck.g0, size_t(ck.seg_p_count) * 8);
                 for (int64_t i = 0; i < k; ++i) {
-                    const int64_t len = ck.rows[4 * size_t(i) + 3] - ck.rows[4 * size_t(i) + 2];
-                    if (genes + len > r.max_seg_genes) {
-                        set_error("segments: seg_p_out too small");
-                        return GECCO_CRF_EINVAL;
-                    }
-                    std::memcpy(r.seg_p_out + genes, ck.seg_p.data() + at, size_t(len) * 8);
-                    at += size_t(len);
-                    genes += len;
+                    genes += ck.rows[4 * size_t(i) + 3] - ck.rows[4 * size_t(i) + 2];
                     r.seg_off_out[row + i + 1] = genes;
                 }
             }

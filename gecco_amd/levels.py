@@ -11,12 +11,15 @@ from . import _native as nat
 
 
 def _timed(fn, reps):
+    """median seconds per call (a single hiccup of the box -- a few ms -- would otherwise be a fifth of a five-call mean)"""
     fn()
     fn()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    ts = []
+    for _ in range(max(reps, 3)):
+        t0 = time.perf_counter()
         fn()
-    return (time.perf_counter() - t0) / reps
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
 
 
 def host_buffer_levels(model, wl, devices=(0,), reps=5, W=20):
@@ -49,10 +52,17 @@ def host_buffer_levels(model, wl, devices=(0,), reps=5, W=20):
                                     "pinned buffers in and out; one pipelined launch per chunk (window tiles + the Viterbi workgroups "
                                     "of the chunk before), a flush at the end"}
     ann = nat.pinned_copy((np.diff(wl["gene_ptr"]) > 0).astype(np.uint8))
-    dt = _timed(lambda: ses.clusters(cp, gp, at, ann, W, want_p=False, want_seg_p=True), reps)
-    seg = ses.clusters(cp, gp, at, ann, W, want_p=False, want_seg_p=True)[0]
-    out["cluster_calls_pinned"] = {"ms": dt * 1e3, "genes_per_s": n / dt, "clusters": int(len(seg)),
-                                   "note": "marginals + refiner on the device; only rows and their probabilities come back"}
+    dt = _timed(lambda: ses.clusters(cp, gp, at, ann, W, want_p=False, want_seg_p=False, degree=deg), reps)
+    seg, _, seg_off, _ = ses.clusters(cp, gp, at, ann, W, want_p=False, want_seg_p=True, degree=deg)
+    out["cluster_calls_pinned"] = {"ms": dt * 1e3, "genes_per_s": n / dt, "clusters": int(len(seg)), "genes_in_clusters": int(seg_off[-1]),
+                                   "h2d_mb": ses.stats()["h2d_bytes"] / 1e6,
+                                   "note": "marginals + refiner on the device, degree bytes on the wire (gecco_crf_session_clusters_degrees); "
+                                           "only the cluster rows come back"}
+    dt = _timed(lambda: ses.clusters(cp, gp, at, ann, W, want_p=False, want_seg_p=True, degree=deg), reps)
+    out["cluster_calls_with_probabilities_pinned"] = {
+        "ms": dt * 1e3, "genes_per_s": n / dt, "clusters": int(len(seg)), "genes_in_clusters": int(seg_off[-1]),
+        "note": "the same + the probabilities of the clusters' genes (what a cluster table needs of p), written by the last kernel "
+                "into pinned memory"}
     for v in out.values():
         v["genes"] = n
         v["devices"] = len(devices)

@@ -274,6 +274,14 @@ int gecco_crf_session_clusters_ex(gecco_crf_session *s, const int32_t *contig_pt
                                   const gecco_crf_refine_params *params, double *p_out, int32_t *seg_out,
                                   int32_t max_seg, int32_t *n_seg, double *seg_p_out, int64_t max_seg_genes,
                                   int64_t *seg_off_out);
+/* gecco_crf_session_clusters_ex with the degree-byte wire format of gecco_crf_session_windowed_degrees: `degree` crosses
+ * PCIe instead of the row pointers.  Same rows, same probabilities. */
+int gecco_crf_session_clusters_degrees(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                       const int32_t *gene_ptr, const uint8_t *degree, const int32_t *attr_id,
+                                       const uint8_t *annotated, int32_t window, int32_t step, int32_t label, int32_t pad,
+                                       const gecco_crf_refine_params *params, double *p_out, int32_t *seg_out,
+                                       int32_t max_seg, int32_t *n_seg, double *seg_p_out, int64_t max_seg_genes,
+                                       int64_t *seg_off_out);
 
 /* ---- columnar host side: table columns -> CSR batch, called clusters -> clusters.tsv rows --------
  * Strings travel as Arrow-style columns: one byte buffer + int64 offsets[n+1] per column (what

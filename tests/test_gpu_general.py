@@ -142,6 +142,38 @@ def test_lane_per_window_kernel(nat, L, monkeypatch):
         assert np.abs(got[ok] - other[ok]).max() <= 1e-12, (L, W, step, pad, label)
 
 
+@pytest.mark.parametrize("L", [9, 12, 13, 16, 17, 20, 24, 25, 29, 32])
+def test_matrix_core_window_kernel(nat, L, monkeypatch):
+    """9 to 32 labels take `gl_windowed_mfma`: sixteen windows per wave as v_mfma_f64_16x16x4_f64 products (labels x
+    windows), alpha / beta in the result registers from step to step, the maximum over the covering windows by LDS atomics.
+    Every number of K-slices (3 to 8) and both tile counts, every queried label at L = 13, windows from 1 to 32 genes,
+    steps, unpadded short contigs (skipped: irregular tiles), against the oracle (1e-12: the summation order of a step
+    differs from CRFsuite's) and against the lane-group kernel (GECCO_CRF_GENERAL_GROUPS=1)."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(1700 + L)
+    A = 200
+    w, trans = synth_model(A, rng, L=L)
+    lengths = LENGTHS + list(rng.integers(1, 60, size=40)) + [237, 238, 474, 475, 3000] + list(rng.integers(1, 400, size=30))
+    cptr, gptr, attr = synth_contigs(rng, lengths, A)
+    model = nat.Model.from_tables(w, trans)
+    assert nat.Plan(model, cptr, 20, 1, True, device=0).kernel_name == "gl_windowed_mfma"
+    labels = range(L) if L == 13 else (0, L // 2, L - 1)
+    cases = [(20, 1, True, lab) for lab in labels] + [(1, 1, True, 0), (2, 1, True, 1), (20, 7, True, 1), (20, 1, False, 0),
+                                                       (5, 4, False, 1), (21, 1, True, 2), (32, 1, True, L - 1), (32, 5, False, 2)]
+    for W, step, pad, label in cases:
+        got = model.windowed_marginals(cptr, gptr, attr, W, step, label, pad)
+        exp = orc.windowed_marginals(w, trans, cptr, gptr, attr, W, step, label, pad)
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.abs(got[ok] - exp[ok]).max() <= 1e-12, (L, W, step, pad, label)
+    monkeypatch.setenv("GECCO_CRF_GENERAL_GROUPS", "1")
+    other = model.windowed_marginals(cptr, gptr, attr, 20, 1, 0, True)
+    monkeypatch.delenv("GECCO_CRF_GENERAL_GROUPS")
+    got = model.windowed_marginals(cptr, gptr, attr, 20, 1, 0, True)
+    assert np.abs(got - other).max() <= 1e-12
+
+
 def test_lane_per_window_kernel_range_guard(nat):
     """Its recurrences are un-normalised: transition weights whose spread times W - 1 stays under 600 keep every value
     in range (checked at the limit, with state weights as extreme as CRFsuite models get); beyond, the scaled kernel."""

@@ -302,5 +302,17 @@ def test_degree_byte_wire_format_equals_row_pointers(nat, real_model, oracle_mod
             out = nat.pinned_empty(n, np.float64)
             c = ses.windowed_marginals(cp, gp, at, 20, out=out, degree=dg)
             assert np.array_equal(a, c, equal_nan=True)
+            # cluster calls take the same wire format (gecco_crf_session_clusters_degrees): same rows, same probabilities
+            ann = (np.diff(gptr) > 0).astype(np.uint8)
+            thr = _threshold(a) if n > 100 else 0.5
+            r0 = ses.clusters(cptr, gptr, attr, ann, 20, threshold=thr)
+            r1 = ses.clusters(cptr, gptr, attr, ann, 20, threshold=thr, degree=deg)
+            assert r0[0].tolist() == r1[0].tolist() and np.array_equal(r0[1], r1[1]) and np.array_equal(r0[2], r1[2])
     with pytest.raises(ValueError):
         nat.degree_bytes(np.array([0, 300], dtype=np.int32))
+    # degree bytes that do not add up to the row pointers are refused (the device would read attributes out of bounds)
+    cptr, gptr, attr = synth_contigs(rng, [300, 200], A)
+    bad = nat.degree_bytes(gptr)
+    bad[17] += 1
+    with pytest.raises(ValueError, match="degree"):
+        ses.windowed_marginals(cptr, gptr, attr, 20, degree=bad)

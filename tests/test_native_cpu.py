@@ -120,8 +120,13 @@ def test_host_only_plan_dispatch_by_label_count(blob, monkeypatch):
     m8 = nat.Model.from_tables(rng.normal(size=(9, 8)), rng.normal(size=(8, 8)))  # ... up to 8 labels at windows of up to 20
     assert nat.Plan(m8, [0, 50], 20, device=-1).kernel_name == "gl_windowed_small"
     assert nat.Plan(m8, [0, 50], 21, device=-1).kernel_name == "gl_windowed"
+    # 9 to 32 labels: sixteen windows per wave on the fp64 matrix cores, same tiles, windows of up to 32 genes
     m9 = nat.Model.from_tables(rng.normal(size=(9, 9)), rng.normal(size=(9, 9)))
-    assert nat.Plan(m9, [0, 50], 20, device=-1).kernel_name == "gl_windowed"
+    p9 = nat.Plan(m9, [0, 5000], 20, device=-1)
+    assert p9.kernel_name == "gl_windowed_mfma" and p9.num_tiles == -(-5000 // (256 - 19))
+    m32 = nat.Model.from_tables(rng.normal(size=(9, 32)), rng.normal(size=(32, 32)))
+    assert nat.Plan(m32, [0, 50], 32, device=-1).kernel_name == "gl_windowed_mfma"
+    assert nat.Plan(m32, [0, 50], 33, device=-1).kernel_name == "gl_windowed"
     monkeypatch.setenv("GECCO_CRF_GENERAL_GROUPS", "1")
     assert nat.Plan(m3, [0, 50], 20, device=-1).kernel_name == "gl_windowed"
     monkeypatch.delenv("GECCO_CRF_GENERAL_GROUPS")
