@@ -730,9 +730,13 @@ class Session:
         `want_p` / `p_out`.  Returns (seg rows (k, 4), seg_p, seg_off, p or None): `seg_p[seg_off[i]:seg_off[i+1]]`
         are the probabilities of the genes of row i.  `degree` (uint8, = diff(gene_ptr)): the degree-byte wire format."""
         contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
-        annotated = np.ascontiguousarray(annotated, dtype=np.uint8)
-        if annotated.size == 0:
-            annotated = np.zeros(1, dtype=np.uint8)
+        if annotated is None:  # (with `degree`: annotated iff the gene has a domain the model knows)
+            if degree is None:
+                raise ValueError("clusters: `annotated` may only be left out together with `degree`")
+        else:
+            annotated = np.ascontiguousarray(annotated, dtype=np.uint8)
+            if annotated.size == 0:
+                annotated = np.zeros(1, dtype=np.uint8)
         if p_out is None and want_p:
             p_out = np.empty(max(n, 1), dtype=np.float64)
         cap = min(n, n // 2 + nc) + 1
@@ -747,7 +751,7 @@ class Session:
             assert degree.dtype == np.uint8 and degree.size >= n
         _check(self._lib.gecco_crf_session_clusters_degrees(
             self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p), _ptr(degree, _c_u8p) if degree is not None else None,
-            _ptr(attr_id, _c_i32p), _ptr(annotated, _c_u8p),
+            _ptr(attr_id, _c_i32p), _ptr(annotated, _c_u8p) if annotated is not None else None,
             int(window), int(step), int(label), int(bool(pad)), ctypes.byref(q),
             _ptr(p_out, _c_f64p) if p_out is not None else None, _ptr(seg, _c_i32p), cap, ctypes.byref(n_seg),
             _ptr(seg_p, _c_f64p) if want_seg_p else None, max(n, 1), seg_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))

@@ -1116,8 +1116,9 @@ int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, con
         set_error("the antismash criterion needs the genes' marker domains");
         return GECCO_CRF_EINVAL;
     }
-    int rc = plan_ensure_seq(p, stream, !p.async_tables);
-    if (rc) return rc;
+    // the contig flags of the whole-contig tables when the plan has them; otherwise the segmenter derives them from the
+    // contig table on the device (a memset and a launch over the contigs instead of an upload of a byte per gene)
+    int rc = GECCO_CRF_OK;
     if (p.n_genes > 0 && (!d_p || !d_annotated)) {
         set_error("null device buffer");
         return GECCO_CRF_EINVAL;
@@ -1127,7 +1128,7 @@ int plan_run_segment(Plan &p, const double *d_p, const uint8_t *d_annotated, con
         if ((rc = grow_ws(p.d_seg_ws, p.seg_ws_cap, segment_workspace_bytes(p.n_genes, p.n_contigs), "hipMalloc segment workspace")))
             return rc;
     }
-    return check_hip(launch_segment(d_p, d_annotated, p.d_seq_flags, p.d_contig_ptr, p.n_genes, p.n_contigs, params, d_seg, max_seg,
+    return check_hip(launch_segment(d_p, d_annotated, p.seq_ready ? p.d_seq_flags : nullptr, p.d_contig_ptr, p.n_genes, p.n_contigs, params, d_seg, max_seg,
                                     d_seg_off, d_total, p.d_seg_ws, stream, d_gather, gather_cap),
                      "segment launch");
 }

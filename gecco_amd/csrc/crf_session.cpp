@@ -345,10 +345,12 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
             return rc;
         S.stats.h2d_bytes += int64_t(nnz * 4);
         if (r.want_segments) {
-            if ((rc = ln.d_ann.reserve(size_t(ng) + 8, "hipMalloc annotated"))) return rc;
-            if ((rc = check_hip(hipMemcpyAsync(ln.d_ann.p, r.annotated + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D annotated")))
-                return rc;
-            S.stats.h2d_bytes += ng;
+            if (r.annotated) {  // (null: a gene is annotated iff it has a domain the model knows -- the degree bytes themselves)
+                if ((rc = ln.d_ann.reserve(size_t(ng) + 8, "hipMalloc annotated"))) return rc;
+                if ((rc = check_hip(hipMemcpyAsync(ln.d_ann.p, r.annotated + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D annotated")))
+                    return rc;
+                S.stats.h2d_bytes += ng;
+            }
             if (r.seg.criterion == 1) {  // the genes' marker domains, offsets kept as the caller's (like gene_ptr)
                 b0 = r.seg.bio_ptr[ck.g0];
                 const int64_t b1 = r.seg.bio_ptr[ck.g1];
@@ -386,7 +388,7 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
         ln.plan.tables_in_host_memory = !always_copy && !r.want_segments && !X.full && !r.score_out;
     }
     if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.up, false))) return rc;
-    if ((X.viterbi || X.full || r.want_segments) && (rc = plan_ensure_seq(ln.plan, ln.up, false))) return rc;
+    if ((X.viterbi || X.full) && (rc = plan_ensure_seq(ln.plan, ln.up, false))) return rc;  // (the refiner builds its contig flags on the device)
     S.stats.host_plan_seconds += now_s() - t0;
     tm.lap("plan_build", chunk_index);
     if ((rc = check_hip(hipEventRecord(ln.ev_up, ln.up), "hipEventRecord"))) return rc;
@@ -467,7 +469,7 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
             sp.bio_ptr = reinterpret_cast<const int32_t *>(ln.d_bp.p);
             sp.bio_id = reinterpret_cast<const int32_t *>(ln.d_bi.p) - b0;
         }
-        if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(ln.d_ann.p), sp, d_rows, int32_t(cap), d_off, d_total,
+        if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(r.annotated ? ln.d_ann.p : ln.d_deg.p), sp, d_rows, int32_t(cap), d_off, d_total,
                                    ln.comp, r.seg_p_out ? reinterpret_cast<double *>(dp + ln.o_p) : nullptr, ng)))
             return rc;
     }
@@ -578,7 +580,7 @@ int session_run(Session &S, const BatchRequest &r) {
             return GECCO_CRF_EINVAL;
         }
     const int64_t n_genes = r.n_contigs ? r.contig_ptr[r.n_contigs] : 0;
-    if (n_genes > 0 && (!r.gene_ptr || (r.want_segments && !r.annotated))) {
+    if (n_genes > 0 && (!r.gene_ptr || (r.want_segments && !r.annotated && !r.degree))) {  // (annotated may be left to the degree bytes)
         set_error("null buffer");
         return GECCO_CRF_EINVAL;
     }

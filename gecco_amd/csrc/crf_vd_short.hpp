@@ -1,6 +1,7 @@
 // The one-launch Viterbi decoder for batches of short contigs (difference form on 8-byte inputs) as a device function,
 // with CRFsuite's own recursion for the contigs that need it: shared by the kernel `vd_short` (crf_sequence.hip) and
-// the fused decode kernel (crf_kernels.hip), which runs window tiles and Viterbi workgroups in ONE launch.
+// the pipelined decode kernel (crf_kernels.hip: crf_decode_pipelined), which runs the window tiles of a batch and the
+// Viterbi workgroups of the batch before in ONE launch.
 #pragma once
 
 #include "crf_device.hpp"
@@ -242,7 +243,7 @@ constexpr double kVdPad = 1e30;
 // back-to-front label pass all happen in this one kernel with the genes read once (8 B + 1 B per gene) and the
 // labels written once (1 B per gene).  (The previous arrangement -- fixed 2048-gene spans, look-back by
 // recomputation, labels in a second launch over three intermediate arrays -- took 12.5 + 5.0 us on C3.)
-// LDS of one workgroup: 18.4 KB, so that eight of them fit a CU next to nothing else (and the fused decode kernel of
+// LDS of one workgroup: 18.4 KB, so that eight of them fit a CU next to nothing else (and the pipelined decode kernel of
 // crf_kernels.hip, whose window tiles take 19.6 KB, keeps its eight workgroups per CU).  The 9th double of every
 // lane's row is padding against bank conflicts; the approximate pass keeps its marks there (one byte per gene).  The
 // label bytes are staged over the first 2 KB of `st` once nothing reads the values any more.
@@ -266,7 +267,7 @@ __device__ __forceinline__ void load_short(const double *__restrict__ v, int g0,
     __syncthreads();
 }
 
-// workgroup `blk` of the short-contig decoder (kernel vd_short in crf_sequence.hip; the fused decode kernel in
+// workgroup `blk` of the short-contig decoder (kernel vd_short in crf_sequence.hip; the pipelined decode kernel in
 // crf_kernels.hip runs the same body for its Viterbi workgroups)
 __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, VdShortSmem &stg) {
     CE *lds = stg.tot;
@@ -280,7 +281,7 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     load_short(A.dstate, g0, n, stg);
     const int cnt = min(kGPL, n - slot * kGPL);
     // (the lane's values are read from its LDS row in every pass instead of living in 16 VGPRs across the workgroup
-    // scans: the body has to fit the 64 registers of the fused decode kernel)
+    // scans: the body has to fit the 64 registers of the pipelined decode kernel)
     const double *row = stg.st + slot * (kGPL + 1);
     // The lane's eight genes as ONE map x -> min(max(x + a, L), H): applying gene k to the map built so far is
     //   a += c_k;  L = clamp(L, lo, hi) + c_k;  H = clamp(H, lo, hi) + c_k      (c_k = (t11 - t00) + d_k)

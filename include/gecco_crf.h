@@ -275,7 +275,8 @@ int gecco_crf_session_clusters_ex(gecco_crf_session *s, const int32_t *contig_pt
                                   int32_t max_seg, int32_t *n_seg, double *seg_p_out, int64_t max_seg_genes,
                                   int64_t *seg_off_out);
 /* gecco_crf_session_clusters_ex with the degree-byte wire format of gecco_crf_session_windowed_degrees: `degree` crosses
- * PCIe instead of the row pointers.  Same rows, same probabilities. */
+ * PCIe instead of the row pointers.  Same rows, same probabilities.  With `degree`, `annotated` may be NULL: a gene then
+ * counts as annotated iff it carries a domain the model knows (degree > 0), and nothing else is uploaded for it. */
 int gecco_crf_session_clusters_degrees(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
                                        const int32_t *gene_ptr, const uint8_t *degree, const int32_t *attr_id,
                                        const uint8_t *annotated, int32_t window, int32_t step, int32_t label, int32_t pad,

@@ -308,6 +308,9 @@ def test_degree_byte_wire_format_equals_row_pointers(nat, real_model, oracle_mod
             r0 = ses.clusters(cptr, gptr, attr, ann, 20, threshold=thr)
             r1 = ses.clusters(cptr, gptr, attr, ann, 20, threshold=thr, degree=deg)
             assert r0[0].tolist() == r1[0].tolist() and np.array_equal(r0[1], r1[1]) and np.array_equal(r0[2], r1[2])
+            # ... and `annotated` may be left to the degree bytes when it is "has a domain the model knows"
+            r2 = ses.clusters(cptr, gptr, attr, None, 20, threshold=thr, degree=deg)
+            assert r0[0].tolist() == r2[0].tolist() and np.array_equal(r0[1], r2[1])
     with pytest.raises(ValueError):
         nat.degree_bytes(np.array([0, 300], dtype=np.int32))
     # degree bytes that do not add up to the row pointers are refused (the device would read attributes out of bounds)
