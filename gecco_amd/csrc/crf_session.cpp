@@ -103,8 +103,9 @@ struct Lane {
     hipEvent_t ev_up = nullptr, ev_comp = nullptr, done = nullptr;
     int chunk = -1;  // index of the chunk in flight, -1: idle
     Plan plan;
-    DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg, d_deg, d_deg_ws;
-    HostBuf h_seg;  // [total][pad..][seg_off: cap+1][rows: cap*4][p of the rows: n_genes]
+    DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg, d_deg, d_deg_ws, d_segp;
+    HostBuf h_seg;  // [total][pad..][seg_off: cap+1][rows: cap*4]
+    bool segp_in_flight = false;  // the download of the rows' probabilities has been issued (retire_begin), not yet waited for
     int32_t seg_cap = 0;
     size_t o_off = 0, o_rows = 0, o_p = 0;
 };
@@ -139,7 +140,7 @@ Session::~Session() {
         if (hipSetDevice(d->device) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
         for (Lane &ln : d->lanes) {
-            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi, &ln.d_seg, &ln.d_deg, &ln.d_deg_ws}) b->release();
+            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi, &ln.d_seg, &ln.d_deg, &ln.d_deg_ws, &ln.d_segp}) b->release();
             ln.h_seg.release();
             for (hipEvent_t e : {ln.ev_up, ln.ev_comp, ln.done})
                 if (e) (void)hipEventDestroy(e);
@@ -455,10 +456,13 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
         ln.o_off = 256;
         ln.o_rows = ln.o_off + align256((cap + 1) * 4);
         ln.o_p = ln.o_rows + align256(cap * 16);
-        const size_t bytes = ln.o_p + (r.seg_p_out ? size_t(ng) * 8 : 0) + 256;
+        const size_t bytes = ln.o_p + 256;
         if ((rc = ln.h_seg.reserve(bytes, "hipHostMalloc segments"))) return rc;
-        // the segmenter's last launch writes rows, offsets, count and the rows' probabilities straight into the pinned block
-        // (written across PCIe, never read back across it)
+        // the segmenter's last launch writes rows, offsets and count straight into the pinned block (written across PCIe,
+        // never read back across it); the probabilities of the rows' genes -- under SURVEY.md 8d's weight law nine genes in
+        // ten -- are gathered in device memory and downloaded by the copy engine once the host knows how many there are
+        // (read back from the pinned block by the host they came at 4 GB/s: 3.5 ms per C3 batch)
+        if (r.seg_p_out && (rc = ln.d_segp.reserve(size_t(ng) * 8 + 8, "hipMalloc cluster probabilities"))) return rc;
         char *dp = ln.h_seg.dp;
         int32_t *d_total = reinterpret_cast<int32_t *>(dp), *d_off = reinterpret_cast<int32_t *>(dp + ln.o_off),
                 *d_rows = reinterpret_cast<int32_t *>(dp + ln.o_rows);
@@ -470,7 +474,7 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
             sp.bio_id = reinterpret_cast<const int32_t *>(ln.d_bi.p) - b0;
         }
         if ((rc = plan_run_segment(ln.plan, d_p, reinterpret_cast<const uint8_t *>(r.annotated ? ln.d_ann.p : ln.d_deg.p), sp, d_rows, int32_t(cap), d_off, d_total,
-                                   ln.comp, r.seg_p_out ? reinterpret_cast<double *>(dp + ln.o_p) : nullptr, ng)))
+                                   ln.comp, r.seg_p_out ? reinterpret_cast<double *>(ln.d_segp.p) : nullptr, ng)))
             return rc;
     }
     tm.lap("launch", chunk_index);
@@ -493,19 +497,23 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
     return rc;
 }
 
-// wait for the lane's chunk and take its segment rows over (translated to batch indices)
-int retire(RunCtx &X, Lane &ln) {
+// wait for the lane's chunk and take its segment rows over (translated to batch indices); the download of the rows'
+// probabilities is ISSUED here (its size is only known now) and waited for in retire_end
+int retire_begin(RunCtx &X, Lane &ln) {
     if (ln.chunk < 0) return GECCO_CRF_OK;
     TraceMark tm;
     int rc = check_hip(hipEventSynchronize(ln.done), "chunk completion");
     tm.lap("wait", ln.chunk);
     Chunk &ck = X.chunks[ln.chunk];
-    ln.chunk = -1;
-    if (rc) return rc;
+    if (rc) {
+        ln.chunk = -1;
+        return rc;
+    }
     if (X.r.want_segments && ck.g1 > ck.g0) {
         const char *hp = ln.h_seg.p;
         const int32_t total = *reinterpret_cast<const int32_t *>(hp);
         if (total < 0 || total > ln.seg_cap) {
+            ln.chunk = -1;
             set_error("segmenter returned an impossible row count");
             return GECCO_CRF_EHIP;
         }
@@ -518,18 +526,37 @@ int retire(RunCtx &X, Lane &ln) {
             ck.rows[4 * size_t(i) + 3] = rows[4 * i + 3] + ck.g0;
         }
         if (X.r.seg_p_out) {
-            // the rows' probabilities leave the pinned block ONCE: straight into the caller's array at the chunk's gene offset
-            // (never behind their final place: the chunks before hold at least as many genes as their rows do), closed up at
-            // the end of the call -- under SURVEY.md 8d's weight law nine genes in ten lie in a cluster, 14 MB per C3 batch
-            const double *sp = reinterpret_cast<const double *>(hp + ln.o_p);
+            // straight into the caller's array at the chunk's gene offset (never behind their final place: the chunks before
+            // hold at least as many genes as their rows do), closed up at the end of the call
             ck.seg_p_count = off[total];
-            if (X.r.max_seg_genes >= int64_t(ck.g0) + ck.seg_p_count)
-                std::memcpy(X.r.seg_p_out + ck.g0, sp, size_t(ck.seg_p_count) * 8);
-            else
-                ck.seg_p.assign(sp, sp + off[total]);
+            double *dst = X.r.seg_p_out + ck.g0;
+            if (X.r.max_seg_genes < int64_t(ck.g0) + ck.seg_p_count) {  // (a caller array smaller than the batch: staged)
+                ck.seg_p.resize(size_t(ck.seg_p_count));
+                dst = ck.seg_p.data();
+            }
+            if (ck.seg_p_count) {
+                if ((rc = check_hip(hipSetDevice(ln.device), "hipSetDevice"))) return rc;
+                X.S.stats.d2h_bytes += ck.seg_p_count * 8;
+                if ((rc = check_hip(hipMemcpyAsync(dst, ln.d_segp.p, size_t(ck.seg_p_count) * 8, hipMemcpyDeviceToHost, ln.down), "D2H cluster probabilities")))
+                    return rc;
+                if ((rc = check_hip(hipEventRecord(ln.done, ln.down), "hipEventRecord"))) return rc;
+                ln.segp_in_flight = true;
+            }
         }
     }
     return GECCO_CRF_OK;
+}
+int retire_end(RunCtx &X, Lane &ln) {
+    if (ln.chunk < 0) return GECCO_CRF_OK;
+    ln.chunk = -1;
+    if (!ln.segp_in_flight) return GECCO_CRF_OK;
+    ln.segp_in_flight = false;
+    return check_hip(hipEventSynchronize(ln.done), "cluster probabilities");
+}
+int retire(RunCtx &X, Lane &ln) {
+    const int rc = retire_begin(X, ln);
+    const int rc2 = retire_end(X, ln);
+    return rc ? rc : rc2;
 }
 
 }  // namespace
@@ -636,9 +663,20 @@ int session_run(Session &S, const BatchRequest &r) {
             if (rc) {  // the failed submission may have left work behind an unrecorded event
                 if (hipSetDevice(ln.device) == hipSuccess) (void)hipDeviceSynchronize();
                 ln.chunk = -1;
+                ln.segp_in_flight = false;
                 continue;
             }
-            rc = retire(X, ln);
+            rc = retire_begin(X, ln);  // (the downloads of all lanes are issued before any of them is waited for)
+        }
+    for (auto &d : S.devs)
+        for (Lane &ln : d->lanes) {
+            if (rc) {
+                if (hipSetDevice(ln.device) == hipSuccess) (void)hipDeviceSynchronize();
+                ln.chunk = -1;
+                ln.segp_in_flight = false;
+                continue;
+            }
+            rc = retire_end(X, ln);
         }
     if (prev_device >= 0) (void)hipSetDevice(prev_device);
     if (rc) return rc;

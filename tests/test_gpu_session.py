@@ -168,7 +168,10 @@ def test_session_clusters_resident(nat, real_model, oracle_model, chunk, pad, n_
     for (c, num, a, b), o0, o1 in zip(seg.tolist(), seg_off[:-1], seg_off[1:]):
         assert o1 - o0 == b - a
         _same(seg_p[o0:o1], p_exp[a:b])
-    assert ses.stats()["d2h_bytes"] == 0  # the rows arrive through pinned memory written by the kernels
+    # the rows arrive through pinned memory written by the kernels; only the probabilities of THEIR genes are downloaded
+    assert ses.stats()["d2h_bytes"] == 8 * int(seg_off[-1]) < 8 * len(p_exp)
+    ses.clusters(cptr, gptr, attr, ann, 20, 1, 1, pad, thr, n_cds, edge, trim, want_seg_p=False)
+    assert ses.stats()["d2h_bytes"] == 0
     seg2, _, _, p2 = ses.clusters(cptr, gptr, attr, ann, 20, 1, 1, pad, thr, n_cds, edge, trim, want_p=True, want_seg_p=False)
     assert seg2.tolist() == exp.tolist()
     _same(p2, p_exp)
