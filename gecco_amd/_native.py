@@ -725,10 +725,12 @@ class Session:
 
     def clusters(self, contig_ptr, gene_ptr, attr_id, annotated, window, step=1, label=1, pad=True, threshold=0.8, n_cds=3,
                  edge_distance=0, trim=True, want_p=False, want_seg_p=True, p_out=None, criterion="gecco", n_biopfams=5,
-                 average_threshold=0.6, marker_ptr=None, marker_id=None, degree=None):
+                 average_threshold=0.6, marker_ptr=None, marker_id=None, degree=None, seg_p_out=None):
         """Windowed marginals + cluster calls in one pass; the probabilities stay on the device unless
         `want_p` / `p_out`.  Returns (seg rows (k, 4), seg_p, seg_off, p or None): `seg_p[seg_off[i]:seg_off[i+1]]`
-        are the probabilities of the genes of row i.  `degree` (uint8, = diff(gene_ptr)): the degree-byte wire format."""
+        are the probabilities of the genes of row i.  `degree` (uint8, = diff(gene_ptr)): the degree-byte wire format.
+        `seg_p_out`: a caller buffer of n doubles for the rows' probabilities (a pinned one is filled by the copy engine at
+        full rate; a fresh pageable array costs a page fault per 4 KB); the returned seg_p is then a view of it."""
         contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
         if annotated is None:  # (with `degree`: annotated iff the gene has a domain the model knows)
             if degree is None:
@@ -741,7 +743,10 @@ class Session:
             p_out = np.empty(max(n, 1), dtype=np.float64)
         cap = min(n, n // 2 + nc) + 1
         seg = np.empty((cap, 4), dtype=np.int32)
-        seg_p = np.empty(max(n, 1), dtype=np.float64) if want_seg_p else None
+        if seg_p_out is not None:
+            assert seg_p_out.dtype == np.float64 and seg_p_out.size >= n
+            want_seg_p = True
+        seg_p = (seg_p_out if seg_p_out is not None else np.empty(max(n, 1), dtype=np.float64)) if want_seg_p else None
         seg_off = np.zeros(cap + 1, dtype=np.int64)
         n_seg = ctypes.c_int32(0)
         keep = []
@@ -756,7 +761,8 @@ class Session:
             _ptr(p_out, _c_f64p) if p_out is not None else None, _ptr(seg, _c_i32p), cap, ctypes.byref(n_seg),
             _ptr(seg_p, _c_f64p) if want_seg_p else None, max(n, 1), seg_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
         k = n_seg.value
-        return (seg[:k].copy(), (seg_p[: seg_off[k]].copy() if want_seg_p else None), seg_off[: k + 1].copy(),
+        return (seg[:k].copy(), ((seg_p[: seg_off[k]] if seg_p_out is not None else seg_p[: seg_off[k]].copy()) if want_seg_p else None),
+                seg_off[: k + 1].copy(),
                 (p_out[:n] if p_out is not None else None))
 
 

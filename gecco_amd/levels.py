@@ -59,11 +59,11 @@ def host_buffer_levels(model, wl, devices=(0,), reps=5, W=20):
                                    "h2d_mb": ses.stats()["h2d_bytes"] / 1e6,
                                    "note": "marginals + refiner on the device, degree bytes on the wire (gecco_crf_session_clusters_degrees); "
                                            "only the cluster rows come back"}
-    dt = _timed(lambda: ses.clusters(cp, gp, at, ann, W, want_p=False, want_seg_p=True, degree=deg), reps)
+    dt = _timed(lambda: ses.clusters(cp, gp, at, ann, W, want_p=False, degree=deg, seg_p_out=outp), reps)
     out["cluster_calls_with_probabilities_pinned"] = {
         "ms": dt * 1e3, "genes_per_s": n / dt, "clusters": int(len(seg)), "genes_in_clusters": int(seg_off[-1]),
-        "note": "the same + the probabilities of the clusters' genes (what a cluster table needs of p), written by the last kernel "
-                "into pinned memory"}
+        "note": "the same + the probabilities of the clusters' genes (what a cluster table needs of p): gathered on the device, "
+                "downloaded into a pinned caller buffer once the host knows how many there are"}
     for v in out.values():
         v["genes"] = n
         v["devices"] = len(devices)

@@ -222,6 +222,12 @@ def test_session_pinned_buffers_every_output(nat, real_model, oracle_model):
     seg_c = ses.clusters(cptr, gptr, attr, ann, 20, threshold=_threshold(p_z), p_out=np.empty(n))
     assert seg_z[0].tolist() == seg_c[0].tolist() and len(seg_z[0]) > 5
     np.testing.assert_array_equal(seg_z[3], seg_c[3])
+    # the rows' probabilities into a caller buffer (pinned: the copy engine fills it at full rate)
+    sp = nat.pinned_empty(n, np.float64)
+    seg_b = ses.clusters(pc, pg, pa, ann, 20, threshold=_threshold(p_z), seg_p_out=sp)
+    assert seg_b[0].tolist() == seg_c[0].tolist()
+    np.testing.assert_array_equal(seg_b[1], seg_c[1])
+    np.testing.assert_array_equal(seg_b[2], seg_c[2])
 
 
 def test_session_argument_errors(nat, real_model):
