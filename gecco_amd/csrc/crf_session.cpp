@@ -636,6 +636,9 @@ int session_run(Session &S, const BatchRequest &r) {
     deal_chunks(chunks, int(S.devs.size()));
     S.stats.n_chunks = int32_t(chunks.size());
     RunCtx X{S, r, chunks, windowed, viterbi, full, windowed ? r.window : 1, windowed ? r.step : 1, windowed ? r.pad : 1};
+    // (every lane is idle here: start from lane 0 again, so that calls of a chunk or two keep to the lanes whose buffers and
+    // workspaces exist already instead of walking the ring and allocating in each of its lanes in turn)
+    for (auto &d : S.devs) d->next_lane = 0;
     // per-device queues in batch order; devices are fed round-robin so that all of them start at once
     std::vector<std::vector<int>> queue(S.devs.size());
     for (size_t i = 0; i < chunks.size(); ++i) queue[size_t(chunks[i].device_slot)].push_back(int(i));
