@@ -14,7 +14,7 @@ B="python bench.py --no-cpu-baseline --no-past-l3 --no-c4 --no-8d --no-levels --
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- $B > $O/kt.log 2>&1
 # the same run on the default schedule (two decode streams: two launches of crf_decode_pipelined in flight, each longer than alone)
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt2 -o kt2 -- ${B/--streams 1/--streams 2} > $O/kt2.log 2>&1
-S="--steps 3 --warmup 1 --kernel-iters 3 --preroll-ms 0 --windowed-only --no-past-l3"  # few dispatches of ONE kind (plain windowed launches): the PMC passes serialise and slow every launch
+S="--steps 3 --warmup 1 --kernel-iters 3 --preroll-ms 0 --windowed-only --no-past-l3 --min-region-ms 0"  # few dispatches of ONE kind (plain windowed launches): the PMC passes serialise and slow every launch
 timeout 180 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc1 -o pmc1 -- $B $S > $O/pmc1.log 2>&1
 timeout 180 rocprofv3 --pmc FETCH_SIZE -d $O/pmc2 -o pmc2 -- $B $S > $O/pmc2.log 2>&1
 timeout 180 rocprofv3 --pmc WRITE_SIZE -d $O/pmc3 -o pmc3 -- $B $S > $O/pmc3.log 2>&1
@@ -22,7 +22,7 @@ timeout 180 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE 
 timeout 180 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum -d $O/pmc5 -o pmc5 -- $B $S > $O/pmc5.log 2>&1
 timeout 180 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $O/pmc6 -o pmc6 -- $B $S > $O/pmc6.log 2>&1
 # the same for the launch that is the step under the default (pipelined) schedule: crf_decode_pipelined
-S2="--steps 4 --warmup 1 --kernel-iters 3 --preroll-ms 0"
+S2="--steps 4 --warmup 1 --kernel-iters 3 --preroll-ms 0 --min-region-ms 0"
 timeout 180 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pipe/pmc1 -o pmc1 -- $B $S2 > $O/pipe_pmc1.log 2>&1
 timeout 180 rocprofv3 --pmc FETCH_SIZE -d $O/pipe/pmc2 -o pmc2 -- $B $S2 > $O/pipe_pmc2.log 2>&1
 timeout 180 rocprofv3 --pmc WRITE_SIZE -d $O/pipe/pmc3 -o pmc3 -- $B $S2 > $O/pipe_pmc3.log 2>&1

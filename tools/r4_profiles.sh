@@ -10,6 +10,13 @@ kt() {  # <name> <command...>: rocprofv3 --kernel-trace --stats of a command -> 
   rm -rf $O/kt_$name
 }
 timeout 1200 tools/profile.sh r4_final > $O/profile.log 2>&1
+# counters of the window kernel on C5 (the dominant kernel of `bench.py --workload C5`): its roofline.traffic
+mkdir -p $R/profiles
+C5="python bench.py --workload C5 --windowed-only --steps 3 --warmup 1 --kernel-iters 3 --preroll-ms 0 --no-cpu-baseline --no-levels --no-past-l3 --min-region-ms 0"
+timeout 200 rocprofv3 --pmc FETCH_SIZE -d $O/c5win/pmc2 -o pmc2 -- $C5 > $O/c5win_pmc2.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE -d $O/c5win/pmc3 -o pmc3 -- $C5 > $O/c5win_pmc3.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -d $O/c5win/pmc1 -o pmc1 -- $C5 > $O/c5win_pmc1.log 2>&1
+python tools/pmc_to_json.py $O/c5win C5 r4_final crf_windowed_l2 >> $O/pmc.json 2>&1
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_c3_driver.json 2> $O/bench_c3_driver.err
 timeout 600 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 timeout 300 python bench.py --schedule two-launch --no-levels --no-cpu-baseline > $O/bench_c3_two_launch.json 2> $O/bench_c3_two_launch.err
