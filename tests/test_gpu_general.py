@@ -174,6 +174,23 @@ def test_matrix_core_window_kernel(nat, L, monkeypatch):
     assert np.abs(got - other).max() <= 1e-12
 
 
+def test_matrix_core_window_kernel_every_label_count(nat):
+    """Every label count from 9 to 32 (every number of K-slices, labels that end inside a slice or a tile), W = 20 and a
+    window of 32, the last label queried: gl_windowed_mfma against the oracle."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(4321)
+    A = 120
+    cptr, gptr, attr = synth_contigs(rng, [1, 19, 20, 21, 64, 237, 238, 500] + list(rng.integers(1, 90, size=25)), A)
+    for L in range(9, 33):
+        w, trans = synth_model(A, rng, L=L)
+        model = nat.Model.from_tables(w, trans)
+        for W, label in ((20, L - 1), (32, L // 3)):
+            got = model.windowed_marginals(cptr, gptr, attr, W, 1, label, True)
+            exp = orc.windowed_marginals(w, trans, cptr, gptr, attr, W, 1, label, True)
+            assert np.abs(got - exp).max() <= 1e-12, (L, W, label)
+
+
 def test_lane_per_window_kernel_range_guard(nat):
     """Its recurrences are un-normalised: transition weights whose spread times W - 1 stays under 600 keep every value
     in range (checked at the limit, with state weights as extreme as CRFsuite models get); beyond, the scaled kernel."""
