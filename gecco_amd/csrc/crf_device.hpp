@@ -207,6 +207,7 @@ struct SegParams {
     int32_t criterion = 0, n_biopfams = 5;
     double average_threshold = 0.6;
     const int32_t *bio_ptr = nullptr, *bio_id = nullptr;
+    int32_t row_contig0 = 0, row_gene0 = 0;  // added to the contig / gene indices of the rows written (a chunk of a larger batch)
 };
 struct SegArgs {
     const double *p;        // [n_genes] probabilities (NaN: none)
@@ -233,6 +234,7 @@ struct SegArgs {
     int32_t *total;
     double *gout;           // [gcap] or null: probabilities of the genes of the kept rows, row after row
     int32_t gcap;
+    int32_t row_c0, row_g0; // offsets of the rows' contig / gene indices as written
 };
 size_t segment_workspace_bytes(int n_genes, int n_contigs);
 // d_gather (may be null; needs d_seg_off): the probabilities of the rows' genes, row after row.  d_seg / d_seg_off / d_total /

@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(kT) seg_compact(const SegArgs A) {
         const int o = int(before.x + excl.x), off = int(before.y + excl.y);
         const bool write = kept && o < A.max_seg;
         if (write) {
-            reinterpret_cast<int4 *>(A.seg)[o] = v;
+            reinterpret_cast<int4 *>(A.seg)[o] = make_int4(v.x + A.row_c0, v.y, v.z + A.row_g0, v.w + A.row_g0);
             if (A.seg_off) A.seg_off[o] = off;
         }
         if (A.gout) {
@@ -397,6 +397,8 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
     a.total = d_total;
     a.gout = d_seg_off ? d_gather : nullptr;  // (the rows' probabilities are laid out by the rows' gene offsets)
     a.gcap = gather_cap;
+    a.row_c0 = params.row_contig0;
+    a.row_g0 = params.row_gene0;
     if (!d_flags) {
         hipError_t e = hipMemsetAsync(own_flags, 0, n + 8, stream);
         if (e != hipSuccess) return e;

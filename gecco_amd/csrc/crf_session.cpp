@@ -100,7 +100,7 @@ struct Chunk {
 struct Lane {
     int device = -1;
     hipStream_t up = nullptr, comp = nullptr, down = nullptr;  // the device's three streams (not owned)
-    hipEvent_t ev_up = nullptr, ev_comp = nullptr, done = nullptr;
+    hipEvent_t ev_up = nullptr, ev_deg = nullptr, ev_comp = nullptr, done = nullptr;
     int chunk = -1;  // index of the chunk in flight, -1: idle
     Plan plan;
     DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg, d_deg, d_deg_ws, d_segp;
@@ -142,7 +142,7 @@ Session::~Session() {
         for (Lane &ln : d->lanes) {
             for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi, &ln.d_seg, &ln.d_deg, &ln.d_deg_ws, &ln.d_segp}) b->release();
             ln.h_seg.release();
-            for (hipEvent_t e : {ln.ev_up, ln.ev_comp, ln.done})
+            for (hipEvent_t e : {ln.ev_up, ln.ev_deg, ln.ev_comp, ln.done})
                 if (e) (void)hipEventDestroy(e);
         }
         for (hipStream_t st : {d->up, d->comp, d->down})
@@ -189,7 +189,7 @@ int session_create(const Model &m, const int32_t *devices, int32_t n_devices, Se
             ln.comp = D.comp;
             ln.down = D.down;
             ln.plan.async_tables = true;
-            for (hipEvent_t *e : {&ln.ev_up, &ln.ev_comp, &ln.done})
+            for (hipEvent_t *e : {&ln.ev_up, &ln.ev_deg, &ln.ev_comp, &ln.done})
                 if ((rc = check_hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate"))) return rc;
         }
     }
@@ -335,6 +335,13 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
             if ((rc = check_hip(hipMemcpyAsync(ln.d_deg.p, r.degree + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D degrees")))
                 return rc;
             S.stats.h2d_bytes += int64_t(ng);
+            // the row pointers are rebuilt as soon as the degree bytes are there: under the attribute upload, not behind it
+            if ((rc = check_hip(hipEventRecord(ln.ev_deg, ln.up), "hipEventRecord"))) return rc;
+            if ((rc = check_hip(hipStreamWaitEvent(ln.comp, ln.ev_deg, 0), "hipStreamWaitEvent"))) return rc;
+            if ((rc = check_hip(launch_degree_to_row_ptr(reinterpret_cast<const uint8_t *>(ln.d_deg.p), int(ng), int32_t(a0),
+                                                         reinterpret_cast<int32_t *>(ln.d_gp.p), reinterpret_cast<int32_t *>(ln.d_deg_ws.p),
+                                                         ln.comp), "degree scan launch")))
+                return rc;
         } else {
             if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
             if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.g0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.up), "H2D gene_ptr")))
@@ -397,10 +404,6 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
     if (ng == 0) return check_hip(hipEventRecord(ln.done, ln.comp), "hipEventRecord");
     // gene_ptr keeps the caller's offsets: the attribute array is addressed from where its element 0 would be
     const int32_t *d_gp = reinterpret_cast<const int32_t *>(ln.d_gp.p);
-    if (r.degree && (rc = check_hip(launch_degree_to_row_ptr(reinterpret_cast<const uint8_t *>(ln.d_deg.p), int(ng), int32_t(a0),
-                                                               reinterpret_cast<int32_t *>(ln.d_gp.p),
-                                                               reinterpret_cast<int32_t *>(ln.d_deg_ws.p), ln.comp), "degree scan launch")))
-        return rc;
     const int32_t *d_at = reinterpret_cast<const int32_t *>(ln.d_at.p) - a0;
     double *d_p = nullptr, *d_score = nullptr;
     int8_t *d_y = nullptr;
@@ -468,6 +471,8 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
                 *d_rows = reinterpret_cast<int32_t *>(dp + ln.o_rows);
         SegParams sp = r.seg;
         sp.carry = 0;
+        sp.row_contig0 = ck.c0;  // (rows arrive in the batch's own indices)
+        sp.row_gene0 = ck.g0;
         sp.bio_ptr = sp.bio_id = nullptr;
         if (sp.criterion == 1) {
             sp.bio_ptr = reinterpret_cast<const int32_t *>(ln.d_bp.p);
@@ -518,13 +523,7 @@ int retire_begin(RunCtx &X, Lane &ln) {
             return GECCO_CRF_EHIP;
         }
         const int32_t *rows = reinterpret_cast<const int32_t *>(hp + ln.o_rows), *off = reinterpret_cast<const int32_t *>(hp + ln.o_off);
-        ck.rows.resize(size_t(total) * 4);
-        for (int32_t i = 0; i < total; ++i) {
-            ck.rows[4 * size_t(i) + 0] = rows[4 * i + 0] + ck.c0;
-            ck.rows[4 * size_t(i) + 1] = rows[4 * i + 1];
-            ck.rows[4 * size_t(i) + 2] = rows[4 * i + 2] + ck.g0;
-            ck.rows[4 * size_t(i) + 3] = rows[4 * i + 3] + ck.g0;
-        }
+        ck.rows.assign(rows, rows + size_t(total) * 4);  // (written in batch indices by the segmenter's last launch)
         if (X.r.seg_p_out) {
             // straight into the caller's array at the chunk's gene offset (never behind their final place: the chunks before
             // hold at least as many genes as their rows do), closed up at the end of the call
