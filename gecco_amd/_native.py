@@ -116,6 +116,12 @@ SIGNATURES = {
         [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_u8p, _c_i32p, _c_u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
          _vp, _c_f64p, _c_i32p, ctypes.c_int32, _c_i32p, _c_f64p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)],
     ),
+    "gecco_crf_session_clusters_wire": (
+        ctypes.c_int,
+        # (array arguments as plain addresses: a typed ctypes pointer costs 3.5 us to make, an address half of that)
+        [_vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+         ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, ctypes.c_int64, _vp],
+    ),
     "gecco_crf_pack_columns": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp)]),
     "gecco_crf_packed_free": (None, [_vp]),
     "gecco_crf_packed_info": (
@@ -730,7 +736,12 @@ class Session:
         `want_p` / `p_out`.  Returns (seg rows (k, 4), seg_p, seg_off, p or None): `seg_p[seg_off[i]:seg_off[i+1]]`
         are the probabilities of the genes of row i.  `degree` (uint8, = diff(gene_ptr)): the degree-byte wire format.
         `seg_p_out`: a caller buffer of n doubles for the rows' probabilities (a pinned one is filled by the copy engine at
-        full rate; a fresh pageable array costs a page fault per 4 KB); the returned seg_p is then a view of it."""
+        full rate; a fresh pageable array costs a page fault per 4 KB); the returned seg_p is then a view of it.
+        `attr_id` may be a uint16 array (a model with at most 65536 attributes): it then crosses PCIe as it is."""
+        attr16 = None
+        if isinstance(attr_id, np.ndarray) and attr_id.dtype == np.uint16:
+            attr16 = np.ascontiguousarray(attr_id) if attr_id.size else np.zeros(1, dtype=np.uint16)
+            attr_id = np.zeros(1, dtype=np.int32)
         contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
         if annotated is None:  # (with `degree`: annotated iff the gene has a domain the model knows)
             if degree is None:
@@ -742,24 +753,25 @@ class Session:
         if p_out is None and want_p:
             p_out = np.empty(max(n, 1), dtype=np.float64)
         cap = min(n, n // 2 + nc) + 1
-        seg = np.empty((cap, 4), dtype=np.int32)
+        held = getattr(self, "_row_buffers", None)  # (the row buffers are kept between calls: no 24 MB of fresh pages per batch)
+        if held is None or held[0].shape[0] < cap:
+            held = self._row_buffers = (np.empty((cap, 4), dtype=np.int32), np.zeros(cap + 1, dtype=np.int64))
+        seg, seg_off = held[0][:cap], held[1][: cap + 1]
         if seg_p_out is not None:
             assert seg_p_out.dtype == np.float64 and seg_p_out.size >= n
             want_seg_p = True
         seg_p = (seg_p_out if seg_p_out is not None else np.empty(max(n, 1), dtype=np.float64)) if want_seg_p else None
-        seg_off = np.zeros(cap + 1, dtype=np.int64)
         n_seg = ctypes.c_int32(0)
         keep = []
         q = refine_params(criterion, threshold, n_cds, n_biopfams, average_threshold, edge_distance, trim, False, marker_ptr,
                           marker_id, keep)
         if degree is not None:
             assert degree.dtype == np.uint8 and degree.size >= n
-        _check(self._lib.gecco_crf_session_clusters_degrees(
-            self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p), _ptr(degree, _c_u8p) if degree is not None else None,
-            _ptr(attr_id, _c_i32p), _ptr(annotated, _c_u8p) if annotated is not None else None,
-            int(window), int(step), int(label), int(bool(pad)), ctypes.byref(q),
-            _ptr(p_out, _c_f64p) if p_out is not None else None, _ptr(seg, _c_i32p), cap, ctypes.byref(n_seg),
-            _ptr(seg_p, _c_f64p) if want_seg_p else None, max(n, 1), seg_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        adr = lambda a: None if a is None else a.ctypes.data  # noqa: E731
+        _check(self._lib.gecco_crf_session_clusters_wire(
+            self._h, adr(contig_ptr), nc, adr(gene_ptr), adr(degree), adr(attr_id) if attr16 is None else None, adr(attr16),
+            adr(annotated), int(window), int(step), int(label), int(bool(pad)), ctypes.addressof(q), adr(p_out), adr(seg), cap,
+            ctypes.addressof(n_seg), adr(seg_p) if want_seg_p else None, max(n, 1), adr(seg_off)))
         k = n_seg.value
         return (seg[:k].copy(), ((seg_p[: seg_off[k]] if seg_p_out is not None else seg_p[: seg_off[k]].copy()) if want_seg_p else None),
                 seg_off[: k + 1].copy(),

@@ -460,9 +460,19 @@ GECCO_API int gecco_crf_session_clusters_degrees(gecco_crf_session *s, const int
                                                  const gecco_crf_refine_params *params, double *p_out, int32_t *seg_out,
                                                  int32_t max_seg, int32_t *n_seg, double *seg_p_out, int64_t max_seg_genes,
                                                  int64_t *seg_off_out) {
+    return gecco_crf_session_clusters_wire(s, contig_ptr, n_contigs, gene_ptr, degree, attr_id, nullptr, annotated, window, step, label,
+                                           pad, params, p_out, seg_out, max_seg, n_seg, seg_p_out, max_seg_genes, seg_off_out);
+}
+GECCO_API int gecco_crf_session_clusters_wire(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                              const int32_t *gene_ptr, const uint8_t *degree, const int32_t *attr_id,
+                                              const uint16_t *attr_id16, const uint8_t *annotated, int32_t window, int32_t step,
+                                              int32_t label, int32_t pad, const gecco_crf_refine_params *params, double *p_out,
+                                              int32_t *seg_out, int32_t max_seg, int32_t *n_seg, double *seg_p_out,
+                                              int64_t max_seg_genes, int64_t *seg_off_out) {
     if (!s || !params) return GECCO_CRF_EINVAL;
     BatchRequest r = csr_request(contig_ptr, n_contigs, gene_ptr, attr_id);
     r.degree = degree;
+    r.attr_id16 = attr_id16;
     r.window = window;
     r.step = step;
     r.label = label;

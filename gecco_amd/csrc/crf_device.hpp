@@ -248,6 +248,13 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
 size_t degree_scratch_bytes(int n);
 hipError_t launch_degree_to_row_ptr(const uint8_t *d_deg, int n, int32_t base, int32_t *d_row_ptr, int32_t *d_scratch, hipStream_t stream);
 
+// `bytes` (a multiple of 16, 16-byte aligned both sides) from device-visible memory -- a pinned host block -- to device memory
+hipError_t launch_copy_block(const void *src, void *dst, size_t bytes, hipStream_t stream);
+// both halves of the wire format in two launches: the row pointers (d_deg may be null: none) and, with d_attr16, nnz 16-bit
+// attribute indices widened to 32-bit ones (both 16-byte aligned device buffers with 8 elements of slack)
+hipError_t launch_wire_format(const uint8_t *d_deg, int n, int32_t base, int32_t *d_row_ptr, int32_t *d_scratch,
+                              const uint16_t *d_attr16, int64_t nnz, int32_t *d_attr32, hipStream_t stream);
+
 // ---- any number of labels (crf_general.hip) -------------------------------------------------
 constexpr int kGenMaxL = 32;  // labels: a group of next-pow2(L) lanes must fit in half a wave
 constexpr int kGenMaxW = 48;  // window length: alpha-hat of a whole window lives in LDS (<= 3 KB per step)

@@ -400,6 +400,11 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     p.d_skipped = reinterpret_cast<int2 *>(d + o_skip);
     p.d_contig_ptr = reinterpret_cast<int32_t *>(d + o_cptr);
     if (p.tables_in_host_memory) return GECCO_CRF_OK;
+    if (p.tables_by_kernel && !sync) {
+        void *dv = nullptr;
+        if ((rc = check_hip(hipHostGetDevicePointer(&dv, h, 0), "hipHostGetDevicePointer"))) return rc;
+        return check_hip(launch_copy_block(dv, d, off, upload_stream), "plan tables launch");
+    }
     if ((rc = check_hip(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, upload_stream), "upload plan tables"))) return rc;
     if (sync && (rc = check_hip(hipStreamSynchronize(upload_stream), "upload plan tables"))) return rc;
     return GECCO_CRF_OK;

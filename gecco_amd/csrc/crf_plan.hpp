@@ -91,6 +91,8 @@ struct Plan {
         const int32_t *gene_ptr = nullptr, *attr_id = nullptr;
     } pipe;
     bool async_tables = false;  // the owner launches everything on ONE stream (batch driver): table uploads are not waited for
+    bool tables_by_kernel = false;  // copied tables are fetched from the pinned block by a small launch on the upload stream, not by
+                                    // the copy engine (batch driver: the engine is busy with the next chunk's arrays by then)
     bool tables_in_host_memory = false;  // the window kernel reads the plan tables from the pinned block itself (batch driver:
                                          // one copy and one inter-copy gap less per chunk; they are ~0.1 MB, read once)
     std::mutex ws_mutex;  // guards the lazy workspace / table creation: launches of one plan may come from several threads

@@ -80,18 +80,34 @@ __device__ __forceinline__ LaneIn load_lane(const SegArgs &A, Stage &stg) {
     return L;
 }
 
-// flags[g]: bit0 = first gene of a contig, bit1 = last gene (the layout of the plan's whole-contig tables)
-__global__ void __launch_bounds__(kT) seg_flags(const int32_t *__restrict__ cptr, int n_contigs, uint8_t *__restrict__ flags) {
-    const int c = blockIdx.x * kT + threadIdx.x;
-    if (c >= n_contigs) return;
-    const int g0 = cptr[c], g1 = cptr[c + 1];
-    if (g1 <= g0) return;
-    if (g1 - g0 == 1) {
-        flags[g0] = 3;
-    } else {
-        flags[g0] = 1;
-        flags[g1 - 1] = 2;
+// flags[g]: bit0 = first gene of a contig, bit1 = last gene (the layout of the plan's whole-contig tables).  One lane per
+// eight genes: it finds the contig of its first gene in the contig table (a binary search through L2-resident words) and
+// walks from there -- every byte of the array is written, by one launch (no memset before it).
+__global__ void __launch_bounds__(kT) seg_flags(const int32_t *__restrict__ cptr, int n_contigs, int n_genes, uint8_t *__restrict__ flags) {
+    const int g0 = (blockIdx.x * kT + threadIdx.x) * 8;
+    if (g0 >= n_genes + 8) return;
+    uint64_t word = 0;
+    if (g0 < n_genes) {
+        int lo = 0, hi = n_contigs;  // largest c with cptr[c] <= g0 (cptr[0] = 0, cptr[n_contigs] = n_genes > g0)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cptr[mid] <= g0) lo = mid; else hi = mid;
+        }
+        int c = lo, end = cptr[c + 1];
+        while (end <= g0) end = cptr[++c + 1];  // (empty contigs that start at g0 sort before the one that holds it)
+        int start = cptr[c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int g = g0 + k;
+            if (g >= n_genes) break;
+            while (end <= g) {
+                start = end;
+                end = cptr[++c + 1];
+            }
+            word |= uint64_t((g == start ? 1u : 0u) | (g + 1 == end ? 2u : 0u)) << (8 * k);
+        }
     }
+    *reinterpret_cast<uint64_t *>(flags + g0) = word;
 }
 
 __global__ void __launch_bounds__(kT) seg_fold(const SegArgs A) {
@@ -400,9 +416,7 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
     a.row_c0 = params.row_contig0;
     a.row_g0 = params.row_gene0;
     if (!d_flags) {
-        hipError_t e = hipMemsetAsync(own_flags, 0, n + 8, stream);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(seg_flags, dim3((n_contigs + kT - 1) / kT), dim3(kT), 0, stream, d_cptr, n_contigs, own_flags);
+        hipLaunchKernelGGL(seg_flags, dim3(unsigned((n / 8 + 1 + kT - 1) / kT)), dim3(kT), 0, stream, d_cptr, n_contigs, n_genes, own_flags);
         d_flags = own_flags;
     }
     a.flags = d_flags;
@@ -455,31 +469,42 @@ __device__ __forceinline__ int deg_block_exclusive(int mine, int *lds /* kDegT /
     *total = all;
     return pre + incl - mine;
 }
-__global__ void __launch_bounds__(kDegT) deg_block_sums(const uint8_t *__restrict__ deg, int n, int32_t *__restrict__ sums) {
+// 16-bit attribute indices of the compact wire format -> the 32-bit ones every kernel reads: 8 per lane, one 16-byte load
+// and two 16-byte stores (in and out are 16-byte aligned device buffers with 8 elements of slack)
+__device__ __forceinline__ void widen_attr_ids(const uint16_t *__restrict__ in, int64_t n, int32_t *__restrict__ out, int64_t block) {
+    const int64_t i = (block * kDegT + threadIdx.x) * 8;
+    if (i >= n) return;
+    const uint4 v = *reinterpret_cast<const uint4 *>(in + i);
+    int4 *o = reinterpret_cast<int4 *>(out + i);
+    o[0] = make_int4(int(v.x & 0xFFFFu), int(v.x >> 16), int(v.y & 0xFFFFu), int(v.y >> 16));
+    o[1] = make_int4(int(v.z & 0xFFFFu), int(v.z >> 16), int(v.w & 0xFFFFu), int(v.w >> 16));
+}
+// launch 1: workgroups [0, nb) total their 4 096 degree bytes; the workgroups behind them widen attribute indices
+__global__ void __launch_bounds__(kDegT) wire_block_sums(const uint8_t *__restrict__ deg, int n, int nb, int32_t *__restrict__ sums,
+                                                        const uint16_t *__restrict__ at16, int64_t nnz, int32_t *__restrict__ at32) {
+    if (int(blockIdx.x) >= nb) {
+        widen_attr_ids(at16, nnz, at32, int64_t(blockIdx.x) - nb);
+        return;
+    }
     __shared__ int lds[kDegT / 64];
     int c[kDegPer], total;
     const int mine = deg_lane_counts(deg, n, blockIdx.x * kDegBlock + threadIdx.x * kDegPer, c);
     (void)deg_block_exclusive(mine, lds, &total);
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
-__global__ void __launch_bounds__(kDegT) deg_scan_sums(int32_t *__restrict__ sums, int nb) {  // ONE workgroup, in place, exclusive
+// launch 2: every workgroup adds up the totals of the workgroups before it itself (a chunk of a million genes has 245 of
+// them: one word per lane) and writes its 4 096 row pointers
+__global__ void __launch_bounds__(kDegT) wire_row_ptr(const uint8_t *__restrict__ deg, int n, const int32_t *__restrict__ sums,
+                                                     int32_t base, int32_t *__restrict__ row_ptr) {
     __shared__ int lds[kDegT / 64];
-    int carry = 0;
-    for (int b0 = 0; b0 < nb; b0 += kDegT) {
-        const int i = b0 + threadIdx.x, mine = i < nb ? sums[i] : 0;
-        int total;
-        const int ex = deg_block_exclusive(mine, lds, &total);
-        if (i < nb) sums[i] = carry + ex;
-        carry += total;
-    }
-}
-__global__ void __launch_bounds__(kDegT) deg_row_ptr(const uint8_t *__restrict__ deg, int n, const int32_t *__restrict__ sums,
-                                                    int32_t base, int32_t *__restrict__ row_ptr) {
-    __shared__ int lds[kDegT / 64];
+    int before = 0;
+    for (int i = threadIdx.x; i < int(blockIdx.x); i += kDegT) before += sums[i];
+    int ahead;
+    (void)deg_block_exclusive(before, lds, &ahead);
     int c[kDegPer], total;
     const int i0 = blockIdx.x * kDegBlock + threadIdx.x * kDegPer;
     const int mine = deg_lane_counts(deg, n, i0, c);
-    int run = base + sums[blockIdx.x] + deg_block_exclusive(mine, lds, &total);
+    int run = base + ahead + deg_block_exclusive(mine, lds, &total);
 #pragma unroll
     for (int k = 0; k < kDegPer; ++k) {
         if (i0 + k <= n) row_ptr[i0 + k] = run;  // (entry n = base + the chunk's total: written by the lane that owns position n)
@@ -488,15 +513,35 @@ __global__ void __launch_bounds__(kDegT) deg_row_ptr(const uint8_t *__restrict__
 }
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(256) copy_block(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+}  // namespace
+hipError_t launch_copy_block(const void *src, void *dst, size_t bytes, hipStream_t stream) {
+    if ((bytes & 15) || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return hipErrorInvalidValue;
+    if (!bytes) return hipSuccess;
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(copy_block, dim3(unsigned((n16 + 255) / 256)), dim3(256), 0, stream, static_cast<const uint4 *>(src),
+                       static_cast<uint4 *>(dst), n16);
+    return hipGetLastError();
+}
+
 size_t degree_scratch_bytes(int n) { return (size_t((n + kDegBlock) / kDegBlock) + 1) * 4; }
 
-hipError_t launch_degree_to_row_ptr(const uint8_t *d_deg, int n, int32_t base, int32_t *d_row_ptr, int32_t *d_scratch, hipStream_t stream) {
-    if (n < 0) return hipErrorInvalidValue;
-    const int nb = (n + kDegBlock) / kDegBlock;  // (n + 1 positions: position n carries the total)
-    hipLaunchKernelGGL(deg_block_sums, dim3(nb), dim3(kDegT), 0, stream, d_deg, n, d_scratch);
-    hipLaunchKernelGGL(deg_scan_sums, dim3(1), dim3(kDegT), 0, stream, d_scratch, nb);
-    hipLaunchKernelGGL(deg_row_ptr, dim3(nb), dim3(kDegT), 0, stream, d_deg, n, d_scratch, base, d_row_ptr);
+hipError_t launch_wire_format(const uint8_t *d_deg, int n, int32_t base, int32_t *d_row_ptr, int32_t *d_scratch,
+                              const uint16_t *d_attr16, int64_t nnz, int32_t *d_attr32, hipStream_t stream) {
+    if (n < 0 || nnz < 0) return hipErrorInvalidValue;
+    const int nb = d_deg ? (n + kDegBlock) / kDegBlock : 0;  // (n + 1 positions: position n carries the total)
+    const int nw = d_attr16 ? int((nnz + kDegT * 8 - 1) / (kDegT * 8)) : 0;
+    if (nb + nw == 0) return hipSuccess;
+    hipLaunchKernelGGL(wire_block_sums, dim3(nb + nw), dim3(kDegT), 0, stream, d_deg, n, nb, d_scratch, d_attr16, nnz, d_attr32);
+    if (nb) hipLaunchKernelGGL(wire_row_ptr, dim3(nb), dim3(kDegT), 0, stream, d_deg, n, d_scratch, base, d_row_ptr);
     return hipGetLastError();
+}
+hipError_t launch_degree_to_row_ptr(const uint8_t *d_deg, int n, int32_t base, int32_t *d_row_ptr, int32_t *d_scratch, hipStream_t stream) {
+    return launch_wire_format(d_deg, n, base, d_row_ptr, d_scratch, nullptr, 0, nullptr, stream);
 }
 
 }  // namespace gecco

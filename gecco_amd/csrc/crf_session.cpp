@@ -1,5 +1,7 @@
 #include "crf_session.hpp"
 
+#include <emmintrin.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -100,10 +102,12 @@ struct Chunk {
 struct Lane {
     int device = -1;
     hipStream_t up = nullptr, comp = nullptr, down = nullptr;  // the device's three streams (not owned)
-    hipEvent_t ev_up = nullptr, ev_deg = nullptr, ev_comp = nullptr, done = nullptr;
+    hipEvent_t ev_up = nullptr, ev_comp = nullptr, done = nullptr;
     int chunk = -1;  // index of the chunk in flight, -1: idle
     Plan plan;
-    DevBuf d_gp, d_at, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg, d_deg, d_deg_ws, d_segp;
+    int up_chunk = -1;  // chunk whose arrays were uploaded ahead of its submission (-1: none)
+    int64_t up_a0 = 0, up_nnz = 0, up_b0 = 0;
+    DevBuf d_gp, d_at, d_at16, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg, d_deg, d_deg_ws, d_segp;
     HostBuf h_seg;  // [total][pad..][seg_off: cap+1][rows: cap*4]
     bool segp_in_flight = false;  // the download of the rows' probabilities has been issued (retire_begin), not yet waited for
     int32_t seg_cap = 0;
@@ -140,9 +144,9 @@ Session::~Session() {
         if (hipSetDevice(d->device) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
         for (Lane &ln : d->lanes) {
-            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi, &ln.d_seg, &ln.d_deg, &ln.d_deg_ws, &ln.d_segp}) b->release();
+            for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_at16, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi, &ln.d_seg, &ln.d_deg, &ln.d_deg_ws, &ln.d_segp}) b->release();
             ln.h_seg.release();
-            for (hipEvent_t e : {ln.ev_up, ln.ev_deg, ln.ev_comp, ln.done})
+            for (hipEvent_t e : {ln.ev_up, ln.ev_comp, ln.done})
                 if (e) (void)hipEventDestroy(e);
         }
         for (hipStream_t st : {d->up, d->comp, d->down})
@@ -189,7 +193,7 @@ int session_create(const Model &m, const int32_t *devices, int32_t n_devices, Se
             ln.comp = D.comp;
             ln.down = D.down;
             ln.plan.async_tables = true;
-            for (hipEvent_t *e : {&ln.ev_up, &ln.ev_deg, &ln.ev_comp, &ln.done})
+            for (hipEvent_t *e : {&ln.ev_up, &ln.ev_comp, &ln.done})
                 if ((rc = check_hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate"))) return rc;
         }
     }
@@ -256,22 +260,21 @@ void deal_chunks(std::vector<Chunk> &chunks, int n_devices) {
     }
 }
 
-// sum of n bytes, eight at a time: neighbouring bytes are added into 16-bit fields of a 64-bit word, 127 rounds of which
-// cannot overflow (127 * 510 < 65536)
+// sum of n bytes: psadbw adds sixteen at a time into two 64-bit lanes (SSE2: the x86-64 baseline)
 uint64_t byte_sum(const uint8_t *p, size_t n) {
-    constexpr uint64_t kLow = 0x00FF00FF00FF00FFull;
-    uint64_t total = 0;
+    const __m128i zero = _mm_setzero_si128();
+    __m128i a0 = zero, a1 = zero, a2 = zero, a3 = zero;
     size_t i = 0;
-    while (i + 8 <= n) {
-        uint64_t acc = 0;
-        const size_t rounds = std::min<size_t>((n - i) / 8, 127);
-        for (size_t k = 0; k < rounds; ++k, i += 8) {
-            uint64_t x;
-            std::memcpy(&x, p + i, 8);
-            acc += (x & kLow) + ((x >> 8) & kLow);
-        }
-        total += (acc & 0xFFFF) + ((acc >> 16) & 0xFFFF) + ((acc >> 32) & 0xFFFF) + (acc >> 48);
+    for (; i + 64 <= n; i += 64) {
+        a0 = _mm_add_epi64(a0, _mm_sad_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(p + i)), zero));
+        a1 = _mm_add_epi64(a1, _mm_sad_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(p + i + 16)), zero));
+        a2 = _mm_add_epi64(a2, _mm_sad_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(p + i + 32)), zero));
+        a3 = _mm_add_epi64(a3, _mm_sad_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(p + i + 48)), zero));
     }
+    const __m128i acc = _mm_add_epi64(_mm_add_epi64(a0, a1), _mm_add_epi64(a2, a3));
+    uint64_t lanes[2];
+    _mm_storeu_si128(reinterpret_cast<__m128i *>(lanes), acc);
+    uint64_t total = lanes[0] + lanes[1];
     for (; i < n; ++i) total += p[i];
     return total;
 }
@@ -309,24 +312,26 @@ int flush_pending(RunCtx &X, DeviceCtx &D) {
     return finish_pending(X, D);
 }
 
-int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
+// the bulk uploads of a chunk into an idle lane.  Issued one chunk ahead (session_run): the copy engine then goes from one
+// chunk's arrays to the next one's while the host still lays out and launches the first
+int submit_uploads(RunCtx &X, Lane &ln, int chunk_index) {
     Session &S = X.S;
     const BatchRequest &r = X.r;
     Chunk &ck = X.chunks[chunk_index];
-    const Model &m = *S.model;
     int rc = check_hip(hipSetDevice(ln.device), "hipSetDevice");
     if (rc) return rc;
-    const int32_t nc = ck.c1 - ck.c0, ng = ck.g1 - ck.g0;
+    const int32_t ng = ck.g1 - ck.g0;
     TraceMark tm;
-    ln.chunk = chunk_index;
     const int64_t a0 = ng ? r.gene_ptr[ck.g0] : 0, a1 = ng ? r.gene_ptr[ck.g1] : 0;
     if (a0 < 0 || a1 < a0) {
         set_error("gene_ptr must be non-decreasing and start at a non-negative offset");
         return GECCO_CRF_EINVAL;
     }
-    const size_t nnz = size_t(a1 - a0), L = size_t(m.L);
+    const size_t nnz = size_t(a1 - a0);
     int64_t b0 = 0;  // first marker offset of the chunk (antismash criterion)
-    // ---- uploads first: the bulk copies are on their way while the host lays the chunk out
+    ln.up_chunk = chunk_index;
+    ln.up_a0 = a0;
+    ln.up_nnz = int64_t(nnz);
     if (ng) {
         if (r.degree) {  // degree bytes cross PCIe; the row pointers are rebuilt on the device (below, on the compute stream)
             if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
@@ -335,23 +340,23 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
             if ((rc = check_hip(hipMemcpyAsync(ln.d_deg.p, r.degree + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D degrees")))
                 return rc;
             S.stats.h2d_bytes += int64_t(ng);
-            // the row pointers are rebuilt as soon as the degree bytes are there: under the attribute upload, not behind it
-            if ((rc = check_hip(hipEventRecord(ln.ev_deg, ln.up), "hipEventRecord"))) return rc;
-            if ((rc = check_hip(hipStreamWaitEvent(ln.comp, ln.ev_deg, 0), "hipStreamWaitEvent"))) return rc;
-            if ((rc = check_hip(launch_degree_to_row_ptr(reinterpret_cast<const uint8_t *>(ln.d_deg.p), int(ng), int32_t(a0),
-                                                         reinterpret_cast<int32_t *>(ln.d_gp.p), reinterpret_cast<int32_t *>(ln.d_deg_ws.p),
-                                                         ln.comp), "degree scan launch")))
-                return rc;
         } else {
             if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
             if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.g0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.up), "H2D gene_ptr")))
                 return rc;
             S.stats.h2d_bytes += int64_t((size_t(ng) + 1) * 4);
         }
-        if ((rc = ln.d_at.reserve((nnz + 4) * 4, "hipMalloc attr_id"))) return rc;
-        if (nnz && (rc = check_hip(hipMemcpyAsync(ln.d_at.p, r.attr_id + a0, nnz * 4, hipMemcpyHostToDevice, ln.up), "H2D attr_id")))
-            return rc;
-        S.stats.h2d_bytes += int64_t(nnz * 4);
+        if ((rc = ln.d_at.reserve((nnz + 8) * 4, "hipMalloc attr_id"))) return rc;
+        if (r.attr_id16) {  // 16-bit indices cross PCIe; widened on the compute stream (below)
+            if ((rc = ln.d_at16.reserve((nnz + 8) * 2, "hipMalloc attr_id16"))) return rc;
+            if (nnz && (rc = check_hip(hipMemcpyAsync(ln.d_at16.p, r.attr_id16 + a0, nnz * 2, hipMemcpyHostToDevice, ln.up), "H2D attr_id16")))
+                return rc;
+            S.stats.h2d_bytes += int64_t(nnz * 2);
+        } else {
+            if (nnz && (rc = check_hip(hipMemcpyAsync(ln.d_at.p, r.attr_id + a0, nnz * 4, hipMemcpyHostToDevice, ln.up), "H2D attr_id")))
+                return rc;
+            S.stats.h2d_bytes += int64_t(nnz * 4);
+        }
         if (r.want_segments) {
             if (r.annotated) {  // (null: a gene is annotated iff it has a domain the model knows -- the degree bytes themselves)
                 if ((rc = ln.d_ann.reserve(size_t(ng) + 8, "hipMalloc annotated"))) return rc;
@@ -377,13 +382,27 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
             }
         }
     }
-    tm.lap("h2d csr", chunk_index);
+    ln.up_b0 = b0;
     // the device derives the rows from the degree bytes, the host takes the chunk's base offset from gene_ptr: they must agree
     // (checked while the copies above are under way)
     if (ng && r.degree && byte_sum(r.degree + ck.g0, size_t(ng)) != uint64_t(a1 - a0)) {
         set_error("degree bytes do not add up to gene_ptr over a chunk (degree must equal diff(gene_ptr))");
         return GECCO_CRF_EINVAL;
     }
+    tm.lap("h2d csr", chunk_index);
+    return GECCO_CRF_OK;
+}
+
+// the chunk's layout (host) and its tables' upload, behind the chunk's arrays on the upload stream
+int submit_plan(RunCtx &X, Lane &ln, int chunk_index) {
+    Session &S = X.S;
+    const BatchRequest &r = X.r;
+    Chunk &ck = X.chunks[chunk_index];
+    const Model &m = *S.model;
+    int rc = check_hip(hipSetDevice(ln.device), "hipSetDevice");
+    if (rc) return rc;
+    const int32_t nc = ck.c1 - ck.c0;
+    TraceMark tm;
     const double t0 = now_s();
     {
         // marginals (and labels) only: the window kernel reads the plan tables (~0.1 MB per chunk, each word once) from the
@@ -394,14 +413,40 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
             return env && env[0] == '1';
         }();
         ln.plan.tables_in_host_memory = !always_copy && !r.want_segments && !X.full && !r.score_out;
+        // copied tables are fetched by a small launch at the head of the chunk's kernels, not by the copy engine: the upload
+        // stream then carries nothing but the chunks' arrays, back to back (a copy issued behind the next chunk's arrays
+        // would hold this chunk's kernels back until those have crossed; every copy also costs ~10 us of engine turnaround)
+        ln.plan.tables_by_kernel = true;
     }
-    if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.up, false))) return rc;
+    if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.comp, false))) return rc;
     if ((X.viterbi || X.full) && (rc = plan_ensure_seq(ln.plan, ln.up, false))) return rc;  // (the refiner builds its contig flags on the device)
     S.stats.host_plan_seconds += now_s() - t0;
     tm.lap("plan_build", chunk_index);
-    if ((rc = check_hip(hipEventRecord(ln.ev_up, ln.up), "hipEventRecord"))) return rc;
+    return check_hip(hipEventRecord(ln.ev_up, ln.up), "hipEventRecord");
+}
+
+int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
+    Session &S = X.S;
+    const BatchRequest &r = X.r;
+    Chunk &ck = X.chunks[chunk_index];
+    const Model &m = *S.model;
+    int rc = check_hip(hipSetDevice(ln.device), "hipSetDevice");
+    if (rc) return rc;
+    const int32_t nc = ck.c1 - ck.c0, ng = ck.g1 - ck.g0;
+    TraceMark tm;
+    ln.chunk = chunk_index;
+    ln.up_chunk = -1;
+    const int64_t a0 = ln.up_a0, b0 = ln.up_b0;
+    const size_t nnz = size_t(ln.up_nnz), L = size_t(m.L);
     if ((rc = check_hip(hipStreamWaitEvent(ln.comp, ln.ev_up, 0), "hipStreamWaitEvent"))) return rc;
     if (ng == 0) return check_hip(hipEventRecord(ln.done, ln.comp), "hipEventRecord");
+    // the wire format's two launches: degree bytes -> row pointers, 16-bit attribute indices -> 32-bit ones
+    if ((r.degree || r.attr_id16) &&
+        (rc = check_hip(launch_wire_format(r.degree ? reinterpret_cast<const uint8_t *>(ln.d_deg.p) : nullptr, int(ng), int32_t(a0),
+                                           reinterpret_cast<int32_t *>(ln.d_gp.p), reinterpret_cast<int32_t *>(ln.d_deg_ws.p),
+                                           r.attr_id16 ? reinterpret_cast<const uint16_t *>(ln.d_at16.p) : nullptr, int64_t(nnz),
+                                           reinterpret_cast<int32_t *>(ln.d_at.p), ln.comp), "wire format launch")))
+        return rc;
     // gene_ptr keeps the caller's offsets: the attribute array is addressed from where its element 0 would be
     const int32_t *d_gp = reinterpret_cast<const int32_t *>(ln.d_gp.p);
     const int32_t *d_at = reinterpret_cast<const int32_t *>(ln.d_at.p) - a0;
@@ -615,8 +660,12 @@ int session_run(Session &S, const BatchRequest &r) {
         set_error("the antismash criterion needs the genes' marker domains");
         return GECCO_CRF_EINVAL;
     }
-    if (n_genes > 0 && r.gene_ptr[n_genes] > r.gene_ptr[0] && !r.attr_id) {
+    if (n_genes > 0 && r.gene_ptr[n_genes] > r.gene_ptr[0] && !r.attr_id && !r.attr_id16) {
         set_error("null buffer");
+        return GECCO_CRF_EINVAL;
+    }
+    if (r.attr_id16 && S.model->A > 65536) {
+        set_error("16-bit attribute indices need a model with at most 65536 attributes");
         return GECCO_CRF_EINVAL;
     }
     std::lock_guard<std::mutex> lock(S.mu);
@@ -637,7 +686,10 @@ int session_run(Session &S, const BatchRequest &r) {
     RunCtx X{S, r, chunks, windowed, viterbi, full, windowed ? r.window : 1, windowed ? r.step : 1, windowed ? r.pad : 1};
     // (every lane is idle here: start from lane 0 again, so that calls of a chunk or two keep to the lanes whose buffers and
     // workspaces exist already instead of walking the ring and allocating in each of its lanes in turn)
-    for (auto &d : S.devs) d->next_lane = 0;
+    for (auto &d : S.devs) {
+        d->next_lane = 0;
+        for (Lane &ln : d->lanes) ln.up_chunk = -1;
+    }
     // per-device queues in batch order; devices are fed round-robin so that all of them start at once
     std::vector<std::vector<int>> queue(S.devs.size());
     for (size_t i = 0; i < chunks.size(); ++i) queue[size_t(chunks[i].device_slot)].push_back(int(i));
@@ -652,7 +704,14 @@ int session_run(Session &S, const BatchRequest &r) {
             Lane &ln = D.lanes[D.next_lane];
             D.next_lane = (D.next_lane + 1) % kLanes;
             if ((rc = retire(X, ln))) break;
-            rc = submit(X, D, ln, queue[d][head[d]++]);
+            const int mine = queue[d][head[d]++];
+            if (ln.up_chunk != mine && (rc = submit_uploads(X, ln, mine))) break;
+            if ((rc = submit_plan(X, ln, mine))) break;
+            // the next chunk's arrays follow this one's arrays and tables through the copy engine, if the lane they go to is
+            // idle: they are on their way while the host launches this chunk and lays out the next
+            Lane &nl = D.lanes[D.next_lane];
+            if (head[d] < queue[d].size() && &nl != &ln && nl.chunk < 0 && (rc = submit_uploads(X, nl, queue[d][head[d]]))) break;
+            rc = submit(X, D, ln, mine);
         }
     }
     for (auto &d : S.devs) {

@@ -23,6 +23,9 @@ struct BatchRequest {
     // given, the degrees are what crosses PCIe (1 instead of 4 bytes per gene) and the row pointers are rebuilt on the
     // device; gene_ptr is then only read at chunk boundaries, on the host.
     const uint8_t *degree = nullptr;
+    // optional wire format: the attribute indices as 16-bit words (a model with at most 65536 attributes; GECCO's has 2766)
+    // instead of attr_id: 2 instead of 4 bytes per domain cross PCIe, widened on the device
+    const uint16_t *attr_id16 = nullptr;
     int32_t window = 1, step = 1, label = 0, pad = 1;
     // what to compute, by output (null = not wanted)
     double *p_out = nullptr;        // [n_genes]      windowed marginals (row W)

@@ -284,6 +284,16 @@ int gecco_crf_session_clusters_degrees(gecco_crf_session *s, const int32_t *cont
                                        int32_t max_seg, int32_t *n_seg, double *seg_p_out, int64_t max_seg_genes,
                                        int64_t *seg_off_out);
 
+/* gecco_crf_session_clusters_degrees with one more option of the wire format: `attr_id16` (or NULL), the attribute indices
+ * as 16-bit words, read instead of attr_id -- for a model with at most 65536 attributes (GECCO's has 2766; EINVAL
+ * otherwise).  2 instead of 4 bytes per domain cross PCIe and are widened on the device.  Same rows, same probabilities. */
+int gecco_crf_session_clusters_wire(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                    const int32_t *gene_ptr, const uint8_t *degree, const int32_t *attr_id,
+                                    const uint16_t *attr_id16, const uint8_t *annotated, int32_t window, int32_t step,
+                                    int32_t label, int32_t pad, const gecco_crf_refine_params *params, double *p_out,
+                                    int32_t *seg_out, int32_t max_seg, int32_t *n_seg, double *seg_p_out,
+                                    int64_t max_seg_genes, int64_t *seg_off_out);
+
 /* ---- columnar host side: table columns -> CSR batch, called clusters -> clusters.tsv rows --------
  * Strings travel as Arrow-style columns: one byte buffer + int64 offsets[n+1] per column (what
  * pandas / polars / pyarrow hold them in).  gecco_crf_pack_columns does, on columns, what the reference

@@ -320,6 +320,11 @@ def test_degree_byte_wire_format_equals_row_pointers(nat, real_model, oracle_mod
             # ... and `annotated` may be left to the degree bytes when it is "has a domain the model knows"
             r2 = ses.clusters(cptr, gptr, attr, None, 20, threshold=thr, degree=deg)
             assert r0[0].tolist() == r2[0].tolist() and np.array_equal(r0[1], r2[1])
+            # ... and the attribute indices may cross as 16-bit words (gecco_crf_session_clusters_wire), pageable or pinned
+            r3 = ses.clusters(cptr, gptr, attr.astype(np.uint16), None, 20, threshold=thr, degree=deg)
+            r4 = ses.clusters(cp, gp, nat.pinned_copy(attr, np.uint16), None, 20, threshold=thr, degree=dg)
+            for r in (r3, r4):
+                assert r0[0].tolist() == r[0].tolist() and np.array_equal(r0[1], r[1]) and np.array_equal(r0[2], r[2])
     with pytest.raises(ValueError):
         nat.degree_bytes(np.array([0, 300], dtype=np.int32))
     # degree bytes that do not add up to the row pointers are refused (the device would read attributes out of bounds)

@@ -20,6 +20,12 @@ for i in range(6):
     ses.clusters(cp, gp, at, None, 20, want_p=False, want_seg_p=False, degree=deg)
     print("call %d: %.3f ms" % (i, (time.perf_counter() - t0) * 1e3), ses.stats())
     time.sleep(0.01)
+at16 = nat.pinned_copy(wl["attr_id"], np.uint16)
+for i in range(6):
+    t0 = time.perf_counter()
+    ses.clusters(cp, gp, at16, None, 20, want_p=False, want_seg_p=False, degree=deg)
+    print("16-bit indices, call %d: %.3f ms" % (i, (time.perf_counter() - t0) * 1e3), ses.stats())
+    time.sleep(0.01)
 for i in range(4):
     t0 = time.perf_counter()
     ses.clusters(cp, gp, at, None, 20, want_p=False, want_seg_p=True, degree=deg)
