@@ -92,10 +92,11 @@ template <class E>
 __device__ __forceinline__ E wave_shift_up(const E &id, const E &v) {  // lane l <- lane l-1, lane 0 <- id
     return dpp_elem<0x138, 0xF>(id, v);                                 // wave_shr:1
 }
-// Workgroup-wide EXCLUSIVE scan of one element per lane (kT lanes); *total = product of all.
+// Workgroup-wide EXCLUSIVE scan of one element per lane (kT lanes); *total = product of all (total may be nullptr).
 template <class Op, bool REV, class E, int NTH = kScanThreads>
 __device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /* NTH/64 */, E *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index as a scalar: `w < wave` below is then a branch, not a select per component of E per wave)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     const E id = Op::identity();
     const E incl = wave_scan_inclusive<Op, REV>(mine);
     if (lane == 63) lds_totals[wave] = incl;
@@ -106,10 +107,10 @@ __device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /
     for (int w = 0; w < NTH / 64; ++w) {
         const E t = lds_totals[w];
         if (w < wave) pre = comb<Op, REV>(pre, t);
-        all = comb<Op, REV>(all, t);
+        if (total) all = comb<Op, REV>(all, t);  // (a caller that has no use for the total passes nullptr)
     }
     __syncthreads();  // lds_totals may be reused by the caller
-    *total = all;
+    if (total) *total = all;
     return comb<Op, REV>(pre, excl);
 }
 
@@ -120,7 +121,7 @@ __device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /
 // through LDS around a forward scan.  `lds_totals` must not be reused before the next barrier of the caller.
 template <class Op, int NTH = kScanThreads>
 __device__ __forceinline__ uint32_t block_scan_exclusive_back(uint32_t mine, uint32_t *lds_totals /* NTH/64 */, uint32_t *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     const uint32_t id = Op::identity();
     const int mirror = (63 - lane) << 2;
     const uint32_t m = uint32_t(__builtin_amdgcn_ds_bpermute(mirror, int(mine)));

@@ -36,6 +36,22 @@ __device__ __forceinline__ double vd_min(double a, double b) {
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// ... against a wave-uniform bound: the second operand straight from its SGPR pair (a "v" operand would cost a v_mov_b64 per use)
+__device__ __forceinline__ double vd_max_s(double a, double bound) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(bound));
+    return r;
+}
+__device__ __forceinline__ double vd_min_s(double a, double bound) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(bound));
+    return r;
+}
+// acc = 2 acc + (x > bound): the comparison's result is the carry of an add-with-carry -- two instructions per decision bit
+// instead of compare, select, shift-or
+__device__ __forceinline__ void vd_shift_in_gt(uint32_t &acc, double x, double bound) {
+    asm("v_cmp_lt_f64 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x), "s"(bound) : "vcc");
+}
 struct COp {
     static __device__ __forceinline__ CE identity() { return CE{0.0, -__builtin_huge_val(), __builtin_huge_val()}; }
     static __device__ __forceinline__ CE combine(const CE &a, const CE &b) {  // a applied first
@@ -259,12 +275,29 @@ static_assert(sizeof(VdShortSmem) <= 20480, "eight workgroups per CU");
 // (lane i takes entries i, i + 256, ...), padded LDS rows
 __device__ __forceinline__ void load_short(const double *__restrict__ v, int g0, int n, VdShortSmem &stg) {
     const int slot = threadIdx.x;
+    static_assert(kT % kGPL == 0, "entry j * kT + slot lies in row j * (kT / kGPL) + slot / kGPL, column slot % kGPL");
+    // all kGPL loads leave before the first value is used: clamped indices instead of a branch around every load (a
+    // branch per load made each one wait for the one before it)
+    const double *vp = v + g0;
+    double x[kGPL];
 #pragma unroll
-    for (int j = 0; j < kGPL; ++j) {
-        const int idx = j * kT + slot;
-        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = idx < n ? v[g0 + idx] : kVdPad;
-    }
+    for (int j = 0; j < kGPL; ++j) x[j] = vp[max(min(j * kT + slot, n - 1), 0)];
+    double *cell = stg.st + (slot / kGPL) * (kGPL + 1) + slot % kGPL;
+#pragma unroll
+    for (int j = 0; j < kGPL; ++j) cell[j * (kT / kGPL) * (kGPL + 1)] = j * kT + slot < n ? x[j] : kVdPad;
     __syncthreads();
+}
+
+// OR of a 16-bit value over the wave, as a wave-uniform number (DPP row shifts / broadcasts, zero fill; lane 63 ends up
+// with everything)
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+    v |= uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xF, 0xF, true));  // row_shr:1
+    v |= uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xF, 0xF, true));  // row_shr:2
+    v |= uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xF, 0xF, true));  // row_shr:4
+    v |= uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xF, 0xF, true));  // row_shr:8
+    v |= uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xA, 0xF, true));  // row_bcast:15 -> rows 1, 3
+    v |= uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xC, 0xF, true));  // row_bcast:31 -> rows 2, 3
+    return uint32_t(__builtin_amdgcn_readlane(int(v), 63));
 }
 
 // workgroup `blk` of the short-contig decoder (kernel vd_short in crf_sequence.hip; the pipelined decode kernel in
@@ -278,6 +311,9 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     // took eight loads, an LDS round trip and 48 VALU instructions to unpack)
     const uint32_t bits = A.lane_bits[blk * kT + slot];
     const uint32_t first = bits & 0xffu, last = bits >> 8;
+    // contigs are hundreds of genes long: at a given k most waves hold no contig start / end among their 64 genes, and a
+    // wave-uniform test (a scalar branch) spares them the selects -- four v_cndmask_b32 per gene in either pass
+    const uint32_t wave_bits = wave_or_u32(bits);
     load_short(A.dstate, g0, n, stg);
     const int cnt = min(kGPL, n - slot * kGPL);
     // (the lane's values are read from its LDS row in every pass instead of living in 16 VGPRs across the workgroup
@@ -294,13 +330,17 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
         const double dvk = row[k];
         const bool fst = (first >> k) & 1u;
         const double c = A.v_k + dvk;
-        const double l2 = vd_min(vd_max(P.L, A.v_lo), A.v_hi) + c, h2 = vd_min(vd_max(P.H, A.v_lo), A.v_hi) + c;
+        const double l2 = vd_min_s(vd_max_s(P.L, A.v_lo), A.v_hi) + c, h2 = vd_min_s(vd_max_s(P.H, A.v_lo), A.v_hi) + c;
         P.a += c;
-        P.L = fst ? dvk : l2;
-        P.H = fst ? dvk : h2;
+        P.L = l2;
+        P.H = h2;
+        if ((wave_bits >> k) & 1u) {
+            asm volatile("" ::: "memory");  // (keeps the scalar branch: the selects are what it is there to skip)
+            P.L = fst ? dvk : l2;
+            P.H = fst ? dvk : h2;
+        }
     }
-    CE total;
-    const CE M = block_scan_exclusive<COp, false>(P, lds, &total);  // the workgroup starts at a contig start
+    const CE M = block_scan_exclusive<COp, false>(P, lds, static_cast<CE *>(nullptr));  // the workgroup starts at a contig start
     // ---- exact entering values.  M comes from COMPOSED maps: its additions are associated differently from the
     // sequential recursion, so M.L may differ from the sequential Delta in the last bits, and a decision that
     // lies within that noise of a threshold would depend on how the scan happens to be cut.  The clamp FORGETS:
@@ -316,19 +356,35 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
         ulpM = vd_bound(A, double(A.csr_gene_ptr[g0 + n] - A.csr_gene_ptr[g0]), double(n)) * kVdEps;
         margin = vd_margin(double(n), ulpM);
     }
-    uint32_t maps = 0, lane_map = MapOp::identity();
+    // (the same number in every lane: kept in scalar registers, not in four of the 64 vector registers)
+    ulpM = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(ulpM)), __builtin_amdgcn_readfirstlane(__double2loint(ulpM)));
+    margin = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(margin)), __builtin_amdgcn_readfirstlane(__double2loint(margin)));
+    uint32_t maps = 0, lane_map;
     bool sensitive = false;  // some decision of this lane lies within the noise of its threshold
     {
         double Dq = M.L;
 #pragma unroll
         for (int k = 0; k < kGPL; ++k) {
             const double dvk = row[k];
-            Dq = ((first >> k) & 1u) ? dvk : vd_min(vd_max(Dq, A.v_lo), A.v_hi) + (A.v_k + dvk);
-            // a contig's last gene decides the end label: both of its "thresholds" are 0 (maps 3 / 0)
-            const bool lst = (last >> k) & 1u;
-            const double thi = lst ? 0.0 : A.v_hi, tlo = lst ? 0.0 : A.v_lo;
-            maps |= ((Dq > thi ? 1u : 0u) | (Dq > tlo ? 2u : 0u)) << (2 * k);
-            sensitive |= fabs(Dq - thi) <= margin || fabs(Dq - tlo) <= margin;
+            const double stepped = vd_min_s(vd_max_s(Dq, A.v_lo), A.v_hi) + (A.v_k + dvk);
+            Dq = stepped;
+            if ((wave_bits >> k) & 1u) {
+                asm volatile("" ::: "memory");
+                Dq = ((first >> k) & 1u) ? dvk : stepped;
+            }
+            // the gene's decisions (bit 0: Delta > hi, bit 1: Delta > lo) enter `maps` from the right: gene k ends up in bits
+            // 2 (kGPL - 1 - k) + {0, 1}
+            vd_shift_in_gt(maps, Dq, A.v_lo);
+            vd_shift_in_gt(maps, Dq, A.v_hi);
+            bool sens = fabs(Dq - A.v_hi) <= margin || fabs(Dq - A.v_lo) <= margin;
+            if ((wave_bits >> (8 + k)) & 1u) {
+                // a contig's last gene decides the end label: both of its "thresholds" are 0 (maps 3 / 0)
+                asm volatile("" ::: "memory");
+                const bool lst = (last >> k) & 1u;
+                maps = lst ? ((maps & ~3u) | (Dq > 0.0 ? 3u : 0u)) : maps;
+                sens = lst ? fabs(Dq) <= margin : sens;
+            }
+            sensitive |= sens;
         }
     }
     // (one barrier either way: the workgroup learns whether any of its lanes has to look back)
@@ -395,7 +451,7 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
                 D = fst ? dvk : fmin(fmax(D, A.v_lo), A.v_hi) + (A.v_k + dvk);
                 const bool lst = (last >> k) & 1u;
                 const double thi = lst ? 0.0 : A.v_hi, tlo = lst ? 0.0 : A.v_lo;
-                maps |= ((D > thi ? 1u : 0u) | (D > tlo ? 2u : 0u)) << (2 * k);
+                maps |= ((D > thi ? 1u : 0u) | (D > tlo ? 2u : 0u)) << (2 * (kGPL - 1 - k));
                 const double mr = vd_margin(double(r), ulpM);
                 lane_flagged |= fabs(D - thi) <= mr || fabs(D - tlo) <= mr;
             }
@@ -411,9 +467,17 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     if (wg_sensitive) wg_flagged = __syncthreads_or(lane_flagged ? 1 : 0);
     else __syncthreads();
     uint8_t *yb = reinterpret_cast<uint8_t *>(stg.st);
+    // the lane's eight genes as ONE label map (label after its last gene -> label before its first): both labels are walked
+    // through the genes' maps, back to front -- an or and a bit-field extract per gene and label
+    {
+        uint32_t y0 = 0u, y1 = 1u;
 #pragma unroll
-    for (int k = kGPL - 1; k >= 0; --k)
-        lane_map = MapOp::combine((maps >> (2 * k)) & 3u, lane_map);
+        for (int k = kGPL - 1; k >= 0; --k) {
+            y0 = __builtin_amdgcn_ubfe(maps, uint32_t(2 * (kGPL - 1 - k)) | y0, 1u);
+            y1 = __builtin_amdgcn_ubfe(maps, uint32_t(2 * (kGPL - 1 - k)) | y1, 1u);
+        }
+        lane_map = y0 | (y1 << 1);
+    }
     // back-to-front scan of the lane maps, then the labels: the workgroup ends at a contig end,
     // so the map entering from its right is irrelevant (the last gene's map is constant)
     uint32_t mtotal;
@@ -421,7 +485,7 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     uint64_t packed = 0;
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) {
-        lab = (maps >> (2 * k + lab)) & 1u;
+        lab = __builtin_amdgcn_ubfe(maps, uint32_t(2 * (kGPL - 1 - k)) | lab, 1u);
         packed |= uint64_t(lab) << (8 * k);
     }
     *reinterpret_cast<uint64_t *>(yb + slot * kGPL) = packed;
