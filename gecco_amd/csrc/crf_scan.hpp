@@ -88,17 +88,51 @@ __device__ __forceinline__ E wave_scan_inclusive(E v) {
     v = comb<Op, REV>(dpp_elem<0x143, 0xC>(id, v), v);  // row_bcast:31 -> rows 2,3
     return v;
 }
+// The same scan without the identity: a lane that receives nothing in a step skips the step (an execution mask from one
+// compare on its position) instead of combining with an identity that six v_mov_b32 have to lay down first, and the
+// combine works in place (Op::combine_into(t, v): v = t (x) v, t is scratch) so that the masked step needs no copies
+// either -- 14 instead of 19 vector instructions per step of a three-double element.  For kernels bound by vector issue.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_z(double src) {  // every lane written; lanes without a source read zero
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <class Op>
+__device__ __forceinline__ CE wave_scan_inclusive_masked(CE v) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t col = lane & 15u;
+#define GECCO_MASKED_STEP(CTRL, COND)                                                  \
+    {                                                                                  \
+        CE t{dpp_f64_z<CTRL>(v.a), dpp_f64_z<CTRL>(v.L), dpp_f64_z<CTRL>(v.H)};         \
+        if (COND) Op::combine_into(t, v);                                              \
+    }
+    GECCO_MASKED_STEP(0x111, col >= 1u)           // row_shr:1
+    GECCO_MASKED_STEP(0x112, col >= 2u)           // row_shr:2
+    GECCO_MASKED_STEP(0x114, col >= 4u)           // row_shr:4
+    GECCO_MASKED_STEP(0x118, col >= 8u)           // row_shr:8
+    GECCO_MASKED_STEP(0x142, (lane & 16u) != 0u)  // row_bcast:15, taken by rows 1 and 3
+    GECCO_MASKED_STEP(0x143, lane >= 32u)         // row_bcast:31, taken by rows 2 and 3
+#undef GECCO_MASKED_STEP
+    return v;
+}
 template <class E>
 __device__ __forceinline__ E wave_shift_up(const E &id, const E &v) {  // lane l <- lane l-1, lane 0 <- id
     return dpp_elem<0x138, 0xF>(id, v);                                 // wave_shr:1
 }
 // Workgroup-wide EXCLUSIVE scan of one element per lane (kT lanes); *total = product of all (total may be nullptr).
-template <class Op, bool REV, class E, int NTH = kScanThreads>
+template <class Op, bool REV, class E, int NTH = kScanThreads, bool MASKED = false>
 __device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /* NTH/64 */, E *total) {
     // (the wave index as a scalar: `w < wave` below is then a branch, not a select per component of E per wave)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     const E id = Op::identity();
-    const E incl = wave_scan_inclusive<Op, REV>(mine);
+    E incl;
+    if constexpr (MASKED) {
+        static_assert(!REV, "the masked scan runs in lane order");
+        incl = wave_scan_inclusive_masked<Op>(mine);
+    } else {
+        incl = wave_scan_inclusive<Op, REV>(mine);
+    }
     if (lane == 63) lds_totals[wave] = incl;
     E excl = wave_shift_up(id, incl);
     __syncthreads();

@@ -57,6 +57,20 @@ struct COp {
     static __device__ __forceinline__ CE combine(const CE &a, const CE &b) {  // a applied first
         return CE{a.a + b.a, vd_min(vd_max(a.L + b.a, b.L), b.H), vd_min(vd_max(a.H + b.a, b.L), b.H)};
     }
+    // v = combine(t, v) in place (t is used up): the same seven instructions in an order that needs no copy, for the
+    // masked wave scan (crf_scan.hpp) whose lanes skip a step under an execution mask
+    static __device__ __forceinline__ void combine_into(CE &t, CE &v) {
+        asm volatile(
+            "v_add_f64 %[tl], %[tl], %[a]\n\t"
+            "v_add_f64 %[th], %[th], %[a]\n\t"
+            "v_add_f64 %[a], %[ta], %[a]\n\t"
+            "v_max_f64 %[tl], %[tl], %[L]\n\t"
+            "v_max_f64 %[th], %[th], %[L]\n\t"
+            "v_min_f64 %[L], %[tl], %[H]\n\t"
+            "v_min_f64 %[H], %[th], %[H]"
+            : [a] "+v"(v.a), [L] "+v"(v.L), [H] "+v"(v.H), [tl] "+v"(t.L), [th] "+v"(t.H)
+            : [ta] "v"(t.a));
+    }
 };
 
 // ---- when is a decision of the difference form PROVABLY crf1dc_viterbi's? -----------------------------------------
@@ -277,7 +291,8 @@ __device__ __forceinline__ void load_short(const double *__restrict__ v, int g0,
     const int slot = threadIdx.x;
     static_assert(kT % kGPL == 0, "entry j * kT + slot lies in row j * (kT / kGPL) + slot / kGPL, column slot % kGPL");
     // all kGPL loads leave before the first value is used: clamped indices instead of a branch around every load (a
-    // branch per load made each one wait for the one before it)
+    // branch per load made each one wait for the one before it: +1.2 us on the C3 decode step).  A clamp-free path for the
+    // waves whose entries all exist was measured: no difference
     const double *vp = v + g0;
     double x[kGPL];
 #pragma unroll
@@ -306,7 +321,7 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     CE *lds = stg.tot;
     uint32_t *ldsm = stg.mtot;
     const int slot = threadIdx.x;
-    const int g0 = A.cblk[blk], n = A.cblk[blk + 1] - g0;
+    const int g0 = __builtin_amdgcn_readfirstlane(A.cblk[blk]), n = __builtin_amdgcn_readfirstlane(A.cblk[blk + 1]) - g0;
     // which of the lane's genes start / end a contig: two bytes the host packed per lane (the per-gene flag bytes
     // took eight loads, an LDS round trip and 48 VALU instructions to unpack)
     const uint32_t bits = A.lane_bits[blk * kT + slot];
@@ -340,7 +355,7 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
             P.H = fst ? dvk : h2;
         }
     }
-    const CE M = block_scan_exclusive<COp, false>(P, lds, static_cast<CE *>(nullptr));  // the workgroup starts at a contig start
+    const CE M = block_scan_exclusive<COp, false, CE, kScanThreads, true>(P, lds, static_cast<CE *>(nullptr));  // the workgroup starts at a contig start
     // ---- exact entering values.  M comes from COMPOSED maps: its additions are associated differently from the
     // sequential recursion, so M.L may differ from the sequential Delta in the last bits, and a decision that
     // lies within that noise of a threshold would depend on how the scan happens to be cut.  The clamp FORGETS:

@@ -19,6 +19,7 @@ for round in 1 2 3; do
   one base $L/libgecco_crf.so
   for n in $VARS; do one $n $L/libgecco_crf_$n.so; done
 done | tee $O/ab.txt
+[ "${PMC:-0}" = 1 ] || exit 0  # counters of every build: PMC=1 (minutes per build)
 for t in base $VARS; do
   lib=$L/libgecco_crf.so; [ $t != base ] && lib=$L/libgecco_crf_$t.so
   GECCO_CRF_LIBRARY=$lib tools/pmc_ab.sh r4_$t --no-c4 --no-8d > /dev/null 2>&1
