@@ -121,7 +121,8 @@ __device__ __forceinline__ E wave_shift_up(const E &id, const E &v) {  // lane l
     return dpp_elem<0x138, 0xF>(id, v);                                 // wave_shr:1
 }
 // Workgroup-wide EXCLUSIVE scan of one element per lane (kT lanes); *total = product of all (total may be nullptr).
-template <class Op, bool REV, class E, int NTH = kScanThreads, bool MASKED = false>
+// LAST_USE: the caller does not touch lds_totals again before its next barrier (spares the closing barrier here).
+template <class Op, bool REV, class E, int NTH = kScanThreads, bool MASKED = false, bool LAST_USE = false>
 __device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /* NTH/64 */, E *total) {
     // (the wave index as a scalar: `w < wave` below is then a branch, not a select per component of E per wave)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
@@ -143,7 +144,7 @@ __device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /
         if (w < wave) pre = comb<Op, REV>(pre, t);
         if (total) all = comb<Op, REV>(all, t);  // (a caller that has no use for the total passes nullptr)
     }
-    __syncthreads();  // lds_totals may be reused by the caller
+    if (!LAST_USE) __syncthreads();  // lds_totals may be reused by the caller
     if (total) *total = all;
     return comb<Op, REV>(pre, excl);
 }
@@ -153,8 +154,10 @@ __device__ __forceinline__ E block_scan_exclusive(const E &mine, E *lds_totals /
 // Every wave mirrors its lanes through the LDS crossbar (ds_bpermute: no memory, no barrier), scans forward and mirrors
 // back; the waves' totals meet in LDS in reverse order -- one barrier instead of the four of a mirrored exchange
 // through LDS around a forward scan.  `lds_totals` must not be reused before the next barrier of the caller.
+// `vote` (may be null): in / out, the workgroup-wide OR of the lanes' values rides on the scan's one barrier.
 template <class Op, int NTH = kScanThreads>
-__device__ __forceinline__ uint32_t block_scan_exclusive_back(uint32_t mine, uint32_t *lds_totals /* NTH/64 */, uint32_t *total) {
+__device__ __forceinline__ uint32_t block_scan_exclusive_back(uint32_t mine, uint32_t *lds_totals /* NTH/64 */, uint32_t *total,
+                                                              int *vote = nullptr) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     const uint32_t id = Op::identity();
     const int mirror = (63 - lane) << 2;
@@ -162,7 +165,8 @@ __device__ __forceinline__ uint32_t block_scan_exclusive_back(uint32_t mine, uin
     const uint32_t incl = wave_scan_inclusive<Op, true>(m);
     if (lane == 63) lds_totals[wave] = incl;
     const uint32_t excl = wave_shift_up(id, incl);
-    __syncthreads();
+    if (vote) *vote = __syncthreads_or(*vote);
+    else __syncthreads();
     uint32_t pre = id, all = id;
 #pragma unroll
     for (int w = NTH / 64 - 1; w >= 0; --w) {

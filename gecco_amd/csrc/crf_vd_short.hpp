@@ -285,22 +285,21 @@ struct VdShortSmem {
     uint32_t mtot[kT / 64];
 };
 static_assert(sizeof(VdShortSmem) <= 20480, "eight workgroups per CU");
-// genes [g0, g0 + n) of the workgroup -> the lanes that own 8 consecutive ones; coalesced global accesses
-// (lane i takes entries i, i + 256, ...), padded LDS rows
-__device__ __forceinline__ void load_short(const double *__restrict__ v, int g0, int n, VdShortSmem &stg) {
-    const int slot = threadIdx.x;
-    static_assert(kT % kGPL == 0, "entry j * kT + slot lies in row j * (kT / kGPL) + slot / kGPL, column slot % kGPL");
-    // all kGPL loads leave before the first value is used: clamped indices instead of a branch around every load (a
-    // branch per load made each one wait for the one before it: +1.2 us on the C3 decode step).  A clamp-free path for the
-    // waves whose entries all exist was measured: no difference
+// genes [g0, g0 + n) of the workgroup -> the lanes that own kGPL consecutive ones.  A lane loads ITS OWN genes (64
+// consecutive bytes; a wave's loads cover 4 KB between them, every line used whole) and parks them in its padded LDS row
+// for the later passes: no exchange between lanes, so no barrier (until round 4: coalesced loads, a transposition through
+// LDS and a barrier).  All loads leave before the first value is used: clamped indices, not a branch around every load.
+__device__ __forceinline__ void load_short(const double *__restrict__ v, int g0, int n, VdShortSmem &stg, double (&x)[kGPL]) {
+    const int base = int(threadIdx.x) * kGPL;
     const double *vp = v + g0;
-    double x[kGPL];
 #pragma unroll
-    for (int j = 0; j < kGPL; ++j) x[j] = vp[max(min(j * kT + slot, n - 1), 0)];
-    double *cell = stg.st + (slot / kGPL) * (kGPL + 1) + slot % kGPL;
+    for (int k = 0; k < kGPL; ++k) x[k] = vp[max(min(base + k, n - 1), 0)];
+    double *row = stg.st + threadIdx.x * (kGPL + 1);
 #pragma unroll
-    for (int j = 0; j < kGPL; ++j) cell[j * (kT / kGPL) * (kGPL + 1)] = j * kT + slot < n ? x[j] : kVdPad;
-    __syncthreads();
+    for (int k = 0; k < kGPL; ++k) {
+        x[k] = base + k < n ? x[k] : kVdPad;
+        row[k] = x[k];
+    }
 }
 
 // OR of a 16-bit value over the wave, as a wave-uniform number (DPP row shifts / broadcasts, zero fill; lane 63 ends up
@@ -329,10 +328,11 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     // contigs are hundreds of genes long: at a given k most waves hold no contig start / end among their 64 genes, and a
     // wave-uniform test (a scalar branch) spares them the selects -- four v_cndmask_b32 per gene in either pass
     const uint32_t wave_bits = wave_or_u32(bits);
-    load_short(A.dstate, g0, n, stg);
+    double x[kGPL];
+    load_short(A.dstate, g0, n, stg, x);
     const int cnt = min(kGPL, n - slot * kGPL);
-    // (the lane's values are read from its LDS row in every pass instead of living in 16 VGPRs across the workgroup
-    // scans: the body has to fit the 64 registers of the pipelined decode kernel)
+    // (the first pass takes the lane's values as they arrive; the later ones read them from its LDS row instead of keeping
+    // them in 16 VGPRs across the workgroup scans: the body has to fit the 64 registers of the pipelined decode kernel)
     const double *row = stg.st + slot * (kGPL + 1);
     // The lane's eight genes as ONE map x -> min(max(x + a, L), H): applying gene k to the map built so far is
     //   a += c_k;  L = clamp(L, lo, hi) + c_k;  H = clamp(H, lo, hi) + c_k      (c_k = (t11 - t00) + d_k)
@@ -342,7 +342,7 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
     CE P = COp::identity();
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
-        const double dvk = row[k];
+        const double dvk = x[k];
         const bool fst = (first >> k) & 1u;
         const double c = A.v_k + dvk;
         const double l2 = vd_min_s(vd_max_s(P.L, A.v_lo), A.v_hi) + c, h2 = vd_min_s(vd_max_s(P.H, A.v_lo), A.v_hi) + c;
@@ -355,7 +355,7 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
             P.H = fst ? dvk : h2;
         }
     }
-    const CE M = block_scan_exclusive<COp, false, CE, kScanThreads, true>(P, lds, static_cast<CE *>(nullptr));  // the workgroup starts at a contig start
+    const CE M = block_scan_exclusive<COp, false, CE, kScanThreads, true, true>(P, lds, static_cast<CE *>(nullptr));  // the workgroup starts at a contig start
     // ---- exact entering values.  M comes from COMPOSED maps: its additions are associated differently from the
     // sequential recursion, so M.L may differ from the sequential Delta in the last bits, and a decision that
     // lies within that noise of a threshold would depend on how the scan happens to be cut.  The clamp FORGETS:
@@ -402,9 +402,26 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
             sensitive |= sens;
         }
     }
-    // (one barrier either way: the workgroup learns whether any of its lanes has to look back)
+    // the lane's eight genes as ONE label map (label after its last gene -> label before its first): both labels are walked
+    // through the genes' maps, back to front -- an or and a bit-field extract per gene and label
+    auto label_map = [&]() {
+        uint32_t y0 = 0u, y1 = 1u;
+#pragma unroll
+        for (int k = kGPL - 1; k >= 0; --k) {
+            y0 = __builtin_amdgcn_ubfe(maps, uint32_t(2 * (kGPL - 1 - k)) | y0, 1u);
+            y1 = __builtin_amdgcn_ubfe(maps, uint32_t(2 * (kGPL - 1 - k)) | y1, 1u);
+        }
+        return y0 | (y1 << 1);
+    };
+    // back-to-front scan of the lane maps: the workgroup ends at a contig end, so the map entering from its right is
+    // irrelevant (the last gene's map is constant).  Whether any lane of the workgroup has to look back rides on the
+    // scan's barrier; in a workgroup where one has to (rare), the scan is repeated on the rebuilt decisions below.
     const bool lane_sensitive = sensitive && A.v_exact;
-    const bool wg_sensitive = __syncthreads_or(lane_sensitive ? 1 : 0);
+    int vote = lane_sensitive ? 1 : 0;
+    uint32_t mtotal;
+    lane_map = label_map();
+    uint32_t lab = block_scan_exclusive_back<MapOp>(lane_map, ldsm, &mtotal, &vote) & 1u;
+    const bool wg_sensitive = vote != 0;
     if (wg_sensitive) {
         // marks for the walk: per gene 1 = beyond hi, 2 = beyond lo (after this gene), 0 = inside or too close to tell
         double Dq = M.L;
@@ -476,39 +493,33 @@ __device__ __forceinline__ void vd_short_block(const SeqArgs &A, const int blk, 
             if (lane_flagged) atomicAdd(A.vd_stats + 1, 1u);
         }
     }
-    // values and marks have been read: the label bytes go over the first rows of `st` below.  (One barrier either way; a
-    // workgroup with candidates learns here whether any of them stayed inside its own margin.)
+    // (a workgroup with candidates learns here whether any of them stayed inside its own margin, and scans the rebuilt
+    // maps: the barrier of the vote also separates the two uses of the scan's LDS words)
     bool wg_flagged = false;
-    if (wg_sensitive) wg_flagged = __syncthreads_or(lane_flagged ? 1 : 0);
-    else __syncthreads();
-    uint8_t *yb = reinterpret_cast<uint8_t *>(stg.st);
-    // the lane's eight genes as ONE label map (label after its last gene -> label before its first): both labels are walked
-    // through the genes' maps, back to front -- an or and a bit-field extract per gene and label
-    {
-        uint32_t y0 = 0u, y1 = 1u;
-#pragma unroll
-        for (int k = kGPL - 1; k >= 0; --k) {
-            y0 = __builtin_amdgcn_ubfe(maps, uint32_t(2 * (kGPL - 1 - k)) | y0, 1u);
-            y1 = __builtin_amdgcn_ubfe(maps, uint32_t(2 * (kGPL - 1 - k)) | y1, 1u);
-        }
-        lane_map = y0 | (y1 << 1);
+    if (wg_sensitive) {
+        wg_flagged = __syncthreads_or(lane_flagged ? 1 : 0);
+        lane_map = label_map();
+        lab = block_scan_exclusive_back<MapOp>(lane_map, ldsm, &mtotal) & 1u;
     }
-    // back-to-front scan of the lane maps, then the labels: the workgroup ends at a contig end,
-    // so the map entering from its right is irrelevant (the last gene's map is constant)
-    uint32_t mtotal;
-    uint32_t lab = block_scan_exclusive_back<MapOp>(lane_map, ldsm, &mtotal) & 1u;
     uint64_t packed = 0;
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) {
         lab = __builtin_amdgcn_ubfe(maps, uint32_t(2 * (kGPL - 1 - k)) | lab, 1u);
         packed |= uint64_t(lab) << (8 * k);
     }
-    *reinterpret_cast<uint64_t *>(yb + slot * kGPL) = packed;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kGPL; ++j) {
-        const int idx = j * kT + slot;
-        if (idx < n) A.y[g0 + idx] = int8_t(yb[idx]);
+    // a lane's eight labels are eight consecutive bytes of the output, a wave's 512: one 8-byte store per lane (at whatever
+    // alignment the contig happens to start: the hardware takes unaligned global accesses); the workgroup's last lane
+    // with genes may own fewer than eight
+    {
+        struct __attribute__((packed)) Bytes8 {
+            uint64_t v;
+        };
+        int8_t *yp = A.y + g0 + slot * kGPL;
+        if (cnt >= kGPL) {
+            reinterpret_cast<Bytes8 *>(yp)->v = packed;
+        } else {
+            for (int k = 0; k < cnt; ++k) yp[k] = int8_t(packed >> (8 * k));
+        }
     }
     // ---- contigs with a decision inside the margin: CRFsuite's own recursion decides (exact_delta_contig).  The
     // sensitive lanes mark the first genes of the contigs they touch; the workgroup then takes the marked contigs one by one.
