@@ -116,6 +116,10 @@ SIGNATURES = {
         [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_u8p, _c_i32p, _c_u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
          _vp, _c_f64p, _c_i32p, ctypes.c_int32, _c_i32p, _c_f64p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)],
     ),
+    "gecco_crf_session_decode_wire": (
+        ctypes.c_int,
+        [_vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
+    ),
     "gecco_crf_session_clusters_wire": (
         ctypes.c_int,
         # (array arguments as plain addresses: a typed ctypes pointer costs 3.5 us to make, an address half of that)
@@ -717,17 +721,28 @@ class Session:
                                                     _ptr(out, _c_f64p)))
         return out[:n]
 
-    def decode(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True, out_p=None, out_y=None):
+    def decode(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True, out_p=None, out_y=None, degree=None,
+               labels=True):
         """Windowed marginals + whole-contig Viterbi labels of a batch in host memory; `out_p` / `out_y`: caller buffers
-        (pinned ones make the downloads asynchronous)."""
+        (pinned ones make the downloads asynchronous).  The compact wire format (gecco_crf_session_decode_wire): `degree`
+        = the genes' domain counts as uint8 (`degree_bytes(gene_ptr)`), sent instead of the row pointers; `attr_id` as a
+        uint16 array (a model with at most 65536 attributes) crosses PCIe as it is.  `labels=False`: marginals only
+        (returns (p, None))."""
+        attr16 = None
+        if isinstance(attr_id, np.ndarray) and attr_id.dtype == np.uint16:
+            attr16 = np.ascontiguousarray(attr_id) if attr_id.size else np.zeros(1, dtype=np.uint16)
+            attr_id = np.zeros(1, dtype=np.int32)
         contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
         p = np.empty(max(n, 1), dtype=np.float64) if out_p is None else out_p
-        y = np.empty(max(n, 1), dtype=np.int8) if out_y is None else out_y
-        assert p.dtype == np.float64 and y.dtype == np.int8 and p.size >= n and y.size >= n
-        _check(self._lib.gecco_crf_session_decode(self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p),
-                                                  _ptr(attr_id, _c_i32p), int(window), int(step), int(label), int(bool(pad)),
-                                                  _ptr(p, _c_f64p), _ptr(y, _c_i8p)))
-        return p[:n], y[:n]
+        y = (np.empty(max(n, 1), dtype=np.int8) if out_y is None else out_y) if labels else None
+        assert p.dtype == np.float64 and p.size >= n and (y is None or (y.dtype == np.int8 and y.size >= n))
+        if degree is not None:
+            assert degree.dtype == np.uint8 and degree.flags.c_contiguous and degree.size >= n
+        adr = lambda a: None if a is None or a.size == 0 else a.ctypes.data  # noqa: E731
+        _check(self._lib.gecco_crf_session_decode_wire(
+            self._h, adr(contig_ptr), nc, adr(gene_ptr), adr(degree), adr(attr_id) if attr16 is None else None, adr(attr16),
+            int(window), int(step), int(label), int(bool(pad)), p.ctypes.data, None if y is None else y.ctypes.data))
+        return p[:n], (None if y is None else y[:n])
 
     def clusters(self, contig_ptr, gene_ptr, attr_id, annotated, window, step=1, label=1, pad=True, threshold=0.8, n_cds=3,
                  edge_distance=0, trim=True, want_p=False, want_seg_p=True, p_out=None, criterion="gecco", n_biopfams=5,

@@ -445,6 +445,22 @@ gecco_crf_refine_params gecco_params(double threshold, int32_t n_cds, int32_t ed
 }
 }  // namespace
 
+GECCO_API int gecco_crf_session_decode_wire(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                            const int32_t *gene_ptr, const uint8_t *degree, const int32_t *attr_id,
+                                            const uint16_t *attr_id16, int32_t window, int32_t step, int32_t label, int32_t pad,
+                                            double *p_out, int8_t *y_out) {
+    if (!s || !p_out) return GECCO_CRF_EINVAL;
+    BatchRequest r = csr_request(contig_ptr, n_contigs, gene_ptr, attr_id);
+    r.degree = degree;
+    r.attr_id16 = attr_id16;
+    r.window = window;
+    r.step = step;
+    r.label = label;
+    r.pad = pad;
+    r.p_out = p_out;
+    r.y_out = y_out;
+    return run_guarded(*s->s, r);
+}
 GECCO_API int gecco_crf_session_clusters_ex(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
                                             const int32_t *gene_ptr, const int32_t *attr_id, const uint8_t *annotated,
                                             int32_t window, int32_t step, int32_t label, int32_t pad,

@@ -248,6 +248,9 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
 size_t degree_scratch_bytes(int n);
 hipError_t launch_degree_to_row_ptr(const uint8_t *d_deg, int n, int32_t base, int32_t *d_row_ptr, int32_t *d_scratch, hipStream_t stream);
 
+// flags[g] for g in [0, n_genes + 8): bit 0 = first gene of its contig, bit 1 = last (d_flags 8-byte aligned, room for
+// n_genes + 16 bytes; d_cptr in device memory: every lane searches it)
+hipError_t launch_contig_flags(const int32_t *d_cptr, int n_contigs, int n_genes, uint8_t *d_flags, hipStream_t stream);
 // `bytes` (a multiple of 16, 16-byte aligned both sides) from device-visible memory -- a pinned host block -- to device memory
 hipError_t launch_copy_block(const void *src, void *dst, size_t bytes, hipStream_t stream);
 // both halves of the wire format in two launches: the row pointers (d_deg may be null: none) and, with d_attr16, nnz 16-bit

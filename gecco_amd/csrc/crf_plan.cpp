@@ -746,20 +746,16 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
         }
     }
     const size_t n_lane_bits = size_t(p.n_cblocks) * 256;  // short contigs: per lane of every workgroup, which of its 8 genes start / end a contig
-    const size_t o_flags = 0, o_blk = align256p(n + 8), o_rank = o_blk + align256p((cblk.size() + 1) * 4),
+    // uploaded: the workgroup tables, the lane bits and a copy of the contig table; NOT uploaded: the byte per gene that
+    // says "first / last gene of its contig" -- a launch behind the copy derives it from the contig table on the device
+    // (two thirds of the block's bytes: 0.5 of 0.77 MB per half-million-gene chunk of the batch driver)
+    const size_t o_blk = 0, o_rank = o_blk + align256p((cblk.size() + 1) * 4),
                  o_ne = o_rank + align256p((rank.size() + 1) * 4), o_lb = o_ne + align256p((ne.size() + 1) * 4),
                  o_fb = o_lb + align256p(n_lane_bits * 2 + 2), n_flat_bits = ((n + kSeqBlockGenes - 1) / kSeqBlockGenes) * 256,
-                 bytes = o_fb + align256p(n_flat_bits * 2 + 2);
-    if ((rc = p.seq.reserve(bytes, "contig flags"))) return rc;
-    uint8_t *flags = reinterpret_cast<uint8_t *>(p.seq.h + o_flags);
-    std::memset(flags, 0, n + 8);
-    for (int32_t c = 0; c < p.n_contigs; ++c) {
-        const int32_t g0 = p.contig_ptr[c], g1 = p.contig_ptr[c + 1];
-        if (g1 > g0) {
-            flags[g0] |= 1;
-            flags[g1 - 1] |= 2;
-        }
-    }
+                 o_cp = o_fb + align256p(n_flat_bits * 2 + 2), bytes = o_cp + align256p((size_t(p.n_contigs) + 1) * 4),
+                 o_flags = bytes, all_bytes = o_flags + align256p(n + 16);
+    if ((rc = p.seq.reserve(all_bytes, "contig flags"))) return rc;
+    if (p.n_contigs) std::memcpy(p.seq.h + o_cp, p.contig_ptr.data(), (size_t(p.n_contigs) + 1) * 4);
     if (n_flat_bits) {
         // the flat layout (long contigs): lane l of the batch owns genes 8 l .. 8 l + 7
         uint16_t *fb = reinterpret_cast<uint16_t *>(p.seq.h + o_fb);
@@ -809,7 +805,16 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
     p.d_seq_flat_bits = reinterpret_cast<const uint16_t *>(p.seq.d + o_fb);
     // launches that read the tables must be ordered behind this copy: `sync` (any stream may follow), or the
     // caller keeps to `stream` (the batch driver)
-    if ((rc = check_hip(hipMemcpyAsync(p.seq.d, p.seq.h, bytes, hipMemcpyHostToDevice, stream), "upload contig flags"))) return rc;
+    if (p.tables_by_kernel && !sync) {  // (batch driver: fetched by a launch, the copy engine keeps to the chunks' arrays)
+        void *dv = nullptr;
+        if ((rc = check_hip(hipHostGetDevicePointer(&dv, p.seq.h, 0), "hipHostGetDevicePointer"))) return rc;
+        if ((rc = check_hip(launch_copy_block(dv, p.seq.d, bytes, stream), "contig tables launch"))) return rc;
+    } else if ((rc = check_hip(hipMemcpyAsync(p.seq.d, p.seq.h, bytes, hipMemcpyHostToDevice, stream), "upload contig flags"))) {
+        return rc;
+    }
+    if ((rc = check_hip(launch_contig_flags(reinterpret_cast<const int32_t *>(p.seq.d + o_cp), p.n_contigs, p.n_genes, p.d_seq_flags, stream),
+                        "contig flags launch")))
+        return rc;
     if (sync && (rc = check_hip(hipStreamSynchronize(stream), "upload contig flags"))) return rc;
     p.seq_ready = true;
     return GECCO_CRF_OK;

@@ -513,6 +513,13 @@ __global__ void __launch_bounds__(kDegT) wire_row_ptr(const uint8_t *__restrict_
 }
 }  // namespace
 
+hipError_t launch_contig_flags(const int32_t *d_cptr, int n_contigs, int n_genes, uint8_t *d_flags, hipStream_t stream) {
+    if (n_genes < 0 || n_contigs < 0) return hipErrorInvalidValue;
+    if (n_contigs == 0 || n_genes == 0) return hipMemsetAsync(d_flags, 0, size_t(n_genes) + 8, stream);
+    hipLaunchKernelGGL(seg_flags, dim3(unsigned((size_t(n_genes) / 8 + 1 + kT - 1) / kT)), dim3(kT), 0, stream, d_cptr, n_contigs, n_genes, d_flags);
+    return hipGetLastError();
+}
+
 namespace {
 __global__ void __launch_bounds__(256) copy_block(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
     const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;

@@ -419,7 +419,8 @@ int submit_plan(RunCtx &X, Lane &ln, int chunk_index) {
         ln.plan.tables_by_kernel = true;
     }
     if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.comp, false))) return rc;
-    if ((X.viterbi || X.full) && (rc = plan_ensure_seq(ln.plan, ln.up, false))) return rc;  // (the refiner builds its contig flags on the device)
+    // (the whole-contig tables too are fetched by a launch on the compute stream; the refiner builds its contig flags on the device)
+    if ((X.viterbi || X.full) && (rc = plan_ensure_seq(ln.plan, ln.comp, false))) return rc;
     S.stats.host_plan_seconds += now_s() - t0;
     tm.lap("plan_build", chunk_index);
     return check_hip(hipEventRecord(ln.ev_up, ln.up), "hipEventRecord");

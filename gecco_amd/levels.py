@@ -51,6 +51,14 @@ def host_buffer_levels(model, wl, devices=(0,), reps=5, W=20):
                             "note": "the metric's own step at this level (gecco_crf_session_decode): windowed marginals + Viterbi labels, "
                                     "pinned buffers in and out; one pipelined launch per chunk (window tiles + the Viterbi workgroups "
                                     "of the chunk before), a flush at the end"}
+    at16 = nat.pinned_copy(wl["attr_id"], np.uint16) if model.num_attrs <= 65536 else None
+    if at16 is not None:
+        dt = _timed(lambda: ses.decode(cp, gp, at16, W, out_p=outp, out_y=outy, degree=deg), reps)
+        st = ses.stats()
+        out["decode_pinned_wire16"] = {
+            "ms": dt * 1e3, "genes_per_s": n / dt, "chunks": st["n_chunks"], "h2d_mb": st["h2d_bytes"] / 1e6, "d2h_mb": st["d2h_bytes"] / 1e6,
+            "note": "the same with the compact wire format (gecco_crf_session_decode_wire): a degree byte per gene and 16-bit "
+                    "attribute indices cross PCIe, row pointers and 32-bit indices are rebuilt on the device"}
     ann = nat.pinned_copy((np.diff(wl["gene_ptr"]) > 0).astype(np.uint8))
     # (`annotated` left to the degree bytes: here a gene is annotated iff it has a domain, which is what they say)
     dt = _timed(lambda: ses.clusters(cp, gp, at, None, W, want_p=False, want_seg_p=False, degree=deg), reps)
@@ -60,8 +68,7 @@ def host_buffer_levels(model, wl, devices=(0,), reps=5, W=20):
                                    "h2d_mb": h2d / 1e6,
                                    "note": "marginals + refiner on the device, degree bytes on the wire (gecco_crf_session_clusters_degrees); "
                                            "only the cluster rows come back"}
-    if model.num_attrs <= 65536:
-        at16 = nat.pinned_copy(wl["attr_id"], np.uint16)
+    if at16 is not None:
         dt = _timed(lambda: ses.clusters(cp, gp, at16, None, W, want_p=False, want_seg_p=False, degree=deg), reps)
         out["cluster_calls_pinned_wire16"] = {
             "ms": dt * 1e3, "genes_per_s": n / dt, "clusters": int(len(seg)), "h2d_mb": ses.stats()["h2d_bytes"] / 1e6,

@@ -254,6 +254,14 @@ int gecco_crf_session_windowed_degrees(gecco_crf_session *s, const int32_t *cont
 int gecco_crf_session_decode(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
                              const int32_t *gene_ptr, const int32_t *attr_id, int32_t window,
                              int32_t step, int32_t label, int32_t pad, double *p_out, int8_t *y_out);
+/* gecco_crf_session_windowed (y_out NULL) / gecco_crf_session_decode with the compact wire format: `degree` (or NULL) =
+ * the genes' domain counts as bytes, sent instead of the row pointers (gecco_crf_session_windowed_degrees); `attr_id16`
+ * (or NULL) = the attribute indices as 16-bit words, read instead of attr_id, for a model with at most 65536 attributes
+ * (EINVAL otherwise).  Same bits out. */
+int gecco_crf_session_decode_wire(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
+                                  const int32_t *gene_ptr, const uint8_t *degree, const int32_t *attr_id,
+                                  const uint16_t *attr_id16, int32_t window, int32_t step, int32_t label, int32_t pad,
+                                  double *p_out, int8_t *y_out /* or NULL */);
 /* predict_probabilities + ClusterRefiner in one pass, one grouper per contig like the CLI
  * (cli/commands/_common.py:595-625): the probabilities never leave the device unless p_out is given;
  * what comes back is the rows (batch-wide contig / gene indices) and, if seg_p_out is given, the

@@ -325,6 +325,17 @@ def test_degree_byte_wire_format_equals_row_pointers(nat, real_model, oracle_mod
             r4 = ses.clusters(cp, gp, nat.pinned_copy(attr, np.uint16), None, 20, threshold=thr, degree=dg)
             for r in (r3, r4):
                 assert r0[0].tolist() == r[0].tolist() and np.array_equal(r0[1], r[1]) and np.array_equal(r0[2], r[2])
+            # the decode call takes both halves of the wire format too (gecco_crf_session_decode_wire): same bits, same labels
+            p0, y0 = ses.decode(cptr, gptr, attr, 20)
+            p0, y0 = p0.copy(), y0.copy()
+            for a_, d_ in ((attr.astype(np.uint16), deg), (attr, deg), (attr.astype(np.uint16), None)):
+                p1, y1 = ses.decode(cptr, gptr, a_, 20, degree=d_)
+                assert np.array_equal(p0, p1, equal_nan=True) and np.array_equal(y0, y1)
+            outy = nat.pinned_empty(n, np.int8)
+            p2, y2 = ses.decode(cp, gp, nat.pinned_copy(attr, np.uint16), 20, out_p=out, out_y=outy, degree=dg)
+            assert np.array_equal(p0, p2, equal_nan=True) and np.array_equal(y0, y2)
+            p3, none = ses.decode(cp, gp, nat.pinned_copy(attr, np.uint16), 20, out_p=out, degree=dg, labels=False)
+            assert none is None and np.array_equal(p0, p3, equal_nan=True)
     with pytest.raises(ValueError):
         nat.degree_bytes(np.array([0, 300], dtype=np.int32))
     # degree bytes that do not add up to the row pointers are refused (the device would read attributes out of bounds)
