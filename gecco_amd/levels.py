@@ -64,16 +64,21 @@ def host_buffer_levels(model, wl, devices=(0,), reps=5, W=20):
     dt = _timed(lambda: ses.clusters(cp, gp, at, None, W, want_p=False, want_seg_p=False, degree=deg), reps)
     h2d = ses.stats()["h2d_bytes"]
     seg, _, seg_off, _ = ses.clusters(cp, gp, at, ann, W, want_p=False, want_seg_p=True, degree=deg)
-    out["cluster_calls_pinned"] = {"ms": dt * 1e3, "genes_per_s": n / dt, "clusters": int(len(seg)), "genes_in_clusters": int(seg_off[-1]),
-                                   "h2d_mb": h2d / 1e6,
-                                   "note": "marginals + refiner on the device, degree bytes on the wire (gecco_crf_session_clusters_degrees); "
-                                           "only the cluster rows come back"}
+    rows32 = {"ms": dt * 1e3, "genes_per_s": n / dt, "clusters": int(len(seg)), "genes_in_clusters": int(seg_off[-1]), "h2d_mb": h2d / 1e6,
+              "note": "marginals + refiner on the device, degree bytes + 32-bit attribute indices on the wire "
+                      "(gecco_crf_session_clusters_degrees); only the cluster rows come back"}
     if at16 is not None:
+        # the level's own entry is the compact wire format (what a caller in a hurry sends); the 32-bit one sits beside it
         dt = _timed(lambda: ses.clusters(cp, gp, at16, None, W, want_p=False, want_seg_p=False, degree=deg), reps)
-        out["cluster_calls_pinned_wire16"] = {
-            "ms": dt * 1e3, "genes_per_s": n / dt, "clusters": int(len(seg)), "h2d_mb": ses.stats()["h2d_bytes"] / 1e6,
-            "note": "the same with 16-bit attribute indices on the wire as well (gecco_crf_session_clusters_wire; a model with "
-                    "at most 65536 attributes): 3.8 instead of 6.6 bytes per gene cross PCIe, widened on the device"}
+        out["cluster_calls_pinned"] = {
+            "ms": dt * 1e3, "genes_per_s": n / dt, "clusters": int(len(seg)), "genes_in_clusters": int(seg_off[-1]),
+            "h2d_mb": ses.stats()["h2d_bytes"] / 1e6,
+            "note": "marginals + refiner on the device; a degree byte per gene and 16-bit attribute indices cross PCIe "
+                    "(gecco_crf_session_clusters_wire; a model with at most 65536 attributes: 3.8 bytes per gene), row pointers "
+                    "and 32-bit indices are rebuilt on the device; only the cluster rows come back"}
+        out["cluster_calls_pinned_i32"] = rows32
+    else:
+        out["cluster_calls_pinned"] = rows32
     dt = _timed(lambda: ses.clusters(cp, gp, at, ann, W, want_p=False, degree=deg, seg_p_out=outp), reps)
     out["cluster_calls_with_probabilities_pinned"] = {
         "ms": dt * 1e3, "genes_per_s": n / dt, "clusters": int(len(seg)), "genes_in_clusters": int(seg_off[-1]),

@@ -37,7 +37,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES"; do
   n=$(echo $c | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $c -d $O/pmc_c5_$n -o pmc -- python tools/bench_full.py > $O/pmc_c5_$n.log 2>&1
 done
-python tools/prof_summary.py $O "" 2>/dev/null | grep -P "\tPMC\t" | grep -E "f_short|vd_|v_labels|seq_state|seg_|deg_" | cut -c1-200 > $O/pmc_c5.txt
+python tools/prof_summary.py $O "" 2>/dev/null | grep -P "\tPMC\t" | grep -E "f_short|vd_|v_labels|seq_state|seg_|wire_|copy_block" | cut -c1-200 > $O/pmc_c5.txt
 rm -rf $O/pmc_c5_*/
 tail -1 $O/bench_c3_driver.json | cut -c1-300
 ls -la $O | head -50

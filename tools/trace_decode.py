@@ -2,7 +2,8 @@
 prints the batch driver's laps; under `rocprofv3 --kernel-trace --memory-copy-trace` read the result with tools/timeline.py."""
 import os, sys, time
 import numpy as np
-import torch  # noqa
+if os.environ.get("NO_TORCH") != "1":  # NO_TORCH=1: the system HIP runtime instead of the one PyTorch bundles
+    import torch  # noqa
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gecco_amd import _native as nat, synth
 
