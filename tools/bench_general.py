@@ -38,6 +38,13 @@ def main():
     d_gp = torch.from_numpy(gptr).to(dev)
     d_at = torch.from_numpy(attr).to(dev)
     only = [int(v) for v in sys.argv[1:]]  # label counts to run (all, plus the long-contig cases, when none is given)
+    # the same shape five times as large (5 000 contigs, ~1.1 M genes) for the windowed kernels: the C2-sized batch is
+    # 940 workgroups of the matrix-core kernel -- 1.2 residency rounds, i.e. the second round runs a fifth full
+    big = None
+    if not only or os.environ.get("GECCO_BENCH_GENERAL_BIG", "1") == "1":
+        rng_b = np.random.default_rng(synth.SEED + 1)
+        bc, bg, ba = synth.synth_contigs(rng_b, synth.contig_lengths(rng_b, 5000), A)
+        big = (bc, torch.from_numpy(bg).to(dev), torch.from_numpy(ba).to(dev), int(bc[-1]))
     for L in only or (2, 3, 4, 6, 8, 16, 32):
         if L == 2:
             w, trans = synth.synth_model(A, rng)
@@ -57,6 +64,11 @@ def main():
                          ("marginals_full", lambda: plan.run_marginals_full(d_gp.data_ptr(), d_at.data_ptr(), marg.data_ptr()))):
             dt = timed(fn)
             res[name] = {"ms": dt * 1e3, "genes_per_s": n / dt}
+        if big is not None and L > 2:
+            bplan = nat.Plan(model, big[0], 20, 1, True, device=0)
+            bp = torch.zeros(big[3], dtype=torch.float64, device=dev)
+            dt = timed(lambda: bplan.run_windowed(big[1].data_ptr(), big[2].data_ptr(), bp.data_ptr(), L - 1))
+            res["windowed_5000_contigs"] = {"genes": big[3], "ms": dt * 1e3, "genes_per_s": big[3] / dt}
         out[f"L={L}" + (" (2-label model forced onto the general kernels)" if L == 2 else "")] = res
     os.environ.pop("GECCO_CRF_FORCE_GENERAL", None)
     if only:
