@@ -862,7 +862,7 @@ __device__ __forceinline__ FE f_step_e(const SeqArgs &A, double2 e, double m, bo
 // of BASELINE.json's configs[4]).  The flat elements carry the contig flags (FE) whether or not log Z is wanted: the
 // look-back needs them.
 template <bool WANT_Z, int MODE>
-__global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
+__global__ void __launch_bounds__(kT, 4) f_short(const SeqArgs A) {
     constexpr bool FLAT = MODE != 0;
     // with log Z: elements carry exponents, emission maxima and the contig-start flag; without: bare 2x2 products
     using E_t = typename std::conditional<WANT_Z || FLAT, FE, F4>::type;
@@ -870,10 +870,14 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     using OpB = typename std::conditional<WANT_Z || FLAT, FOpB, F4Op>::type;
     constexpr bool ELEM_FE = WANT_Z || FLAT;
     __shared__ E_t lds[kT / 64];
-    __shared__ E_t xch[kT];
     __shared__ struct {
         double2 st[kT * (kGPL + 1)];  // d (and maxima) in, marginals out
-    } stg;  // 36 KB + 14 KB of exchange: three workgroups per CU (the contig flags are read by their owner lanes directly)
+    } stg;
+    // the exchange area of the mirrored scans lies OVER the stage (which is dead between the emissions read from it at the
+    // start and the marginals written to it at the end): 37 KB per workgroup, FOUR of them per CU at <= 128 VGPRs (round 4;
+    // 51 KB and three until then -- C5's 2 442 workgroups took four residency rounds of 768 instead of three of 1 024)
+    E_t *const xch = reinterpret_cast<E_t *>(stg.st);
+    static_assert(sizeof(E_t) * kT <= sizeof(stg.st), "exchange area over the stage");
     const int slot = threadIdx.x;
     const int g0 = FLAT ? int(blockIdx.x) * kBlockGenes : A.cblk[blockIdx.x];
     const int n = FLAT ? min(kBlockGenes, A.n_genes - g0) : A.cblk[blockIdx.x + 1] - g0;
@@ -1053,6 +1057,7 @@ __global__ void __launch_bounds__(kT) f_short(const SeqArgs A) {
     xch[kT - 1 - slot] = bexcl;
     __syncthreads();
     E_t S = xch[slot];  // product of the backward matrices of the lanes to the right (up to the contig's end)
+    __syncthreads();    // (the marginals go over the exchange area)
     if constexpr (MODE == 2) S = FOpB::combine(S, lookahead_suffix(A.fBlockSuf, blockIdx.x, gridDim.x));
     double b0 = S.a00 + S.a01, b1 = S.a10 + S.a11;
 #pragma unroll
