@@ -516,40 +516,33 @@ __global__ void __launch_bounds__(kT) vd_exact_fix(const SeqArgs A) {
 }
 
 // ---- difference form: fold / replay on 8-byte inputs ------------------------------------------
-struct LaneStageD {
-    double st[kT * (kGPL + 1)];
-};
 struct LaneGenesD {
     double d[kGPL];
     uint32_t first, last;
     int g0, cnt;
 };
-__device__ __forceinline__ LaneGenesD load_lane_d(const SeqArgs &A, int slot, LaneStageD &stg) {
-    const int base = blockIdx.x * kT * kGPL;
+// A lane loads ITS OWN kGPL genes (64 consecutive bytes; a wave's loads cover 4 KB between them, every line used whole): no
+// transposition through LDS, no barrier, all loads in flight at once (clamped indices, not a branch per load) -- as in
+// crf_vd_short.hpp since round 4.  Positions past the last gene of the batch get the padding value.
+__device__ __forceinline__ LaneGenesD load_lane_d(const SeqArgs &A, int slot) {
+    LaneGenesD L;
+    L.g0 = (int(blockIdx.x) * kT + slot) * kGPL;
+    L.cnt = min(kGPL, A.n_genes - L.g0);
     // which of the lane's genes start / end a contig: two bytes per lane, packed by the host (positions past the last
     // gene of the batch count as one-gene contigs)
     const uint32_t bits = A.flat_bits[blockIdx.x * kT + slot];
-#pragma unroll
-    for (int j = 0; j < kGPL; ++j) {  // coalesced 8-B loads, transposed through padded LDS rows
-        const int idx = j * kT + slot, g = base + idx;
-        stg.st[(idx / kGPL) * (kGPL + 1) + idx % kGPL] = g < A.n_genes ? A.dstate[g] : kVdPad;
-    }
-    __syncthreads();
-    LaneGenesD L;
-    L.g0 = base + slot * kGPL;
-    L.cnt = min(kGPL, A.n_genes - L.g0);
     L.first = bits & 0xffu;
     L.last = bits >> 8;
 #pragma unroll
-    for (int k = 0; k < kGPL; ++k) L.d[k] = stg.st[slot * (kGPL + 1) + k];
-    __syncthreads();
+    for (int k = 0; k < kGPL; ++k) L.d[k] = A.dstate[max(min(L.g0 + k, A.n_genes - 1), 0)];
+#pragma unroll
+    for (int k = 0; k < kGPL; ++k) L.d[k] = k < L.cnt ? L.d[k] : kVdPad;
     return L;
 }
 
 __global__ void __launch_bounds__(kT) vd_fold(const SeqArgs A) {
     __shared__ CE lds[kT / 64];
-    __shared__ LaneStageD stg;
-    const LaneGenesD L = load_lane_d(A, threadIdx.x, stg);
+    const LaneGenesD L = load_lane_d(A, threadIdx.x);
     CE P = COp::identity();
 #pragma unroll
     for (int k = 0; k < kGPL; ++k) {
@@ -579,9 +572,8 @@ __global__ void __launch_bounds__(kT) vd_fold(const SeqArgs A) {
 
 __global__ void __launch_bounds__(kT) vd_replay(const SeqArgs A) {
     __shared__ uint32_t lds[kT / 64];
-    __shared__ LaneStageD stg;
     const int slot = threadIdx.x;
-    const LaneGenesD L = load_lane_d(A, slot, stg);
+    const LaneGenesD L = load_lane_d(A, slot);
     const CE M = COp::combine(lookback_prefix(reinterpret_cast<const CE *>(A.vBlock), blockIdx.x),
                               reinterpret_cast<const CE *>(A.vLane)[blockIdx.x * kT + slot]);
     double D = M.L;  // the map entering a lane is constant once a contig has started
