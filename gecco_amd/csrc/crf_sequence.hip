@@ -854,7 +854,9 @@ __device__ __forceinline__ FE f_step_e(const SeqArgs &A, double2 e, double m, bo
 // of BASELINE.json's configs[4]).  The flat elements carry the contig flags (FE) whether or not log Z is wanted: the
 // look-back needs them.
 template <bool WANT_Z, int MODE>
-__global__ void __launch_bounds__(kT, 4) f_short(const SeqArgs A) {
+// (with log Z the replaying kernels hold exponents and maxima too: at 128 registers they spill, and three unspilled
+// workgroups per CU beat four spilling ones)
+__global__ void __launch_bounds__(kT, (WANT_Z && MODE != 1) ? 3 : 4) f_short(const SeqArgs A) {
     constexpr bool FLAT = MODE != 0;
     // with log Z: elements carry exponents, emission maxima and the contig-start flag; without: bare 2x2 products
     using E_t = typename std::conditional<WANT_Z || FLAT, FE, F4>::type;
@@ -985,7 +987,21 @@ __global__ void __launch_bounds__(kT, 4) f_short(const SeqArgs A) {
         }
         return;
     }
-    if constexpr (MODE == 2) M = FOp::combine(lookback_prefix(A.fBlock, blockIdx.x), M);
+    __shared__ E_t looked[2];  // MODE 2: products of the workgroups before / behind this one, up to the contig's start / end
+    if constexpr (MODE == 2) {
+        // ONE wave looks back over the forward products of the workgroups before this one, another ahead over the backward
+        // products, at the same time; the results cross LDS.  (Every wave used to do both looks itself: a wave scan of
+        // 56-byte elements is ~320 vector instructions, and the launch is issue-bound.)
+        if (slot < 64) {
+            const E_t r = lookback_prefix(A.fBlock, blockIdx.x);
+            if (slot == 0) looked[0] = r;
+        } else if (slot >= kT - 64) {
+            const E_t r = lookahead_suffix(A.fBlockSuf, blockIdx.x, gridDim.x);
+            if (slot == kT - 64) looked[1] = r;
+        }
+        __syncthreads();
+        M = FOp::combine(looked[0], M);  // (looked[1] is read where it is needed: it would cost 14 registers until then)
+    }
     // contig ends before this lane (workgroup-wide count): which contig a log Z belongs to
     uint32_t ends_before = 0;
     if (want_z && !FLAT) {
@@ -1050,7 +1066,7 @@ __global__ void __launch_bounds__(kT, 4) f_short(const SeqArgs A) {
     __syncthreads();
     E_t S = xch[slot];  // product of the backward matrices of the lanes to the right (up to the contig's end)
     __syncthreads();    // (the marginals go over the exchange area)
-    if constexpr (MODE == 2) S = FOpB::combine(S, lookahead_suffix(A.fBlockSuf, blockIdx.x, gridDim.x));
+    if constexpr (MODE == 2) S = FOpB::combine(S, looked[1]);
     double b0 = S.a00 + S.a01, b1 = S.a10 + S.a11;
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) {
