@@ -830,6 +830,13 @@ int ensure_seq(Plan &p, hipStream_t stream) {
     rc = grow_ws(p.d_seq_ws, p.seq_ws_cap, l.bytes + align256(size_t(p.n_contigs) + 24), "hipMalloc scan workspace");
     // (the decoder's counters accumulate over launches: they start from zero in a new block)
     if (!rc && fresh) rc = check_hip(hipMemsetAsync(p.d_seq_ws + l.off_stats, 0, 64, stream), "memset decoder counters");
+    // the exactness test's bound, candidate counter and contig flags (behind the layout): zero before the first decode on
+    // this layout; every decode leaves them zero again (vd_exact_fix)
+    const size_t sig = l.bytes * 1000003u + size_t(p.n_contigs) + 1;
+    if (!rc && (fresh || sig != p.vbound_sig)) {
+        rc = check_hip(hipMemsetAsync(p.d_seq_ws + l.bytes, 0, 16 + size_t(p.n_contigs), stream), "memset contig flags");
+        if (!rc) p.vbound_sig = sig;
+    }
     return rc;
 }
 

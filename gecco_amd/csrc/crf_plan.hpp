@@ -76,6 +76,7 @@ struct Plan {
     bool seq_short = false;           // no contig longer than one scan block: whole contigs per workgroup, one launch per decoder
     // workspaces, allocated on first use, grow-only
     char *d_seq_ws = nullptr, *d_gen_ws = nullptr, *d_seg_ws = nullptr;
+    size_t vbound_sig = 0;  // layout for which the exactness test's bound / counter / contig flags were last zeroed
     double *d_win_scratch = nullptr;
     size_t seq_ws_cap = 0, gen_ws_cap = 0, seg_ws_cap = 0, win_scratch_cap = 0;
     // chunk tables of the any-L whole-contig kernels (first gene / contig of every chunk, chunks of every contig): they

@@ -485,8 +485,16 @@ __global__ void __launch_bounds__(kT) v_labels(const SeqArgs A) {
 // ~50 cycles per gene, is what a 50 000-gene contig costs: about a millisecond).
 __global__ void __launch_bounds__(kT) vd_exact_fix(const SeqArgs A) {
     __shared__ FixStage fx[2];
+    // this is the last launch of a decode: it leaves the bound, the candidate counter and the contig flags at zero for the
+    // next one (until round 4 a memset per decode did that: two fill kernels, 12 us of the stream per C5 step)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.vBound[0] = 0ull;
+        A.vBound[1] = 0ull;
+    }
     for (int c = blockIdx.x; c < A.n_contigs; c += gridDim.x) {
         if (!A.fix_flag[c]) continue;  // (workgroup-uniform)
+        __syncthreads();               // (every lane has seen the flag)
+        if (threadIdx.x == 0) A.fix_flag[c] = 0;
         const int gs = A.contig_ptr[c], ge = A.contig_ptr[c + 1];
         if (ge <= gs) continue;
         if (threadIdx.x == 0 && A.vd_stats) {
@@ -1147,10 +1155,8 @@ hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream) {
     const bool exact = a.v_exact && a.csr_gene_ptr && a.fix_flag;
     SeqArgs b = a;
     if (!exact) b.fix_flag = nullptr;
-    if (exact) {  // (the bound and the candidate counter sit in the 16 bytes in front of the flags)
-        const hipError_t e = hipMemsetAsync(a.vBound, 0, 16 + size_t(a.n_contigs), stream);
-        if (e != hipSuccess) return e;
-    }
+    // (the bound, the candidate counter and the contig flags are zero here: zeroed with the workspace, and again by
+    // vd_exact_fix at the end of every decode)
     hipLaunchKernelGGL(vd_fold, dim3(nb), dim3(kT), 0, stream, b);
     hipLaunchKernelGGL(vd_replay, dim3(nb), dim3(kT), 0, stream, b);
     if (exact) hipLaunchKernelGGL(vd_refine, dim3(8), dim3(kT), 0, stream, b);
