@@ -65,7 +65,12 @@ def main():
     dt = timed(lambda: ses.clusters(cp, gpp, atp, ann, 20, want_p=False, want_seg_p=True))
     seg = ses.clusters(cp, gpp, atp, ann, 20, want_p=False, want_seg_p=True)[0]
     out["one_shot_pinned_cluster_calls"] = {"genes": n, "ms": dt * 1e3, "genes_per_s": n / dt, "clusters": len(seg),
-                                            "note": "marginals + refiner on the device, only rows and their probabilities come back"}
+                                            "note": "marginals + refiner on the device, rows and their probabilities come back "
+                                                    "into fresh pageable arrays (32-bit wire format)"}
+    # the levels of the bench line (pinned buffers in and out, degree bytes / 16-bit indices on the wire, decode, cluster calls)
+    from gecco_amd import levels  # noqa: E402
+    ses.set_chunk_genes(1 << 19)
+    out["batch_driver_levels"] = levels.host_buffer_levels(model, wl, reps=10)
     # object API on the real model: 500 contigs x 200 genes of Gene objects
     golden = os.path.join(ROOT, "tests", "golden")
     crf = ClusterCRF.trained(golden)
