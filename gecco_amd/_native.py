@@ -768,9 +768,11 @@ class Session:
         if p_out is None and want_p:
             p_out = np.empty(max(n, 1), dtype=np.float64)
         cap = min(n, n // 2 + nc) + 1
-        held = getattr(self, "_row_buffers", None)  # (the row buffers are kept between calls: no 24 MB of fresh pages per batch)
+        # the row buffers are kept between calls (no 24 MB of fresh pages per batch); a second thread inside this method on the
+        # same session takes fresh ones
+        held = self.__dict__.pop("_row_buffers", None)
         if held is None or held[0].shape[0] < cap:
-            held = self._row_buffers = (np.empty((cap, 4), dtype=np.int32), np.zeros(cap + 1, dtype=np.int64))
+            held = (np.empty((cap, 4), dtype=np.int32), np.zeros(cap + 1, dtype=np.int64))
         seg, seg_off = held[0][:cap], held[1][: cap + 1]
         if seg_p_out is not None:
             assert seg_p_out.dtype == np.float64 and seg_p_out.size >= n
@@ -788,9 +790,11 @@ class Session:
             adr(annotated), int(window), int(step), int(label), int(bool(pad)), ctypes.addressof(q), adr(p_out), adr(seg), cap,
             ctypes.addressof(n_seg), adr(seg_p) if want_seg_p else None, max(n, 1), adr(seg_off)))
         k = n_seg.value
-        return (seg[:k].copy(), ((seg_p[: seg_off[k]] if seg_p_out is not None else seg_p[: seg_off[k]].copy()) if want_seg_p else None),
-                seg_off[: k + 1].copy(),
-                (p_out[:n] if p_out is not None else None))
+        res = (seg[:k].copy(), ((seg_p[: seg_off[k]] if seg_p_out is not None else seg_p[: seg_off[k]].copy()) if want_seg_p else None),
+               seg_off[: k + 1].copy(),
+               (p_out[:n] if p_out is not None else None))
+        self._row_buffers = held  # (handed back only now: nobody else wrote into them meanwhile)
+        return res
 
 
 class Plan:
