@@ -171,6 +171,10 @@ def main() -> None:
             l0 = self.lanes[0]
             self.plan, self.d_p, self.d_y, self.stream = l0["plan"], l0["d_p"], l0["d_y"], l0["stream"]
             self.turn = 0
+            # device addresses as plain ints: the timed loop is a ctypes call per step and nothing else
+            self.a_gp, self.a_at = self.d_gp.data_ptr(), self.d_at.data_ptr()
+            for ln in self.lanes:
+                ln["a_p"], ln["a_y"] = ln["d_p"].data_ptr(), ln["d_y"].data_ptr()
 
         def step(self, schedule=None):
             schedule = schedule or args.schedule
@@ -179,9 +183,8 @@ def main() -> None:
             elif schedule == "pipelined":  # window tiles of this batch + Viterbi workgroups of the lane's batch before, one launch
                 ln = self.lanes[self.turn % len(self.lanes)]
                 self.turn += 1
-                ln["plan"].run_decode_pipelined(self.d_gp.data_ptr(), self.d_at.data_ptr(), ln["d_p"].data_ptr(),
-                                                ln["plan"] if ln["primed"] else None, ln["d_y"].data_ptr() if ln["primed"] else 0,
-                                                LABEL, ln["stream"])
+                ln["plan"].run_decode_pipelined(self.a_gp, self.a_at, ln["a_p"], ln["plan"] if ln["primed"] else None,
+                                                ln["a_y"] if ln["primed"] else 0, LABEL, ln["stream"])
                 ln["primed"] = True
             else:  # one pass over the CSR: state scores are accumulated once for both outputs
                 self.plan.run_decode(self.d_gp.data_ptr(), self.d_at.data_ptr(), self.d_p.data_ptr(), self.d_y.data_ptr(), LABEL, 0,
