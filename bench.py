@@ -72,7 +72,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C5", "Cinf"])
+    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5", "Cinf"])
+    ap.add_argument("--no-latency", action="store_true", help="skip the small-batch latency block (50 ... 100 000 genes, cold and warm)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-past-l3", action="store_true", help="skip the HBM-resident (2e8-gene) roofline point")
     ap.add_argument("--kernel-iters", type=int, default=200)
@@ -242,16 +243,26 @@ def main() -> None:
         return int(g.item())
 
     # ---- workload: every rank generates its own batch (same model, different contigs) for the weak-scaling value
-    wl = synth.workload(args.workload, seed=synth.SEED, law=args.synth)
+    if args.workload == "C1":
+        # BASELINE.json configs[0]: ONE 50-gene contig on the pretrained weights (tests/golden/model.pkl), SURVEY.md 8d's
+        # domain law; a step of it is one launch of one window tile + one Viterbi workgroup: launch-bound by construction
+        from gecco_amd import latency as _lat
+
+        c1_model = nat.Model.from_lcrf(_lat.real_blob())
+        cptr, gptr, attr = _lat.c1_batch(50, c1_model.num_attrs)
+        wl = dict(name="C1", w=c1_model.state_weights()[0], trans=c1_model.trans_weights()[0], contig_ptr=cptr, gene_ptr=gptr, attr_id=attr,
+                  A=c1_model.num_attrs)
+    else:
+        wl = synth.workload(args.workload, seed=synth.SEED, law=args.synth)
     base = dict(wl)  # rank 0's batch = the batch BASELINE.json names; C4 partitions THIS one
-    if rank > 0:
+    if rank > 0 and args.workload != "C1":
         rng = np.random.default_rng(synth.SEED + rank)
         lengths = np.diff(wl["contig_ptr"]).astype(np.int64)
         rng.shuffle(lengths)
         hot = np.argsort(wl["w"][:, 1] - wl["w"][:, 0])[-200:]
         cptr, gptr, attr = synth.synth_contigs(rng, lengths, wl["A"], planted=0.01, hot_attrs=hot)
         wl.update(contig_ptr=cptr, gene_ptr=gptr, attr_id=attr)
-    model = nat.Model.from_tables(wl["w"], wl["trans"])
+    model = c1_model if args.workload == "C1" else nat.Model.from_tables(wl["w"], wl["trans"])
     n_lanes = args.streams if (args.schedule == "pipelined" and not args.windowed_only) else 1
     res = Resident(model, wl["contig_ptr"], wl["gene_ptr"], wl["attr_id"], lanes=n_lanes)
     n_genes, nnz = res.n_genes, res.nnz
@@ -364,7 +375,11 @@ def main() -> None:
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: {res.n_contigs} contigs, {n_genes} genes, {nnz} domain hits per GPU; "
+            "workload": (f"C1: ONE contig of {n_genes} genes, {nnz} domain hits, on GECCO's pretrained CRF weights (tests/golden/model.pkl: "
+                         f"{wl['A']} attributes, 2 labels), SURVEY.md 8d's domain law, window 20 step 1, pad -- BASELINE.json configs[0]; a "
+                         "step is one launch (one window tile + one Viterbi workgroup): launch-bound, see `latency` for what a call costs")
+                        if args.workload == "C1" else
+                        f"{args.workload}: {res.n_contigs} contigs, {n_genes} genes, {nnz} domain hits per GPU; "
                         f"A=35000 synthetic 2-label model, window 20 step 1, pad.  " + (
                             "Side point, not SURVEY.md 8d's law: weights ~ Laplace(-0.4, 1.7) and the Zipf head (ids < A/50) forced "
                             "negative, so that most genes lean to label '0' as under the embedded model (mean w1-w0 = -0.76)"
@@ -563,6 +578,30 @@ def main() -> None:
         except Exception as err:
             out["session_multi_device"] = {"error": f"{type(err).__name__}: {err}"}
 
+    # ---- small batches: what ONE call costs at 50 ... 100 000 genes, warm and cold, at every level a caller enters the path
+    # (BASELINE.json configs[0] is the first of them; gecco_amd/latency.py)
+    lat_checks = None
+    if rank == 0 and world == 1 and not args.no_latency and args.workload in ("C1", "C3"):
+        from gecco_amd import latency as _lat
+
+        try:
+            block, lat_checks, _lat_model = _lat.latency_block(device=local_rank)
+            block["launch_floor_note"] = ("tools/ubench/launch_floor.hip on the same box class: an EMPTY kernel launch + hipStreamSynchronize "
+                                          "takes 11.9 us (12.3 us for a kernel that reads and writes pinned host memory): the floor of any "
+                                          "synchronous one-shot call (profiles/r05_launch_floor.txt)")
+            try:
+                import subprocess
+
+                env = dict(os.environ, GECCO_AMD_MODEL_DIR=os.path.join(ROOT, "tests", "golden"))
+                cp = subprocess.run([sys.executable, "-m", "gecco_amd.latency", "--cold-process"], cwd=ROOT, env=env, capture_output=True,
+                                    text=True, timeout=180)
+                block["cold_process"] = json.loads(cp.stdout.strip().splitlines()[-1]) if cp.returncode == 0 else {"error": cp.stderr[-400:]}
+            except Exception as err:
+                block["cold_process"] = {"error": f"{type(err).__name__}: {err}"}
+            out["latency"] = block
+        except Exception as err:
+            out["latency"] = {"error": f"{type(err).__name__}: {err}"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (C restatement of the CRFsuite tagger driven window by
         # window like the reference), 1 thread, on a bounded sample of the same workload.
@@ -611,6 +650,28 @@ def main() -> None:
         }
         if not args.windowed_only:
             out["parity"]["viterbi_label_mismatches"] = int((res.d_y[:ng].cpu().numpy() != y_ref.astype(np.int8)).sum())
+        if lat_checks:
+            # the C port's time for the very inputs of the latency block, and their parity (marginals, labels, cluster rows)
+            lw, lt = _lat_model.state_weights()[0], _lat_model.trans_weights()[0]
+            for n, ck in lat_checks.items():
+                best = None
+                for _ in range(3 if n <= 10000 else 1):
+                    t0 = time.perf_counter()
+                    lp = orc.windowed_marginals(lw, lt, ck["cptr"], ck["gptr"], ck["attr"], W, STEP, LABEL, True)
+                    d1 = time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    ly, _ = orc.viterbi(lw, lt, ck["cptr"], ck["gptr"], ck["attr"])
+                    d2 = time.perf_counter() - t0
+                    best = (d1, d2) if best is None or d1 + d2 < sum(best) else best
+                ann = (np.diff(ck["gptr"]) > 0).astype(np.uint8)
+                lseg = orc.segment(lp, ann, ck["cptr"], 0.8, 3, 0, True)
+                out["latency"][str(n)]["cpu_port"] = {
+                    "windowed_us": best[0] * 1e6, "viterbi_us": best[1] * 1e6, "cores": 1,
+                    "note": "the C oracle on the same input, one thread, best of 3 (driven window by window like the reference)"}
+                out["latency"][str(n)]["parity"] = {
+                    "max_abs_dp_vs_oracle": float(np.abs(ck["p"] - lp).max()),
+                    "viterbi_label_mismatches": int((ck["y"] != ly.astype(np.int8)).sum()),
+                    "cluster_rows_identical": bool(np.array_equal(ck["seg"], lseg))}
         # the TRUE reference, only if the box happens to have it (a site install; never shipped from
         # this repository): sklearn_crfsuite's tagger in the reference's own per-window Python loop
         # (gecco/crf/__init__.py:251-256) on the embedded model, 10^4 genes, one core

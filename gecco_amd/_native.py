@@ -83,10 +83,12 @@ SIGNATURES = {
     "gecco_crf_session_create": (ctypes.c_int, [_vp, _c_i32p, ctypes.c_int32, ctypes.POINTER(_vp)]),
     "gecco_crf_session_free": (None, [_vp]),
     "gecco_crf_session_set_chunk_genes": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "gecco_crf_session_set_direct_genes": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "gecco_crf_session_stats": (
         ctypes.c_int,
         [_vp, _c_i32p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _c_f64p, _c_f64p],
     ),
+    "gecco_crf_session_stats_ex": (ctypes.c_int, [_vp, _vp]),
     "gecco_crf_session_windowed": (
         ctypes.c_int,
         [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p],
@@ -664,6 +666,13 @@ def degree_bytes(gene_ptr) -> np.ndarray:
     return np.ascontiguousarray(d, dtype=np.uint8) if d.size else np.zeros(1, dtype=np.uint8)
 
 
+class SessionStatsStruct(ctypes.Structure):
+    """``gecco_crf_session_stats_t``"""
+    _fields_ = [("n_chunks", ctypes.c_int32), ("n_devices", ctypes.c_int32), ("direct", ctypes.c_int32), ("host_threads", ctypes.c_int32),
+                ("h2d_bytes", ctypes.c_int64), ("d2h_bytes", ctypes.c_int64), ("host_plan_seconds", ctypes.c_double),
+                ("host_issue_seconds", ctypes.c_double), ("wall_seconds", ctypes.c_double)]
+
+
 class Session:
     """Batch driver over one or several devices (include/gecco_crf.h, `gecco_crf_session_*`): host
     arrays in, host arrays out; contig chunks are dealt to the devices longest-first and pipelined
@@ -686,14 +695,16 @@ class Session:
     def set_chunk_genes(self, genes: int) -> None:
         _check(self._lib.gecco_crf_session_set_chunk_genes(self._h, int(genes)))
 
+    def set_direct_genes(self, genes: int) -> None:
+        """Largest batch (genes) that takes the direct path -- one chunk, kernels on pinned host memory, no copy commands
+        (`gecco_crf_session_set_direct_genes`; 0: never)."""
+        _check(self._lib.gecco_crf_session_set_direct_genes(self._h, int(genes)))
+
     def stats(self) -> dict:
-        n = ctypes.c_int32(0)
-        h2d, d2h = ctypes.c_int64(0), ctypes.c_int64(0)
-        plan_s, wall_s = ctypes.c_double(0), ctypes.c_double(0)
-        _check(self._lib.gecco_crf_session_stats(self._h, ctypes.byref(n), ctypes.byref(h2d), ctypes.byref(d2h),
-                                                 ctypes.byref(plan_s), ctypes.byref(wall_s)))
-        return {"n_chunks": n.value, "h2d_bytes": h2d.value, "d2h_bytes": d2h.value, "host_plan_seconds": plan_s.value,
-                "wall_seconds": wall_s.value}
+        """Figures of the last batch (`gecco_crf_session_stats_ex`)."""
+        st = SessionStatsStruct()
+        _check(self._lib.gecco_crf_session_stats_ex(self._h, ctypes.addressof(st)))
+        return {name: getattr(st, name) for name, _ in SessionStatsStruct._fields_}
 
     @staticmethod
     def _csr(contig_ptr, gene_ptr, attr_id):
@@ -735,7 +746,8 @@ class Session:
         contig_ptr, gene_ptr, attr_id, n, nc = self._csr(contig_ptr, gene_ptr, attr_id)
         p = np.empty(max(n, 1), dtype=np.float64) if out_p is None else out_p
         y = (np.empty(max(n, 1), dtype=np.int8) if out_y is None else out_y) if labels else None
-        assert p.dtype == np.float64 and p.size >= n and (y is None or (y.dtype == np.int8 and y.size >= n))
+        assert p.dtype == np.float64 and p.flags.c_contiguous and p.size >= n
+        assert y is None or (y.dtype == np.int8 and y.flags.c_contiguous and y.size >= n)
         if degree is not None:
             assert degree.dtype == np.uint8 and degree.flags.c_contiguous and degree.size >= n
         adr = lambda a: None if a is None or a.size == 0 else a.ctypes.data  # noqa: E731
@@ -774,8 +786,10 @@ class Session:
         if held is None or held[0].shape[0] < cap:
             held = (np.empty((cap, 4), dtype=np.int32), np.zeros(cap + 1, dtype=np.int64))
         seg, seg_off = held[0][:cap], held[1][: cap + 1]
+        if p_out is not None:
+            assert p_out.dtype == np.float64 and p_out.flags.c_contiguous and p_out.size >= n
         if seg_p_out is not None:
-            assert seg_p_out.dtype == np.float64 and seg_p_out.size >= n
+            assert seg_p_out.dtype == np.float64 and seg_p_out.flags.c_contiguous and seg_p_out.size >= n
             want_seg_p = True
         seg_p = (seg_p_out if seg_p_out is not None else np.empty(max(n, 1), dtype=np.float64)) if want_seg_p else None
         n_seg = ctypes.c_int32(0)
@@ -783,15 +797,16 @@ class Session:
         q = refine_params(criterion, threshold, n_cds, n_biopfams, average_threshold, edge_distance, trim, False, marker_ptr,
                           marker_id, keep)
         if degree is not None:
-            assert degree.dtype == np.uint8 and degree.size >= n
+            assert degree.dtype == np.uint8 and degree.flags.c_contiguous and degree.size >= n
         adr = lambda a: None if a is None else a.ctypes.data  # noqa: E731
         _check(self._lib.gecco_crf_session_clusters_wire(
             self._h, adr(contig_ptr), nc, adr(gene_ptr), adr(degree), adr(attr_id) if attr16 is None else None, adr(attr16),
             adr(annotated), int(window), int(step), int(label), int(bool(pad)), ctypes.addressof(q), adr(p_out), adr(seg), cap,
             ctypes.addressof(n_seg), adr(seg_p) if want_seg_p else None, max(n, 1), adr(seg_off)))
         k = n_seg.value
+        # (without seg_p the C side writes no offsets: the reused buffer would show those of an earlier call)
         res = (seg[:k].copy(), ((seg_p[: seg_off[k]] if seg_p_out is not None else seg_p[: seg_off[k]].copy()) if want_seg_p else None),
-               seg_off[: k + 1].copy(),
+               (seg_off[: k + 1].copy() if want_seg_p else None),
                (p_out[:n] if p_out is not None else None))
         self._row_buffers = held  # (handed back only now: nobody else wrote into them meanwhile)
         return res

@@ -53,6 +53,7 @@ class _CRFSuiteModelView:
         self._attr_index: Dict[str, int] = {a: i for i, a in enumerate(self.attributes_)}
         self._state: Optional[Dict[Tuple[str, str], float]] = None
         self._trans: Optional[Dict[Tuple[str, str], float]] = None
+        self._w1: Optional[Dict[str, float]] = None
 
     # [EXT] sklearn-crfsuite parses these back from CRFsuite's text dump, which prints weights
     # with "%f": values are rounded to 6 decimals there, and so they are here.
@@ -75,6 +76,15 @@ class _CRFSuiteModelView:
                 for i in range(len(self.classes_)) for j in range(len(self.classes_)) if present[i, j]
             }
         return self._trans
+
+    @property
+    def cluster_weights_(self) -> Dict[str, float]:
+        """``{domain: state_features_[(domain, '1')]}``: what `predict_probabilities` annotates domains with
+        (crf/__init__.py:261-269).  Built once per model: filtering the 4 211 state features on every call cost more than
+        scoring a 50-gene contig."""
+        if self._w1 is None:
+            self._w1 = {name: w for (name, lab), w in self.state_features_.items() if lab == "1"}
+        return self._w1
 
     @property
     def num_attributes_(self) -> int:
@@ -398,7 +408,7 @@ class ClusterCRF(object):
         # weight of (domain, '1'), None if absent) -- new Gene/Protein/Domain objects; contigs that
         # were skipped keep their probabilities and only get the weights.
         weights = self.model.state_features_
-        w1 = {name: w for (name, lab), w in weights.items() if lab == "1"}
+        w1 = self.model.cluster_weights_
         predicted: List[Any] = []
         # Millions of small container objects are about to be allocated and none of them dies: the cyclic collector's
         # generational passes over the growing heap cost 6x the allocations themselves (measured: 430 -> 63 ms per 50 000

@@ -89,7 +89,7 @@ int check_device(int32_t device) {
 }  // namespace
 
 GECCO_API const char *gecco_crf_last_error(void) { return last_error(); }
-GECCO_API int gecco_crf_version(void) { return 210; }
+GECCO_API int gecco_crf_version(void) { return 220; }
 
 GECCO_API int gecco_crf_model_load(const uint8_t *lcrf, size_t n_bytes, gecco_crf_model **out) {
     if (!out) return GECCO_CRF_EINVAL;
@@ -350,6 +350,11 @@ GECCO_API int gecco_crf_session_set_chunk_genes(gecco_crf_session *s, int32_t ge
     session_set_chunk_genes(*s->s, genes);
     return GECCO_CRF_OK;
 }
+GECCO_API int gecco_crf_session_set_direct_genes(gecco_crf_session *s, int32_t genes) {
+    if (!s || genes < 0) return GECCO_CRF_EINVAL;
+    session_set_direct_genes(*s->s, genes);
+    return GECCO_CRF_OK;
+}
 GECCO_API int gecco_crf_session_stats(const gecco_crf_session *s, int32_t *n_chunks, int64_t *h2d_bytes, int64_t *d2h_bytes,
                                       double *host_plan_seconds, double *wall_seconds) {
     if (!s) return GECCO_CRF_EINVAL;
@@ -359,6 +364,21 @@ GECCO_API int gecco_crf_session_stats(const gecco_crf_session *s, int32_t *n_chu
     if (d2h_bytes) *d2h_bytes = st.d2h_bytes;
     if (host_plan_seconds) *host_plan_seconds = st.host_plan_seconds;
     if (wall_seconds) *wall_seconds = st.wall_seconds;
+    return GECCO_CRF_OK;
+}
+
+GECCO_API int gecco_crf_session_stats_ex(const gecco_crf_session *s, gecco_crf_session_stats_t *out) {
+    if (!s || !out) return GECCO_CRF_EINVAL;
+    const SessionStats st = session_stats(*s->s);
+    out->n_chunks = st.n_chunks;
+    out->n_devices = st.n_devices;
+    out->direct = st.direct;
+    out->host_threads = st.host_threads;
+    out->h2d_bytes = st.h2d_bytes;
+    out->d2h_bytes = st.d2h_bytes;
+    out->host_plan_seconds = st.host_plan_seconds;
+    out->host_issue_seconds = st.host_issue_seconds;
+    out->wall_seconds = st.wall_seconds;
     return GECCO_CRF_OK;
 }
 

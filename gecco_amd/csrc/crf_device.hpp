@@ -38,6 +38,11 @@ struct WinArgs {
     const double *exp_trans;   // [L*L] exp(trans) for the generic kernel
     double *scratch;           // generic kernel workspace
     const double *rtab;        // [32] mu01 * 2^(j/32): exp table of the ratio-form slot constants (mu_exp_tab)
+    // What the host may know of the CSR arrays (batch driver's direct path: they are its own copies; a caller of the resident
+    // API keeps them in device memory, where the kernel has to look: -1).  csr_end = gene_ptr[n_genes], csr_begin = gene_ptr[0]:
+    // a batch of ONE regular tile (crf_windowed_small_l2) takes them from here instead of loading them in front of its first
+    // attribute load -- a round trip over PCIe when the arrays live in pinned host memory.
+    int32_t csr_end, csr_begin;
 };
 
 // Geometry of the fast L==2 kernel.

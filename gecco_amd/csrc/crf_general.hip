@@ -1089,13 +1089,16 @@ hipError_t launch_gen_windowed_small(const GenArgs &a, const double *trans_host,
     if (L > 8) {  // sixteen windows per wave on the fp64 matrix cores
         const int wmax = a.W <= 20 ? 20 : 32, ns = (L + 3) / 4;
         const size_t lds = size_t(L) * gl_mfma_stride(wmax) * 8 + size_t(kMfmaNT + wmax) * 12;
+        hipError_t attr_rc = hipSuccess;
 #define GL_MFMA(TT, NN)                                                                                                              \
     do {                                                                                                                             \
         if (wmax == 20) {                                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gl_windowed_mfma<TT, NN, 20>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)); \
+            attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&gl_windowed_mfma<TT, NN, 20>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)); \
+            if (attr_rc != hipSuccess) return attr_rc; /* (a device whose LDS cannot hold L label rows of a tile: fail loudly) */ \
             hipLaunchKernelGGL((gl_windowed_mfma<TT, NN, 20>), dim3(ntiles), dim3(kMfmaNT), lds, stream, a, mx, d_tile_desc);        \
         } else {                                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gl_windowed_mfma<TT, NN, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)); \
+            attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&gl_windowed_mfma<TT, NN, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)); \
+            if (attr_rc != hipSuccess) return attr_rc;                                                                               \
             hipLaunchKernelGGL((gl_windowed_mfma<TT, NN, 32>), dim3(ntiles), dim3(kMfmaNT), lds, stream, a, mx, d_tile_desc);        \
         }                                                                                                                            \
     } while (0)

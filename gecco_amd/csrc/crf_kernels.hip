@@ -203,7 +203,11 @@ __device__ __forceinline__ void state_scores_buf(__amdgpu_buffer_rsrc_t ra, __am
 //   in x / (x + y).
 // One window tile (workgroup `tile` of the launch).
 // LEAN: the tile shares its kernel with the Viterbi workgroups (crf_decode_pipelined), whose SGPR spills take one VGPR of the 64.
-template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT, bool LEAN = false>
+// SMALL: a batch of ONE regular tile whose CSR extent the host knows (the batch driver's direct path on a contig of a few dozen
+// genes, BASELINE.json configs[0]): nothing is looked up in front of the first attribute load, and a phase without output
+// slots is skipped.  A kernel of its own (crf_windowed_small_l2): the extra scalars would cost the tiles of the big launches
+// a register spill, and occupancy means nothing to one workgroup.
+template <int WMAX, bool EXACT, bool RESCALE, int NT, int TT, bool LEAN = false, bool SMALL = false>
 __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT, TT, EXACT> &sm, const int tile) {
     using Smem = WinSmem<WMAX, NT, TT, EXACT>;
     constexpr int JMAX = Smem::JMAX;
@@ -262,9 +266,9 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
 
     // buffer descriptors: attribute ids relative to the workgroup's first run (keeps byte offsets in
     // 32 bits for any batch), the weight-pair table whole.  All operands are wave-uniform (SGPRs).
-    const uint32_t nnz = uint32_t(P.gene_ptr[P.n_genes]);
+    const uint32_t nnz = SMALL ? uint32_t(P.csr_end) : uint32_t(P.gene_ptr[P.n_genes]);
     const int g_first = (td.w & 1) ? (q0 > 0 ? q0 : 0) + td.x : P.c_gene[td.y];
-    const uint32_t lo_tile = uint32_t(P.gene_ptr[g_first]);
+    const uint32_t lo_tile = SMALL ? uint32_t(P.csr_begin) : uint32_t(P.gene_ptr[g_first]);
     const uint64_t abytes = uint64_t(nnz - lo_tile) << 2;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int32_t *>(P.attr_id + lo_tile), 0, abytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(abytes), 0x00020000);
@@ -296,7 +300,7 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
             }
         }
         const int q_end = min(q0 + ns, P.S);  // one past the workgroup's last slot
-        const uint32_t hi_tile = uint32_t(P.gene_ptr[q_end + td.x]);
+        const uint32_t hi_tile = SMALL ? uint32_t(P.csr_end) : uint32_t(P.gene_ptr[q_end + td.x]);  // (one tile: it ends where the batch does)
         const uint32_t n_attr = hi_tile - lo_tile;
         // parking area: the upper three quarters of `ef` -- the ratio form's slot constants (the lower quarter) never
         // touch it, so no barrier is needed between the sums and those writes; the max-normalised pairs (lower
@@ -446,6 +450,8 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
     const double rho = P.rho;
 #pragma unroll 1
     for (int ph = 0; ph < TT; ++ph) {
+        // (the last workgroup of a batch -- the only one of a 50-gene contig -- may have no output slot left for a later phase)
+        if (SMALL && ph > 0 && q0 + (W - 1) + ph * OUT >= P.S) break;  // (no output slot left for this phase)
         const int sbase = ph * OUT + tid;  // slot of this lane's window start (and of its output)
         // the lane's output gene and whether a window may start at its slot: ratio-form kernels carry the start flag in
         // the sign bit of the slot constant and compute the gene of a regular tile from the slot; the others read both
@@ -707,6 +713,12 @@ __global__ void __launch_bounds__(NT, (RESCALE ? (WMAX <= 20 ? 5 : 3) : (WMAX <=
     windowed_tile<WMAX, EXACT, RESCALE, NT, TT>(P, sm, xcd_remap(blockIdx.x, P.ntiles));
 }
 
+// one regular tile, CSR extent in the arguments (launch_windowed picks it when the plan carries the extent)
+__global__ void __launch_bounds__(kWinThreads, 4) crf_windowed_small_l2(const WinArgs P) {
+    __shared__ WinSmem<20, kWinThreads, 2, true> sm;
+    windowed_tile<20, true, false, kWinThreads, 2, false, true>(P, sm, 0);
+}
+
 // ---- the decode step, software-pipelined over batches: ONE launch, NO hand-over inside it ---------------------------------
 // Launch k carries the window tiles of batch k and the Viterbi workgroups of batch k - 1, whose score differences the
 // tiles of launch k - 1 left in that plan's workspace (two buffers per plan, alternating, so a plan may follow itself).
@@ -844,6 +856,10 @@ hipError_t launch_windowed(const WinArgs &a, hipStream_t stream) {
         return hipGetLastError();
     }
     if (a.L != 2 || a.W > kWinMaxW) return hipErrorNotSupported;
+    if (a.ntiles == 1 && a.all_regular && a.csr_end >= 0 && a.csr_begin >= 0 && a.W == 20 && a.rescale_mask == 0 && a.tiles_per_wg == 2) {
+        hipLaunchKernelGGL(crf_windowed_small_l2, dim3(1), dim3(kWinThreads), 0, stream, a);
+        return hipGetLastError();
+    }
     switch (a.tiles_per_wg) {
     case 1: return launch_windowed_tt<1>(a, stream);
     case 2: return launch_windowed_tt<2>(a, stream);

@@ -231,6 +231,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     p.gen_small = false;
     p.gen_tab_chunk = 0;  // (chunk tables of the previous contigs)
     p.pipe = Plan::Pipe{};  // (score differences and CSR pointers of the previous layout)
+    p.csr_begin = p.csr_end = -1;  // (the owner sets them after the build, for the batch at hand)
     p.model = &m;
     p.device = device;
     p.W = W;
@@ -636,6 +637,8 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
         const char *env = std::getenv("GECCO_CRF_RATIO");
         a.ratio_dmax = (env && env[0] == '0') ? -1e300 : 600.0 / double(p.W);
     }
+    a.csr_begin = int32_t(p.csr_begin);  // (row pointers are 32-bit)
+    a.csr_end = int32_t(p.csr_end);
     a.generic = p.fast_ok ? 0 : 1;
     if (a.generic) {
         {
@@ -797,12 +800,32 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
     if (!cblk.empty()) std::memcpy(p.seq.h + o_blk, cblk.data(), cblk.size() * 4);
     if (!rank.empty()) std::memcpy(p.seq.h + o_rank, rank.data(), rank.size() * 4);
     if (!ne.empty()) std::memcpy(p.seq.h + o_ne, ne.data(), ne.size() * 4);
-    p.d_seq_flags = reinterpret_cast<uint8_t *>(p.seq.d + o_flags);
-    p.d_seq_cblk = reinterpret_cast<int32_t *>(p.seq.d + o_blk);
-    p.d_seq_cblk_rank = reinterpret_cast<int32_t *>(p.seq.d + o_rank);
-    p.d_seq_ne_contig = reinterpret_cast<int32_t *>(p.seq.d + o_ne);
-    p.d_seq_lane_bits = reinterpret_cast<const uint16_t *>(p.seq.d + o_lb);
-    p.d_seq_flat_bits = reinterpret_cast<const uint16_t *>(p.seq.d + o_fb);
+    char *base = p.seq.d;
+    if (p.seq_in_host_memory) {
+        // a small batch: the decoder reads its tables (a few hundred bytes) from the pinned block itself and the host writes the
+        // flag bytes -- nothing is copied, nothing is launched in front of the decoder
+        uint8_t *fl = reinterpret_cast<uint8_t *>(p.seq.h + o_flags);
+        std::memset(fl, 0, n + 16);
+        for (int32_t c = 0; c < p.n_contigs; ++c) {
+            const int32_t g0 = p.contig_ptr[c], g1 = p.contig_ptr[c + 1];
+            if (g1 <= g0) continue;
+            fl[g0] |= 1u;
+            fl[g1 - 1] |= 2u;
+        }
+        void *dv = nullptr;
+        if ((rc = check_hip(hipHostGetDevicePointer(&dv, p.seq.h, 0), "hipHostGetDevicePointer"))) return rc;
+        base = static_cast<char *>(dv);
+    }
+    p.d_seq_flags = reinterpret_cast<uint8_t *>(base + o_flags);
+    p.d_seq_cblk = reinterpret_cast<int32_t *>(base + o_blk);
+    p.d_seq_cblk_rank = reinterpret_cast<int32_t *>(base + o_rank);
+    p.d_seq_ne_contig = reinterpret_cast<int32_t *>(base + o_ne);
+    p.d_seq_lane_bits = reinterpret_cast<const uint16_t *>(base + o_lb);
+    p.d_seq_flat_bits = reinterpret_cast<const uint16_t *>(base + o_fb);
+    if (p.seq_in_host_memory) {
+        p.seq_ready = true;
+        return GECCO_CRF_OK;
+    }
     // launches that read the tables must be ordered behind this copy: `sync` (any stream may follow), or the
     // caller keeps to `stream` (the batch driver)
     if (p.tables_by_kernel && !sync) {  // (batch driver: fetched by a launch, the copy engine keeps to the chunks' arrays)

@@ -96,6 +96,9 @@ struct Plan {
                                     // the copy engine (batch driver: the engine is busy with the next chunk's arrays by then)
     bool tables_in_host_memory = false;  // the window kernel reads the plan tables from the pinned block itself (batch driver:
                                          // one copy and one inter-copy gap less per chunk; they are ~0.1 MB, read once)
+    int64_t csr_begin = -1, csr_end = -1;  // gene_ptr[0] / gene_ptr[n_genes] when the owner knows them (batch driver's direct path), else -1
+    bool seq_in_host_memory = false;     // small batches (batch driver's direct path): the whole-contig tables AND the contig flags
+                                         // stay in the pinned block, flags built by the host -- no copy, no launch in front of the decoder
     std::mutex ws_mutex;  // guards the lazy workspace / table creation: launches of one plan may come from several threads
     ~Plan();
 };

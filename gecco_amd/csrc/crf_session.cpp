@@ -1,6 +1,8 @@
 #include "crf_session.hpp"
 
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -108,6 +110,15 @@ struct Lane {
     int up_chunk = -1;  // chunk whose arrays were uploaded ahead of its submission (-1: none)
     int64_t up_a0 = 0, up_nnz = 0, up_b0 = 0;
     DevBuf d_gp, d_at, d_at16, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg, d_deg, d_deg_ws, d_segp;
+    HostBuf h_io;   // direct path (small batches): the chunk's arrays and outputs in pinned, device-visible memory
+    // direct path: device-visible addresses of the chunk's arrays (the staging block, or the caller's own pinned buffers) and
+    // what the host copies out of the staging block once the launch has completed
+    const int32_t *x_gp = nullptr, *x_at = nullptr, *x_bp = nullptr, *x_bi = nullptr;
+    const uint8_t *x_ann = nullptr;
+    double *x_p = nullptr;       // where the kernels write p (null: the lane's device buffer)
+    int8_t *x_y = nullptr;
+    const double *x_p_host = nullptr;  // ... the same places as the host sees them, when they lie inside h_io: copied to the
+    const int8_t *x_y_host = nullptr;  // caller's arrays at retirement (null: the kernels wrote to the caller's arrays)
     HostBuf h_seg;  // [total][pad..][seg_off: cap+1][rows: cap*4]
     bool segp_in_flight = false;  // the download of the rows' probabilities has been issued (retire_begin), not yet waited for
     int32_t seg_cap = 0;
@@ -133,6 +144,13 @@ struct Session {
     std::vector<std::unique_ptr<DeviceCtx>> devs;
     int32_t chunk_genes = 1 << 19;
     std::mutex mu;  // one batch at a time per session
+    // Batches of at most this many genes take the DIRECT path: one chunk, no copy commands, no second stream -- the kernels read
+    // the arrays from pinned host memory and write their outputs there, the host waits for the compute stream.
+    // GECCO_CRF_DIRECT_GENES overrides (0: never).
+    // Measured (tools/direct_sweep.py, pinned buffers, us per call direct / chunked): marginals 33 / 61 at 2 000 genes, 33 / 78 at
+    // 10 000, 62 / 97 at 65 000, 105 / 140 at 200 000; cluster rows 62 / 72, 63 / 91, 91 / 94, 121 / 113: the refiner's seven
+    // short launches sit in one stream behind the tiles either way, so cluster calls stop at half the size.
+    int32_t direct_genes = 1 << 17;
     SessionStats stats;
     ~Session();
 };
@@ -146,6 +164,7 @@ Session::~Session() {
         for (Lane &ln : d->lanes) {
             for (DevBuf *b : {&ln.d_gp, &ln.d_at, &ln.d_at16, &ln.d_p, &ln.d_y, &ln.d_ann, &ln.d_score, &ln.d_marg, &ln.d_lognorm, &ln.d_bp, &ln.d_bi, &ln.d_seg, &ln.d_deg, &ln.d_deg_ws, &ln.d_segp}) b->release();
             ln.h_seg.release();
+            ln.h_io.release();
             for (hipEvent_t e : {ln.ev_up, ln.ev_comp, ln.done})
                 if (e) (void)hipEventDestroy(e);
         }
@@ -173,6 +192,7 @@ int session_create(const Model &m, const int32_t *devices, int32_t n_devices, Se
         const long v = std::atol(env);
         if (v >= 1024) s->chunk_genes = int32_t(std::min<long>(v, 1 << 28));
     }
+    if (const char *env = std::getenv("GECCO_CRF_DIRECT_GENES")) s->direct_genes = int32_t(std::max<long>(0, std::min<long>(std::atol(env), 1 << 24)));
     for (int32_t i = 0; i < n_devices; ++i) {
         if (devices[i] < 0 || devices[i] >= count) {
             set_error("device index out of range");
@@ -205,6 +225,10 @@ void session_destroy(Session *s) { delete s; }
 void session_set_chunk_genes(Session &s, int32_t genes) {
     std::lock_guard<std::mutex> lock(s.mu);
     s.chunk_genes = std::max(1024, genes);
+}
+void session_set_direct_genes(Session &s, int32_t genes) {
+    std::lock_guard<std::mutex> lock(s.mu);
+    s.direct_genes = std::max(0, genes);
 }
 SessionStats session_stats(const Session &s) { return s.stats; }
 
@@ -262,6 +286,7 @@ void deal_chunks(std::vector<Chunk> &chunks, int n_devices) {
 
 // sum of n bytes: psadbw adds sixteen at a time into two 64-bit lanes (SSE2: the x86-64 baseline)
 uint64_t byte_sum(const uint8_t *p, size_t n) {
+#if defined(__SSE2__)
     const __m128i zero = _mm_setzero_si128();
     __m128i a0 = zero, a1 = zero, a2 = zero, a3 = zero;
     size_t i = 0;
@@ -275,6 +300,10 @@ uint64_t byte_sum(const uint8_t *p, size_t n) {
     uint64_t lanes[2];
     _mm_storeu_si128(reinterpret_cast<__m128i *>(lanes), acc);
     uint64_t total = lanes[0] + lanes[1];
+#else
+    uint64_t total = 0;
+    size_t i = 0;
+#endif
     for (; i < n; ++i) total += p[i];
     return total;
 }
@@ -285,6 +314,7 @@ struct RunCtx {
     std::vector<Chunk> &chunks;
     bool windowed, viterbi, full;
     int32_t W, step, pad;
+    bool direct = false;  // small batch: one chunk, kernels on pinned host memory, no copy commands (submit_direct_arrays)
 };
 
 // labels of the device's pending chunk: its Viterbi workgroups have just been launched on `comp` and `down` waits for them
@@ -393,6 +423,144 @@ int submit_uploads(RunCtx &X, Lane &ln, int chunk_index) {
     return GECCO_CRF_OK;
 }
 
+// Device-visible address of caller memory that is pinned (gecco_crf_host_alloc / hipHostMalloc / hipHostRegister), or null.
+// Only asked for arrays large enough for the question to cost less than the copy it may save.
+template <class T>
+T *mapped_or_null(T *host) {
+    if (!host) return nullptr;
+    void *dv = nullptr;
+    if (hipHostGetDevicePointer(&dv, const_cast<void *>(static_cast<const void *>(host)), 0) != hipSuccess) {
+        (void)hipGetLastError();  // (not pinned: not an error of this call)
+        return nullptr;
+    }
+    return static_cast<T *>(dv);
+}
+
+// Direct path: what submit_uploads does on the upload stream, done by the host and by address.  The chunk (= the whole batch)
+// gets device-visible addresses for its arrays: a copy in the lane's pinned staging block (a 50-gene contig: 600 bytes) that
+// the kernels read in place; for an array of 64 KB and more, device memory filled by a copy command on the COMPUTE stream.
+// Outputs are written by the kernels into pinned host memory: the caller's own buffer where it is pinned and large enough to
+// be worth asking, the staging block otherwise.  The compact wire format is undone on the way (row pointers are the caller's
+// gene_ptr; 16-bit indices are widened by the staging copy), so no launch has to.
+int submit_direct_arrays(RunCtx &X, Lane &ln, int chunk_index) {
+    Session &S = X.S;
+    const BatchRequest &r = X.r;
+    Chunk &ck = X.chunks[chunk_index];
+    int rc = check_hip(hipSetDevice(ln.device), "hipSetDevice");
+    if (rc) return rc;
+    const size_t ng = size_t(ck.g1 - ck.g0);
+    const int64_t a0 = r.gene_ptr[ck.g0], a1 = r.gene_ptr[ck.g1];
+    if (a0 < 0 || a1 < a0) {
+        set_error("gene_ptr must be non-decreasing and start at a non-negative offset");
+        return GECCO_CRF_EINVAL;
+    }
+    const size_t nnz = size_t(a1 - a0);
+    if (r.degree && byte_sum(r.degree + ck.g0, ng) != uint64_t(nnz)) {
+        set_error("degree bytes do not add up to gene_ptr over a chunk (degree must equal diff(gene_ptr))");
+        return GECCO_CRF_EINVAL;
+    }
+    int64_t b0 = 0;
+    size_t nb = 0;
+    const bool markers = r.want_segments && r.seg.criterion == 1;
+    if (markers) {
+        b0 = r.seg.bio_ptr[ck.g0];
+        const int64_t b1 = r.seg.bio_ptr[ck.g1];
+        if (b0 < 0 || b1 < b0) {
+            set_error("marker_ptr must be non-decreasing and start at a non-negative offset");
+            return GECCO_CRF_EINVAL;
+        }
+        nb = size_t(b1 - b0);
+    }
+    constexpr size_t kAsk = 32768;  // bytes from which a caller's OUTPUT buffer is asked whether it is pinned
+    // An input array of kCopy bytes and more goes to device memory by a copy command on the compute stream (2.5 us + the
+    // transfer, against a PCIe round trip for every tile that reads it in place: break-even near 10 000 genes); smaller ones
+    // are read from the staging block.
+    constexpr size_t kCopy = 65536;
+    const bool c_gp = (ng + 1) * 4 >= kCopy, c_at = nnz * 4 >= kCopy && !r.attr_id16;
+    if (c_gp) {
+        if ((rc = ln.d_gp.reserve((ng + 1) * 4, "hipMalloc gene_ptr"))) return rc;
+        if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.g0, (ng + 1) * 4, hipMemcpyHostToDevice, ln.comp), "H2D gene_ptr"))) return rc;
+        S.stats.h2d_bytes += int64_t((ng + 1) * 4);
+    }
+    if (c_at) {
+        if ((rc = ln.d_at.reserve((nnz + 8) * 4, "hipMalloc attr_id"))) return rc;
+        if ((rc = check_hip(hipMemcpyAsync(ln.d_at.p, r.attr_id + a0, nnz * 4, hipMemcpyHostToDevice, ln.comp), "H2D attr_id"))) return rc;
+        S.stats.h2d_bytes += int64_t(nnz * 4);
+    }
+    const bool c_at16 = nnz * 4 >= kCopy && r.attr_id16;  // (16-bit indices: half the bytes cross, a launch widens them)
+    if (c_at16) {
+        if ((rc = ln.d_at.reserve((nnz + 8) * 4, "hipMalloc attr_id"))) return rc;
+        if ((rc = ln.d_at16.reserve((nnz + 8) * 2, "hipMalloc attr_id16"))) return rc;
+        if ((rc = check_hip(hipMemcpyAsync(ln.d_at16.p, r.attr_id16 + a0, nnz * 2, hipMemcpyHostToDevice, ln.comp), "H2D attr_id16"))) return rc;
+        S.stats.h2d_bytes += int64_t(nnz * 2);
+        if ((rc = check_hip(launch_wire_format(nullptr, 0, 0, nullptr, nullptr, reinterpret_cast<const uint16_t *>(ln.d_at16.p), int64_t(nnz),
+                                               reinterpret_cast<int32_t *>(ln.d_at.p), ln.comp), "wire format launch")))
+            return rc;
+    }
+    const int32_t *m_gp = c_gp ? reinterpret_cast<const int32_t *>(ln.d_gp.p) : nullptr;
+    const int32_t *m_at = (c_at || c_at16) ? reinterpret_cast<const int32_t *>(ln.d_at.p) : nullptr;
+    // the kernels write p / y straight into host memory only where nothing reads them again on the device (no refiner behind
+    // them) and the window kernel stores every gene exactly once (the 2-label register kernel: decided in submit)
+    double *m_p = (r.p_out && !r.want_segments && ng * 8 >= kAsk) ? mapped_or_null(r.p_out + ck.g0) : nullptr;
+    int8_t *m_y = (r.y_out && ng >= kAsk) ? mapped_or_null(r.y_out + ck.g0) : nullptr;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align256(bytes + 32);
+        return o;
+    };
+    const size_t o_gp = take(m_gp ? 0 : (ng + 1) * 4), o_at = take(m_at ? 0 : (nnz + 8) * 4),
+                 o_ann = take(r.want_segments ? ng + 32 : 0), o_bp = take(markers ? (ng + 1) * 4 : 0), o_bi = take(markers ? (nb + 4) * 4 : 0),
+                 o_p = take((r.p_out && !r.want_segments && !m_p) ? ng * 8 : 0), o_y = take((r.y_out && !m_y) ? ng + 8 : 0);
+    if ((rc = ln.h_io.reserve(off, "hipHostMalloc staging"))) return rc;
+    char *h = ln.h_io.p, *d = ln.h_io.dp;
+    ln.x_gp = m_gp;
+    if (!m_gp) {
+        std::memcpy(h + o_gp, r.gene_ptr + ck.g0, (ng + 1) * 4);
+        ln.x_gp = reinterpret_cast<const int32_t *>(d + o_gp);
+    }
+    ln.x_at = m_at;
+    if (!m_at) {
+        int32_t *dst = reinterpret_cast<int32_t *>(h + o_at);
+        if (r.attr_id16) {
+            const uint16_t *src = r.attr_id16 + a0;
+            for (size_t i = 0; i < nnz; ++i) dst[i] = src[i];
+        } else if (nnz) {
+            std::memcpy(dst, r.attr_id + a0, nnz * 4);
+        }
+        ln.x_at = reinterpret_cast<const int32_t *>(d + o_at);
+    }
+    ln.x_ann = nullptr;
+    if (r.want_segments) {  // (annotated, or the degree bytes standing in for it)
+        std::memcpy(h + o_ann, (r.annotated ? r.annotated : r.degree) + ck.g0, ng);
+        ln.x_ann = reinterpret_cast<const uint8_t *>(d + o_ann);
+    }
+    ln.x_bp = ln.x_bi = nullptr;
+    if (markers) {
+        std::memcpy(h + o_bp, r.seg.bio_ptr + ck.g0, (ng + 1) * 4);
+        if (nb) std::memcpy(h + o_bi, r.seg.bio_id + b0, nb * 4);
+        ln.x_bp = reinterpret_cast<const int32_t *>(d + o_bp);
+        ln.x_bi = reinterpret_cast<const int32_t *>(d + o_bi);
+    }
+    ln.x_p = m_p;
+    ln.x_p_host = nullptr;
+    if (r.p_out && !r.want_segments && !m_p) {
+        ln.x_p = reinterpret_cast<double *>(d + o_p);
+        ln.x_p_host = reinterpret_cast<const double *>(h + o_p);
+    }
+    ln.x_y = m_y;
+    ln.x_y_host = nullptr;
+    if (r.y_out && !m_y) {
+        ln.x_y = reinterpret_cast<int8_t *>(d + o_y);
+        ln.x_y_host = reinterpret_cast<const int8_t *>(h + o_y);
+    }
+    ln.up_chunk = chunk_index;
+    ln.up_a0 = a0;
+    ln.up_nnz = int64_t(nnz);
+    ln.up_b0 = b0;
+    return GECCO_CRF_OK;
+}
+
 // the chunk's layout (host) and its tables' upload, behind the chunk's arrays on the upload stream
 int submit_plan(RunCtx &X, Lane &ln, int chunk_index) {
     Session &S = X.S;
@@ -417,13 +585,83 @@ int submit_plan(RunCtx &X, Lane &ln, int chunk_index) {
         // stream then carries nothing but the chunks' arrays, back to back (a copy issued behind the next chunk's arrays
         // would hold this chunk's kernels back until those have crossed; every copy also costs ~10 us of engine turnaround)
         ln.plan.tables_by_kernel = true;
+        // small batches: the decoder's tables and flag bytes too are read where the host wrote them
+        ln.plan.seq_in_host_memory = X.direct && !r.want_segments && !X.full && !r.score_out;
     }
     if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.comp, false))) return rc;
     // (the whole-contig tables too are fetched by a launch on the compute stream; the refiner builds its contig flags on the device)
     if ((X.viterbi || X.full) && (rc = plan_ensure_seq(ln.plan, ln.comp, false))) return rc;
     S.stats.host_plan_seconds += now_s() - t0;
     tm.lap("plan_build", chunk_index);
+    if (X.direct) {  // (nothing is on the upload stream; the host has read the CSR's extent itself)
+        ln.plan.csr_begin = ln.up_a0;
+        ln.plan.csr_end = ln.up_a0 + ln.up_nnz;
+        return GECCO_CRF_OK;
+    }
     return check_hip(hipEventRecord(ln.ev_up, ln.up), "hipEventRecord");
+}
+
+// Direct path: every launch of the (one) chunk on the compute stream, on the addresses submit_direct_arrays chose; the host then
+// waits for that stream (retire_begin) -- no copy command, no event, no second stream.  A 50-gene contig: one launch.
+int submit_direct(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
+    Session &S = X.S;
+    const BatchRequest &r = X.r;
+    Chunk &ck = X.chunks[chunk_index];
+    int rc;
+    const int32_t ng = ck.g1 - ck.g0;
+    const int32_t *d_gp = ln.x_gp, *d_at = ln.x_at - ln.up_a0;  // (gene_ptr keeps the caller's offsets)
+    // the register-resident 2-label kernel stores every gene's probability exactly once: it may write to host memory.  The
+    // other window kernels accumulate with atomic maxima on a zeroed array: device memory, copied out on the same stream.
+    const bool p_to_host = ln.x_p && !ln.plan.general && ln.plan.fast_ok;
+    double *d_p = nullptr;
+    if (X.windowed) {
+        if (p_to_host) {
+            d_p = ln.x_p;
+        } else {
+            if ((rc = ln.d_p.reserve(size_t(ng) * 8, "hipMalloc p"))) return rc;
+            d_p = reinterpret_cast<double *>(ln.d_p.p);
+        }
+    }
+    if (X.windowed && X.viterbi) {
+        // marginals, then the labels from the score differences the tiles left behind (the pipelined pair on one batch)
+        if ((rc = plan_run_decode_pipelined(&ln.plan, d_gp, d_at, r.label, d_p, nullptr, nullptr, ln.comp))) return rc;
+        if ((rc = plan_run_decode_pipelined(nullptr, nullptr, nullptr, r.label, nullptr, &ln.plan, ln.x_y, ln.comp))) return rc;
+    } else if (X.windowed) {
+        if ((rc = plan_run_windowed(ln.plan, d_gp, d_at, r.label, d_p, ln.comp))) return rc;
+    } else if (X.viterbi) {
+        if ((rc = plan_run_viterbi(ln.plan, d_gp, d_at, ln.x_y, nullptr, ln.comp))) return rc;
+    }
+    if (r.want_segments) {
+        const int32_t nc = ck.c1 - ck.c0;
+        const size_t cap = std::min<size_t>(size_t(ng), size_t(ng) / 2 + size_t(nc)) + 1;
+        ln.seg_cap = int32_t(cap);
+        ln.o_off = 256;
+        ln.o_rows = ln.o_off + align256((cap + 1) * 4);
+        ln.o_p = ln.o_rows + align256(cap * 16);
+        if ((rc = ln.h_seg.reserve(ln.o_p + 256, "hipHostMalloc segments"))) return rc;
+        if (r.seg_p_out && (rc = ln.d_segp.reserve(size_t(ng) * 8 + 8, "hipMalloc cluster probabilities"))) return rc;
+        char *dp = ln.h_seg.dp;
+        SegParams sp = r.seg;
+        sp.carry = 0;
+        sp.row_contig0 = ck.c0;
+        sp.row_gene0 = ck.g0;
+        sp.bio_ptr = sp.bio_id = nullptr;
+        if (sp.criterion == 1) {
+            sp.bio_ptr = ln.x_bp;
+            sp.bio_id = ln.x_bi - ln.up_b0;
+        }
+        if ((rc = plan_run_segment(ln.plan, d_p, ln.x_ann, sp, reinterpret_cast<int32_t *>(dp + ln.o_rows), int32_t(cap),
+                                   reinterpret_cast<int32_t *>(dp + ln.o_off), reinterpret_cast<int32_t *>(dp), ln.comp,
+                                   r.seg_p_out ? reinterpret_cast<double *>(ln.d_segp.p) : nullptr, ng)))
+            return rc;
+    }
+    if (r.p_out && !p_to_host) {  // (p lives in device memory: the refiner reads it, or a window kernel with atomic maxima wrote it)
+        S.stats.d2h_bytes += int64_t(ng) * 8;
+        if ((rc = check_hip(hipMemcpyAsync(r.p_out + ck.g0, d_p, size_t(ng) * 8, hipMemcpyDeviceToHost, ln.comp), "D2H p"))) return rc;
+        ln.x_p_host = nullptr;
+    }
+    (void)D;
+    return GECCO_CRF_OK;
 }
 
 int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
@@ -439,6 +677,7 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
     ln.up_chunk = -1;
     const int64_t a0 = ln.up_a0, b0 = ln.up_b0;
     const size_t nnz = size_t(ln.up_nnz), L = size_t(m.L);
+    if (X.direct) return submit_direct(X, D, ln, chunk_index);
     if ((rc = check_hip(hipStreamWaitEvent(ln.comp, ln.ev_up, 0), "hipStreamWaitEvent"))) return rc;
     if (ng == 0) return check_hip(hipEventRecord(ln.done, ln.comp), "hipEventRecord");
     // the wire format's two launches: degree bytes -> row pointers, 16-bit attribute indices -> 32-bit ones
@@ -553,9 +792,18 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
 int retire_begin(RunCtx &X, Lane &ln) {
     if (ln.chunk < 0) return GECCO_CRF_OK;
     TraceMark tm;
-    int rc = check_hip(hipEventSynchronize(ln.done), "chunk completion");
-    tm.lap("wait", ln.chunk);
+    int rc;
     Chunk &ck = X.chunks[ln.chunk];
+    if (X.direct) {
+        // everything of the chunk went to the compute stream; outputs the kernels left in the staging block go to the caller
+        rc = check_hip(hipStreamSynchronize(ln.comp), "chunk completion");
+        const size_t ng = size_t(ck.g1 - ck.g0);
+        if (!rc && ln.x_p_host && X.r.p_out) std::memcpy(X.r.p_out + ck.g0, ln.x_p_host, ng * 8);
+        if (!rc && ln.x_y_host && X.r.y_out) std::memcpy(X.r.y_out + ck.g0, ln.x_y_host, ng);
+    } else {
+        rc = check_hip(hipEventSynchronize(ln.done), "chunk completion");
+    }
+    tm.lap("wait", ln.chunk);
     if (rc) {
         ln.chunk = -1;
         return rc;
@@ -679,12 +927,23 @@ int session_run(Session &S, const BatchRequest &r) {
     if (hipGetDevice(&prev_device) != hipSuccess) prev_device = -1;
 
     std::vector<Chunk> chunks;
-    // cluster calls launch eight more (short) kernels per chunk and download next to nothing: twice the chunk size
-    cut_chunks(r, r.want_segments ? int32_t(std::min<int64_t>(2 * int64_t(S.chunk_genes), 1 << 28)) : S.chunk_genes, int(S.devs.size()),
-               chunks);
-    deal_chunks(chunks, int(S.devs.size()));
+    // a small batch is ONE chunk on the first device, its kernels working on pinned host memory (no copy commands)
+    // (a caller who asked for chunks smaller than the batch gets chunks)
+    const bool direct = n_genes > 0 && n_genes <= std::min(r.want_segments ? S.direct_genes / 2 : S.direct_genes, S.chunk_genes) && !full && !r.score_out;
+    if (direct) {
+        Chunk ck;
+        ck.c1 = r.n_contigs;
+        ck.g1 = int32_t(n_genes);
+        chunks.push_back(std::move(ck));
+    } else {
+        // cluster calls launch eight more (short) kernels per chunk and download next to nothing: twice the chunk size
+        cut_chunks(r, r.want_segments ? int32_t(std::min<int64_t>(2 * int64_t(S.chunk_genes), 1 << 28)) : S.chunk_genes, int(S.devs.size()),
+                   chunks);
+        deal_chunks(chunks, int(S.devs.size()));
+    }
     S.stats.n_chunks = int32_t(chunks.size());
-    RunCtx X{S, r, chunks, windowed, viterbi, full, windowed ? r.window : 1, windowed ? r.step : 1, windowed ? r.pad : 1};
+    S.stats.direct = direct ? 1 : 0;
+    RunCtx X{S, r, chunks, windowed, viterbi, full, windowed ? r.window : 1, windowed ? r.step : 1, windowed ? r.pad : 1, direct};
     // (every lane is idle here: start from lane 0 again, so that calls of a chunk or two keep to the lanes whose buffers and
     // workspaces exist already instead of walking the ring and allocating in each of its lanes in turn)
     for (auto &d : S.devs) {
@@ -692,8 +951,21 @@ int session_run(Session &S, const BatchRequest &r) {
         for (Lane &ln : d->lanes) ln.up_chunk = -1;
     }
     // per-device queues in batch order; devices are fed round-robin so that all of them start at once
+    // A chunk without genes (contigs of length 0 only) has nothing to upload, launch or download and never takes a lane: in a
+    // decode call its lane would otherwise come round to the one whose labels are still pending without ever recording an
+    // event for it.  Per-contig outputs of such contigs are what an empty sequence gives: score 0, log Z 0.
     std::vector<std::vector<int>> queue(S.devs.size());
-    for (size_t i = 0; i < chunks.size(); ++i) queue[size_t(chunks[i].device_slot)].push_back(int(i));
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        const Chunk &ck = chunks[i];
+        if (ck.g1 > ck.g0) {
+            queue[size_t(ck.device_slot)].push_back(int(i));
+            continue;
+        }
+        for (int32_t c = ck.c0; c < ck.c1; ++c) {
+            if (r.score_out) r.score_out[c] = 0.0;
+            if (r.lognorm_out) r.lognorm_out[c] = 0.0;
+        }
+    }
     std::vector<size_t> head(S.devs.size(), 0);
     int rc = GECCO_CRF_OK;
     for (bool any = true; any && !rc;) {
@@ -706,12 +978,21 @@ int session_run(Session &S, const BatchRequest &r) {
             D.next_lane = (D.next_lane + 1) % kLanes;
             if ((rc = retire(X, ln))) break;
             const int mine = queue[d][head[d]++];
-            if (ln.up_chunk != mine && (rc = submit_uploads(X, ln, mine))) break;
+            if (X.direct) {
+                if ((rc = submit_direct_arrays(X, ln, mine))) break;
+            } else if (ln.up_chunk != mine && (rc = submit_uploads(X, ln, mine))) {
+                break;
+            }
             if ((rc = submit_plan(X, ln, mine))) break;
             // the next chunk's arrays follow this one's arrays and tables through the copy engine, if the lane they go to is
-            // idle: they are on their way while the host launches this chunk and lays out the next
+            // idle -- or has finished meanwhile: it is then retired here instead of at its own turn --: they are on their way
+            // while the host launches this chunk and lays out the next
             Lane &nl = D.lanes[D.next_lane];
-            if (head[d] < queue[d].size() && &nl != &ln && nl.chunk < 0 && (rc = submit_uploads(X, nl, queue[d][head[d]]))) break;
+            if (head[d] < queue[d].size() && &nl != &ln) {
+                if (nl.chunk >= 0 && &nl != D.pending && hipEventQuery(nl.done) == hipSuccess && (rc = retire(X, nl))) break;
+                (void)hipGetLastError();  // (hipErrorNotReady of the query is not an error of this call)
+                if (nl.chunk < 0 && (rc = submit_uploads(X, nl, queue[d][head[d]]))) break;
+            }
             rc = submit(X, D, ln, mine);
         }
     }

@@ -51,6 +51,9 @@ struct SessionStats {
     int64_t h2d_bytes = 0, d2h_bytes = 0;
     double host_plan_seconds = 0.0;  // time the submitting thread spent building chunk layouts
     double wall_seconds = 0.0;
+    double host_issue_seconds = 0.0;  // time the submitting threads spent issuing work: HIP API calls + chunk layouts (all devices)
+    int32_t host_threads = 1;         // threads that issued the batch's work
+    int32_t direct = 0;  // the batch took the direct path (one chunk, kernels on pinned host memory, no copy commands)
 };
 
 struct Session;
@@ -58,6 +61,7 @@ int session_create(const Model &m, const int32_t *devices, int32_t n_devices, Se
 void session_destroy(Session *s);
 int session_run(Session &s, const BatchRequest &r);
 void session_set_chunk_genes(Session &s, int32_t genes);
+void session_set_direct_genes(Session &s, int32_t genes);
 SessionStats session_stats(const Session &s);
 
 }  // namespace gecco

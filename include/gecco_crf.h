@@ -48,7 +48,7 @@ typedef struct gecco_crf_plan gecco_crf_plan;
 
 /* Thread-local description of the last error returned on this thread. */
 const char *gecco_crf_last_error(void);
-/* ABI version: major*100 + minor*10 + patch (2.1.0 = 210). */
+/* ABI version: major*100 + minor*10 + patch (2.2.0 = 220). */
 int gecco_crf_version(void);
 
 /* ---- model (replaces [EXT] pycrfsuite.Tagger.open / labels() / info(); the blob is the
@@ -235,9 +235,25 @@ int gecco_crf_session_create(const gecco_crf_model *m, const int32_t *devices, i
                              gecco_crf_session **out);
 void gecco_crf_session_free(gecco_crf_session *s);
 int gecco_crf_session_set_chunk_genes(gecco_crf_session *s, int32_t genes); /* default 2^19 */
+/* Small batches -- what `gecco run` on ONE genome hands over: a contig of a few dozen genes, BASELINE.json configs[0],
+ * /root/reference/tests/test_cli/test_run.py:35-70 -- take the DIRECT path: the batch is one chunk, its arrays are read by the
+ * kernels from pinned host memory (the caller's own buffers when they come from gecco_crf_host_alloc and are large enough for
+ * that to matter, a pinned staging copy otherwise) and its outputs are written there; no copy command, no second stream, the
+ * call is its launches and one wait (input arrays of 64 KB and more are copied to device memory by a copy command on that same
+ * stream).  `genes` = largest batch that takes it (default 131072, half of that for cluster calls; 0 = never; never more
+ * than the chunk size).  Same output bits as the chunked path.  Whole-contig marginals and path scores always take the chunked path. */
+int gecco_crf_session_set_direct_genes(gecco_crf_session *s, int32_t genes);
 /* Figures of the last batch (any pointer may be NULL). */
 int gecco_crf_session_stats(const gecco_crf_session *s, int32_t *n_chunks, int64_t *h2d_bytes,
                             int64_t *d2h_bytes, double *host_plan_seconds, double *wall_seconds);
+/* The same and more as one struct: whether the batch took the direct path, and the time the submitting host threads spent
+ * issuing work (HIP API calls + chunk layouts), which is what bounds a session over many devices. */
+typedef struct {
+    int32_t n_chunks, n_devices, direct, host_threads;
+    int64_t h2d_bytes, d2h_bytes;
+    double host_plan_seconds, host_issue_seconds, wall_seconds;
+} gecco_crf_session_stats_t;
+int gecco_crf_session_stats_ex(const gecco_crf_session *s, gecco_crf_session_stats_t *out);
 /* = gecco_crf_windowed_marginals over the session's devices. */
 int gecco_crf_session_windowed(gecco_crf_session *s, const int32_t *contig_ptr, int32_t n_contigs,
                                const int32_t *gene_ptr, const int32_t *attr_id, int32_t window,

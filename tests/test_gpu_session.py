@@ -72,6 +72,10 @@ def test_session_windowed_chunks(nat, real_model, oracle_model, chunk, pad, pinn
         got = ses.windowed_marginals(cptr, gptr, attr, 20, 1, 1, pad, out=out)
         _same(got, exp)
     st = ses.stats()
+    if chunk >= int(cptr[-1]):  # (a batch of one chunk, small enough for the direct path: no copy commands at all)
+        assert st["direct"] == 1 and st["n_chunks"] == 1 and st["d2h_bytes"] == 0
+        return
+    assert st["direct"] == 0
     assert st["n_chunks"] == max(1, min(len(cptr) - 1, (int(cptr[-1]) + chunk // 2) // chunk))
     assert st["d2h_bytes"] == 8 * len(exp)
     assert st["h2d_bytes"] == 4 * (len(gptr) + st["n_chunks"] - 1 + len(attr))
@@ -122,6 +126,30 @@ def test_session_decode_one_launch_per_chunk(nat, real_model, oracle_model, devi
             _same(p, ep)
             np.testing.assert_array_equal(y.astype(np.int32), ey)
         assert ses.stats()["n_chunks"] >= (3 if chunk < 100000 else 1)
+
+
+@pytest.mark.parametrize("lengths", [[5000, 0, 0, 0, 0], [3000, 0, 0, 0, 0, 700, 0, 0, 0, 0, 0, 1500], [0, 0, 0, 0, 0, 0]])
+def test_session_decode_empty_chunks_never_take_a_lane(nat, real_model, oracle_model, lengths):
+    """Chunks without genes behind a scored one (contigs of length 0: one contig per chunk once the chunk size is small
+    enough) must not come round to the lane whose labels are still pending: marginals, labels and path scores of the
+    scored chunks stay the oracle's (advisor finding of round 4 on crf_session.cpp)."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(5)
+    cptr, gptr, attr = synth_contigs(rng, lengths, oracle_model["state"].shape[0])
+    ep = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, 20, 1, 1, True)
+    ey, es = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    ses = nat.Session(real_model, [0])
+    ses.set_chunk_genes(1024)
+    for _ in range(3):
+        p, y = ses.decode(cptr, gptr, attr, 20)
+        if sum(lengths):
+            assert ses.stats()["n_chunks"] >= min(len(lengths), 5)
+        _same(p, ep)
+        np.testing.assert_array_equal(y.astype(np.int32), ey)
+    y2, sc = real_model.viterbi(cptr, gptr, attr)
+    np.testing.assert_array_equal(y2.astype(np.int32), ey)
+    np.testing.assert_allclose(sc, es, rtol=1e-12, atol=1e-12)
 
 
 def test_session_unknown_attribute_ids_carry_no_weight(nat, real_model, oracle_model):
