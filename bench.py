@@ -545,6 +545,15 @@ def main() -> None:
             "frac": ab8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "ms_per_step": el8 / min(args.steps, 200) * 1e3,
             "ratio_form_fallback_frac": _ratio_form_fallback_fraction(w8, r8.plan.num_tiles, _tile_out(r8.plan, r8.n_genes)),
         }
+        if not args.no_levels:
+            # the cluster-call levels on this law too: 8d's law puts nine genes in ten into a cluster (a degenerate refiner
+            # input, and "rows + their probabilities" is then a download of nearly everything); this one calls few
+            try:
+                from gecco_amd import levels as _lv2
+
+                out["levels_" + other + "_law"] = _lv2.cluster_levels_for(m8, w8, devices=(local_rank,))
+            except Exception as err:
+                out["levels_" + other + "_law"] = {"error": f"{type(err).__name__}: {err}"}
         del r8, m8, w8
         torch.cuda.empty_cache()
 
@@ -567,9 +576,11 @@ def main() -> None:
         nvis = torch.cuda.device_count()
         try:
             smd = {"visible_devices": nvis,
-                   "one_device": levels.host_buffer_levels(model, wl, devices=(0,), reps=5)["one_shot_pinned"]}
+                   "one_device": levels.multi_entry_level(model, wl, (0,)),
+                   # the multi-device machinery on the hardware there is: eight entries of device 0, a submitting thread each
+                   "eight_entries_of_device_0": levels.multi_entry_level(model, wl, (0,) * 8)}
             if nvis > 1:
-                smd["all_devices"] = levels.host_buffer_levels(model, wl, devices=tuple(range(nvis)), reps=5)["one_shot_pinned"]
+                smd["all_devices"] = levels.multi_entry_level(model, wl, tuple(range(nvis)))
                 smd["speedup"] = smd["one_device"]["ms"] / smd["all_devices"]["ms"]
             else:
                 smd["all_devices"] = None
@@ -643,7 +654,14 @@ def main() -> None:
         out["cpu_baseline_all_cores"] = {"value": ng / best, "unit": "genes/s", "cores": ncpu, "kind": "port",
                                          "speedup_over_one_thread": (ng / best) / (ng / dt),
                                          "sample": f"same sample, OpenMP over ranges of 8 contigs inside the C oracle, best of 2; {cpu_note}"}
+        try:
+            from gecco_amd import levels as _lv
+
+            golden_tables = _lv.golden_table_identity(os.path.join(ROOT, "tests", "golden"))
+        except Exception as err:
+            golden_tables = {"error": f"{type(err).__name__}: {err}"}
         out["parity"] = {
+            "golden_tables": golden_tables,
             "max_abs_dp_vs_oracle": float(np.abs(got - p_ref).max()),
             "cluster_call_mismatches": int(((got > 0.8) != (p_ref > 0.8)).sum()),
             "genes_checked": ng,

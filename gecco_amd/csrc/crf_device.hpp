@@ -32,7 +32,8 @@ struct WinArgs {
     //   mu01 = m01*m10/m00^2, mu11 = m11/m00, kappa = m10/m00, rho = mu11/mu01  with m = exp(trans)
     double mu01, rho, kappa_over_mu01, inv_kappa;
     double expc[12];            // 1/13!, 1/12!, ..., 1/2!: Taylor coefficients of exp (SGPR-resident)
-    double ratio_dmax;          // < 0: every wave of the ratio-form kernels takes the max-normalised form (GECCO_CRF_RATIO=0: A/B runs)
+    double ratio_zmax;          // a window whose forward pass ends on Z >= this (1e250) is repeated in the max-normalised form; -1: every
+                                // window is (GECCO_CRF_RATIO=0: A/B runs, tests)
     double g00, g01, g10, g11;  // exp(trans - max), (other, label) order: generic kernel
     int32_t generic;            // 1: dispatch to the generic window kernel
     const double *exp_trans;   // [L*L] exp(trans) for the generic kernel

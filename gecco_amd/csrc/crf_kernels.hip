@@ -485,10 +485,14 @@ __device__ __forceinline__ void windowed_tile(const WinArgs &P, WinSmem<WMAX, NT
             }
             asm volatile("" ::: "memory");
             double z = fma(a1, P.inv_kappa, a0);
-            // (ratio_dmax < 0: GECCO_CRF_RATIO=0, every wave takes the max-normalised form -- A/B runs, tests)
-            const bool renorm = __builtin_amdgcn_ballot_w64(!(z < 1.0e250) || P.ratio_dmax < 0.0) != 0;
+            // (ratio_zmax = 1e250; GECCO_CRF_RATIO=0 sets it to -1: every window takes the max-normalised form -- A/B runs, tests)
+            const bool renorm = __builtin_amdgcn_ballot_w64(!(z < P.ratio_zmax)) != 0;
             // max-normalised pair of a slot from its ratio constant: r > mu01 <=> d > 0, where (e0, f) = (exp(-d), mu01)
-            // = (mu01 / r, mu01); else (1, mu01 exp(d)) = (1, r)
+            // = (mu01 / r, mu01); else (1, mu01 exp(d)) = (1, r).
+            // (The fallback is taken by the WAVE: a window that would have stayed in the ratio form gets the other form's
+            // rounding when a neighbour in its wave needs it, so the last bits of such a window -- 1e-15 -- depend on how the
+            // batch was tiled.  Making the choice per window was tried in round 5 -- the flag in a register, in LDS, in the
+            // sign bit of A1[0] --: each cost the 64-register kernels a spill on the hot path.)
             auto pair_of = [&](double r, double &e0, double &f) {
                 const bool pos = r > P.mu01;
                 const double rc = fmin(r, 1.0e300);  // (r = inf for d > 709: e0 = 0 as exp(-d) would be)

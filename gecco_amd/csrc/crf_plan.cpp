@@ -635,7 +635,7 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     fill_exp_coefficients(a.expc);
     {
         const char *env = std::getenv("GECCO_CRF_RATIO");
-        a.ratio_dmax = (env && env[0] == '0') ? -1e300 : 600.0 / double(p.W);
+        a.ratio_zmax = (env && env[0] == '0') ? -1.0 : 1.0e250;
     }
     a.csr_begin = int32_t(p.csr_begin);  // (row pointers are 32-bit)
     a.csr_end = int32_t(p.csr_end);

@@ -6,6 +6,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -88,7 +91,12 @@ struct HostBuf {  // grow-only pinned, device-visible host block: kernels write 
 
 struct Chunk {
     int32_t c0 = 0, c1 = 0;  // contigs
-    int32_t g0 = 0, g1 = 0;  // genes
+    int32_t g0 = 0, g1 = 0;  // genes whose results the chunk delivers
+    // genes the chunk uploads and scores: [g0, g1) for a chunk of whole contigs; for a PIECE of a contig too long for one
+    // chunk (cut_chunks) the W - 1 genes either side as well -- every window that covers a gene of [g0, g1) lies inside
+    // [u0, u1), so the piece is scored as a contig of its own and its inner genes get the bits they get in the whole contig
+    int32_t u0 = 0, u1 = 0;
+    bool piece = false;
     int32_t device_slot = 0;
     // segment rows of the chunk, translated to batch indices, and the probabilities of their genes
     std::vector<int32_t> rows;
@@ -110,6 +118,7 @@ struct Lane {
     int up_chunk = -1;  // chunk whose arrays were uploaded ahead of its submission (-1: none)
     int64_t up_a0 = 0, up_nnz = 0, up_b0 = 0;
     DevBuf d_gp, d_at, d_at16, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg, d_deg, d_deg_ws, d_segp;
+    SessionStats *st = nullptr;  // the device's share of the batch's figures (merged when the batch is done)
     HostBuf h_io;   // direct path (small batches): the chunk's arrays and outputs in pinned, device-visible memory
     // direct path: device-visible addresses of the chunk's arrays (the staging block, or the caller's own pinned buffers) and
     // what the host copies out of the staging block once the launch has completed
@@ -127,7 +136,11 @@ struct Lane {
 
 struct DeviceCtx {
     int device = -1;
+    SessionStats stats;  // this device's share of the last batch (written by the thread that drives the device)
+    int rc = 0;          // ... and how its submissions ended
+    std::string err;
     hipStream_t up = nullptr, comp = nullptr, down = nullptr;
+    bool owns_streams = true;  // (a device listed twice: the later entries use the first one's three streams)
     Lane lanes[kLanes];
     int next_lane = 0;
     // decode calls (marginals + labels): the launch of chunk k carries the Viterbi workgroups of the device's chunk k - 1
@@ -139,8 +152,73 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 }  // namespace
 
+// One thread per device entry beyond the first, parked between batches: run(n, job) has the calling thread do job(0) and
+// worker k do job(k) and returns when all are done.
+class Workers {
+public:
+    ~Workers() { stop(); }
+    void run(int n, const std::function<void(int)> &job) {
+        {
+            std::unique_lock<std::mutex> lock(mu_);
+            while (int(th_.size()) < n - 1) {
+                const int slot = int(th_.size()) + 1;
+                th_.emplace_back([this, slot] { loop(slot); });
+            }
+            job_ = &job;
+            n_ = n;
+            pending_ = n - 1;
+            ++gen_;
+        }
+        cv_go_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_done_.wait(lock, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    void stop() {
+        {
+            std::unique_lock<std::mutex> lock(mu_);
+            quit_ = true;
+        }
+        cv_go_.notify_all();
+        for (std::thread &t : th_)
+            if (t.joinable()) t.join();
+        th_.clear();
+    }
+
+private:
+    void loop(int slot) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)> *job = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_go_.wait(lock, [&] { return quit_ || gen_ != seen; });
+                if (quit_) return;
+                seen = gen_;
+                if (slot < n_) job = job_;  // (a batch over fewer entries than there are workers: nothing to do)
+            }
+            if (!job) continue;
+            (*job)(slot);
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                --pending_;
+            }
+            cv_done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_go_, cv_done_;
+    const std::function<void(int)> *job_ = nullptr;
+    uint64_t gen_ = 0;
+    int n_ = 0, pending_ = 0;
+    bool quit_ = false;
+};
+
 struct Session {
     const Model *model = nullptr;
+    Workers workers;
     std::vector<std::unique_ptr<DeviceCtx>> devs;
     int32_t chunk_genes = 1 << 19;
     std::mutex mu;  // one batch at a time per session
@@ -156,6 +234,7 @@ struct Session {
 };
 
 Session::~Session() {
+    workers.stop();
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     for (auto &d : devs) {
@@ -168,8 +247,9 @@ Session::~Session() {
             for (hipEvent_t e : {ln.ev_up, ln.ev_comp, ln.done})
                 if (e) (void)hipEventDestroy(e);
         }
-        for (hipStream_t st : {d->up, d->comp, d->down})
-            if (st) (void)hipStreamDestroy(st);
+        if (d->owns_streams)
+            for (hipStream_t st : {d->up, d->comp, d->down})
+                if (st) (void)hipStreamDestroy(st);
     }
     devs.clear();  // plans free their blocks under their own device guard
     if (prev >= 0) (void)hipSetDevice(prev);
@@ -198,21 +278,34 @@ int session_create(const Model &m, const int32_t *devices, int32_t n_devices, Se
             set_error("device index out of range");
             return GECCO_CRF_ENODEV;
         }
-        // a device may be listed more than once: every entry gets its own ring of lanes
+        // a device may be listed more than once: every entry gets its own ring of lanes and its own submitting thread, but a
+        // physical device has ONE stream per direction (copies of one direction queue up behind each other anyway; three
+        // streams per entry only multiplied the hardware queues the device has to poll)
         int rc = check_hip(hipSetDevice(devices[i]), "hipSetDevice");
         if (rc) return rc;
         std::unique_ptr<DeviceCtx> d(new DeviceCtx());
         d->device = devices[i];
         s->devs.push_back(std::move(d));  // from here on the session's destructor cleans up
         DeviceCtx &D = *s->devs.back();
-        for (hipStream_t *st : {&D.up, &D.comp, &D.down})
-            if ((rc = check_hip(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
+        const DeviceCtx *first = nullptr;
+        for (size_t k = 0; k + 1 < s->devs.size() && !first; ++k)
+            if (s->devs[k]->device == devices[i]) first = s->devs[k].get();
+        if (first) {
+            D.up = first->up;
+            D.comp = first->comp;
+            D.down = first->down;
+            D.owns_streams = false;
+        } else {
+            for (hipStream_t *st : {&D.up, &D.comp, &D.down})
+                if ((rc = check_hip(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
+        }
         for (Lane &ln : D.lanes) {
             ln.device = devices[i];
             ln.up = D.up;
             ln.comp = D.comp;
             ln.down = D.down;
             ln.plan.async_tables = true;
+            ln.st = &D.stats;
             for (hipEvent_t *e : {&ln.ev_up, &ln.ev_comp, &ln.done})
                 if ((rc = check_hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate"))) return rc;
         }
@@ -234,37 +327,91 @@ SessionStats session_stats(const Session &s) { return s.stats; }
 
 namespace {
 
-// Cut the batch into chunks of about `target` genes at contig boundaries (a contig is never split:
-// its windows overlap).  With several devices there are at least two chunks per device when the
-// batch is large enough to make that worthwhile.
-void cut_chunks(const BatchRequest &r, int32_t target, int n_devices, std::vector<Chunk> &chunks) {
+// Cut the batch into chunks of about `target` genes.  Chunks end at contig boundaries; a contig much longer than a chunk is
+// cut into PIECES when the call allows it (`split_window` > 0: windowed marginals only -- every window is independent,
+// /root/reference/gecco/crf/__init__.py:251-256, so a piece plus the W - 1 genes either side of it is scored as a contig of its
+// own; whole-contig recursions and the refiner need the contig in one place).  With several devices there are at
+// least two chunks per device when the batch is large enough to make that worthwhile.
+void cut_chunks(const BatchRequest &r, int32_t target, int n_devices, std::vector<Chunk> &chunks, int32_t split_window = 0,
+                int32_t split_step = 1) {
     chunks.clear();
     const int32_t nc = r.n_contigs;
     if (nc <= 0) return;
     const int64_t n = int64_t(r.contig_ptr[nc]) - r.contig_ptr[0];
     int64_t want = std::max<int64_t>(1, (n + target / 2) / target);
     if (n_devices > 1) want = std::max<int64_t>(want, std::min<int64_t>(2 * n_devices, std::max<int64_t>(1, n / 65536)));
-    want = std::min<int64_t>(want, nc);
-    const double per = double(n) / double(want);
-    int32_t c = 0;
-    for (int64_t k = 0; k < want && c < nc; ++k) {
-        Chunk ck;
-        ck.c0 = c;
-        const int64_t goal = r.contig_ptr[0] + int64_t(per * double(k + 1) + 0.5);
-        if (k == want - 1) {
-            c = nc;
-        } else {
-            // first contig boundary at or past the goal, leaving at least one contig per remaining chunk
-            const int32_t *e = std::lower_bound(r.contig_ptr + c + 1, r.contig_ptr + nc, int32_t(std::min<int64_t>(goal, INT32_MAX)));
-            c = int32_t(e - r.contig_ptr);
-            c = std::min<int32_t>(c, nc - int32_t(want - 1 - k));
-            c = std::max<int32_t>(c, ck.c0 + 1);
+    const double per = double(n) / double(std::max<int64_t>(want, 1));
+    // a contig is "long" when it alone would make a chunk half as large again as the others
+    const int64_t long_genes = std::max<int64_t>(int64_t(per * 1.5), 4 * int64_t(split_window) + 1024);
+    bool any_long = false;
+    if (split_window > 0)
+        for (int32_t c = 0; c < nc && !any_long; ++c) any_long = int64_t(r.contig_ptr[c + 1]) - r.contig_ptr[c] > long_genes;
+    if (!any_long) {
+        want = std::min<int64_t>(want, nc);
+        const double per_c = double(n) / double(want);
+        int32_t c = 0;
+        for (int64_t k = 0; k < want && c < nc; ++k) {
+            Chunk ck;
+            ck.c0 = c;
+            const int64_t goal = r.contig_ptr[0] + int64_t(per_c * double(k + 1) + 0.5);
+            if (k == want - 1) {
+                c = nc;
+            } else {
+                // first contig boundary at or past the goal, leaving at least one contig per remaining chunk
+                const int32_t *e = std::lower_bound(r.contig_ptr + c + 1, r.contig_ptr + nc, int32_t(std::min<int64_t>(goal, INT32_MAX)));
+                c = int32_t(e - r.contig_ptr);
+                c = std::min<int32_t>(c, nc - int32_t(want - 1 - k));
+                c = std::max<int32_t>(c, ck.c0 + 1);
+            }
+            ck.c1 = c;
+            ck.g0 = ck.u0 = r.contig_ptr[ck.c0];
+            ck.g1 = ck.u1 = r.contig_ptr[ck.c1];
+            chunks.push_back(std::move(ck));
         }
-        ck.c1 = c;
-        ck.g0 = r.contig_ptr[ck.c0];
-        ck.g1 = r.contig_ptr[ck.c1];
-        chunks.push_back(std::move(ck));
+        return;
     }
+    // some contig is long: runs of whole contigs of about `per` genes, long contigs in pieces of about `per` genes
+    const int32_t halo = split_window - 1;
+    Chunk cur;
+    bool open = false;
+    auto close = [&](int32_t c_end) {
+        if (!open) return;
+        cur.c1 = c_end;
+        cur.g1 = cur.u1 = r.contig_ptr[c_end];
+        chunks.push_back(cur);
+        open = false;
+    };
+    for (int32_t c = 0; c < nc; ++c) {
+        const int32_t s0 = r.contig_ptr[c], s1 = r.contig_ptr[c + 1];
+        const int64_t len = int64_t(s1) - s0;
+        if (len > long_genes) {
+            close(c);
+            const int64_t pieces = std::max<int64_t>(2, (len + int64_t(per) / 2) / std::max<int64_t>(int64_t(per), 1));
+            for (int64_t k = 0; k < pieces; ++k) {
+                Chunk pk;
+                pk.piece = true;
+                pk.c0 = c;
+                pk.c1 = c + 1;
+                pk.g0 = int32_t(s0 + len * k / pieces);
+                pk.g1 = int32_t(s0 + len * (k + 1) / pieces);
+                // the halo: W - 1 genes either side, the left end moved down to a window start of the contig (step > 1)
+                int64_t lo = std::max<int64_t>(s0, int64_t(pk.g0) - halo);
+                lo -= (lo - s0) % split_step;
+                pk.u0 = int32_t(lo);
+                pk.u1 = int32_t(std::min<int64_t>(s1, int64_t(pk.g1) + halo));
+                chunks.push_back(pk);
+            }
+            continue;
+        }
+        if (!open) {
+            cur = Chunk{};
+            cur.c0 = c;
+            cur.g0 = cur.u0 = s0;
+            open = true;
+        }
+        if (int64_t(s1) - cur.g0 >= int64_t(per)) close(c + 1);
+    }
+    close(nc);
 }
 
 // Chunks to devices, longest first onto the least loaded device (the greedy partition of SURVEY.md
@@ -323,7 +470,7 @@ int finish_pending(RunCtx &X, DeviceCtx &D) {
     D.pending = nullptr;
     const Chunk &pk = X.chunks[pl.chunk];
     const size_t ng = size_t(pk.g1 - pk.g0);
-    X.S.stats.d2h_bytes += int64_t(ng);
+    pl.st->d2h_bytes += int64_t(ng);
     int rc = check_hip(hipMemcpyAsync(X.r.y_out + pk.g0, pl.d_y.p, ng, hipMemcpyDeviceToHost, pl.down), "D2H labels");
     if (rc) return rc;
     return check_hip(hipEventRecord(pl.done, pl.down), "hipEventRecord");
@@ -345,14 +492,13 @@ int flush_pending(RunCtx &X, DeviceCtx &D) {
 // the bulk uploads of a chunk into an idle lane.  Issued one chunk ahead (session_run): the copy engine then goes from one
 // chunk's arrays to the next one's while the host still lays out and launches the first
 int submit_uploads(RunCtx &X, Lane &ln, int chunk_index) {
-    Session &S = X.S;
     const BatchRequest &r = X.r;
     Chunk &ck = X.chunks[chunk_index];
     int rc = check_hip(hipSetDevice(ln.device), "hipSetDevice");
     if (rc) return rc;
-    const int32_t ng = ck.g1 - ck.g0;
+    const int32_t ng = ck.u1 - ck.u0;
     TraceMark tm;
-    const int64_t a0 = ng ? r.gene_ptr[ck.g0] : 0, a1 = ng ? r.gene_ptr[ck.g1] : 0;
+    const int64_t a0 = ng ? r.gene_ptr[ck.u0] : 0, a1 = ng ? r.gene_ptr[ck.u1] : 0;
     if (a0 < 0 || a1 < a0) {
         set_error("gene_ptr must be non-decreasing and start at a non-negative offset");
         return GECCO_CRF_EINVAL;
@@ -367,36 +513,36 @@ int submit_uploads(RunCtx &X, Lane &ln, int chunk_index) {
             if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
             if ((rc = ln.d_deg.reserve(size_t(ng) + 32, "hipMalloc degrees"))) return rc;
             if ((rc = ln.d_deg_ws.reserve(degree_scratch_bytes(ng), "hipMalloc degree scan"))) return rc;
-            if ((rc = check_hip(hipMemcpyAsync(ln.d_deg.p, r.degree + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D degrees")))
+            if ((rc = check_hip(hipMemcpyAsync(ln.d_deg.p, r.degree + ck.u0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D degrees")))
                 return rc;
-            S.stats.h2d_bytes += int64_t(ng);
+            ln.st->h2d_bytes += int64_t(ng);
         } else {
             if ((rc = ln.d_gp.reserve((size_t(ng) + 1) * 4, "hipMalloc gene_ptr"))) return rc;
-            if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.g0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.up), "H2D gene_ptr")))
+            if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.u0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.up), "H2D gene_ptr")))
                 return rc;
-            S.stats.h2d_bytes += int64_t((size_t(ng) + 1) * 4);
+            ln.st->h2d_bytes += int64_t((size_t(ng) + 1) * 4);
         }
         if ((rc = ln.d_at.reserve((nnz + 8) * 4, "hipMalloc attr_id"))) return rc;
         if (r.attr_id16) {  // 16-bit indices cross PCIe; widened on the compute stream (below)
             if ((rc = ln.d_at16.reserve((nnz + 8) * 2, "hipMalloc attr_id16"))) return rc;
             if (nnz && (rc = check_hip(hipMemcpyAsync(ln.d_at16.p, r.attr_id16 + a0, nnz * 2, hipMemcpyHostToDevice, ln.up), "H2D attr_id16")))
                 return rc;
-            S.stats.h2d_bytes += int64_t(nnz * 2);
+            ln.st->h2d_bytes += int64_t(nnz * 2);
         } else {
             if (nnz && (rc = check_hip(hipMemcpyAsync(ln.d_at.p, r.attr_id + a0, nnz * 4, hipMemcpyHostToDevice, ln.up), "H2D attr_id")))
                 return rc;
-            S.stats.h2d_bytes += int64_t(nnz * 4);
+            ln.st->h2d_bytes += int64_t(nnz * 4);
         }
         if (r.want_segments) {
             if (r.annotated) {  // (null: a gene is annotated iff it has a domain the model knows -- the degree bytes themselves)
                 if ((rc = ln.d_ann.reserve(size_t(ng) + 8, "hipMalloc annotated"))) return rc;
-                if ((rc = check_hip(hipMemcpyAsync(ln.d_ann.p, r.annotated + ck.g0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D annotated")))
+                if ((rc = check_hip(hipMemcpyAsync(ln.d_ann.p, r.annotated + ck.u0, size_t(ng), hipMemcpyHostToDevice, ln.up), "H2D annotated")))
                     return rc;
-                S.stats.h2d_bytes += ng;
+                ln.st->h2d_bytes += ng;
             }
             if (r.seg.criterion == 1) {  // the genes' marker domains, offsets kept as the caller's (like gene_ptr)
-                b0 = r.seg.bio_ptr[ck.g0];
-                const int64_t b1 = r.seg.bio_ptr[ck.g1];
+                b0 = r.seg.bio_ptr[ck.u0];
+                const int64_t b1 = r.seg.bio_ptr[ck.u1];
                 if (b0 < 0 || b1 < b0) {
                     set_error("marker_ptr must be non-decreasing and start at a non-negative offset");
                     return GECCO_CRF_EINVAL;
@@ -404,18 +550,18 @@ int submit_uploads(RunCtx &X, Lane &ln, int chunk_index) {
                 const size_t nb = size_t(b1 - b0);
                 if ((rc = ln.d_bp.reserve((size_t(ng) + 1) * 4, "hipMalloc marker_ptr"))) return rc;
                 if ((rc = ln.d_bi.reserve((nb + 4) * 4, "hipMalloc marker_id"))) return rc;
-                if ((rc = check_hip(hipMemcpyAsync(ln.d_bp.p, r.seg.bio_ptr + ck.g0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.up), "H2D marker_ptr")))
+                if ((rc = check_hip(hipMemcpyAsync(ln.d_bp.p, r.seg.bio_ptr + ck.u0, (size_t(ng) + 1) * 4, hipMemcpyHostToDevice, ln.up), "H2D marker_ptr")))
                     return rc;
                 if (nb && (rc = check_hip(hipMemcpyAsync(ln.d_bi.p, r.seg.bio_id + b0, nb * 4, hipMemcpyHostToDevice, ln.up), "H2D marker_id")))
                     return rc;
-                S.stats.h2d_bytes += int64_t((size_t(ng) + 1 + nb) * 4);
+                ln.st->h2d_bytes += int64_t((size_t(ng) + 1 + nb) * 4);
             }
         }
     }
     ln.up_b0 = b0;
     // the device derives the rows from the degree bytes, the host takes the chunk's base offset from gene_ptr: they must agree
     // (checked while the copies above are under way)
-    if (ng && r.degree && byte_sum(r.degree + ck.g0, size_t(ng)) != uint64_t(a1 - a0)) {
+    if (ng && r.degree && byte_sum(r.degree + ck.u0, size_t(ng)) != uint64_t(a1 - a0)) {
         set_error("degree bytes do not add up to gene_ptr over a chunk (degree must equal diff(gene_ptr))");
         return GECCO_CRF_EINVAL;
     }
@@ -443,7 +589,6 @@ T *mapped_or_null(T *host) {
 // be worth asking, the staging block otherwise.  The compact wire format is undone on the way (row pointers are the caller's
 // gene_ptr; 16-bit indices are widened by the staging copy), so no launch has to.
 int submit_direct_arrays(RunCtx &X, Lane &ln, int chunk_index) {
-    Session &S = X.S;
     const BatchRequest &r = X.r;
     Chunk &ck = X.chunks[chunk_index];
     int rc = check_hip(hipSetDevice(ln.device), "hipSetDevice");
@@ -480,19 +625,19 @@ int submit_direct_arrays(RunCtx &X, Lane &ln, int chunk_index) {
     if (c_gp) {
         if ((rc = ln.d_gp.reserve((ng + 1) * 4, "hipMalloc gene_ptr"))) return rc;
         if ((rc = check_hip(hipMemcpyAsync(ln.d_gp.p, r.gene_ptr + ck.g0, (ng + 1) * 4, hipMemcpyHostToDevice, ln.comp), "H2D gene_ptr"))) return rc;
-        S.stats.h2d_bytes += int64_t((ng + 1) * 4);
+        ln.st->h2d_bytes += int64_t((ng + 1) * 4);
     }
     if (c_at) {
         if ((rc = ln.d_at.reserve((nnz + 8) * 4, "hipMalloc attr_id"))) return rc;
         if ((rc = check_hip(hipMemcpyAsync(ln.d_at.p, r.attr_id + a0, nnz * 4, hipMemcpyHostToDevice, ln.comp), "H2D attr_id"))) return rc;
-        S.stats.h2d_bytes += int64_t(nnz * 4);
+        ln.st->h2d_bytes += int64_t(nnz * 4);
     }
     const bool c_at16 = nnz * 4 >= kCopy && r.attr_id16;  // (16-bit indices: half the bytes cross, a launch widens them)
     if (c_at16) {
         if ((rc = ln.d_at.reserve((nnz + 8) * 4, "hipMalloc attr_id"))) return rc;
         if ((rc = ln.d_at16.reserve((nnz + 8) * 2, "hipMalloc attr_id16"))) return rc;
         if ((rc = check_hip(hipMemcpyAsync(ln.d_at16.p, r.attr_id16 + a0, nnz * 2, hipMemcpyHostToDevice, ln.comp), "H2D attr_id16"))) return rc;
-        S.stats.h2d_bytes += int64_t(nnz * 2);
+        ln.st->h2d_bytes += int64_t(nnz * 2);
         if ((rc = check_hip(launch_wire_format(nullptr, 0, 0, nullptr, nullptr, reinterpret_cast<const uint16_t *>(ln.d_at16.p), int64_t(nnz),
                                                reinterpret_cast<int32_t *>(ln.d_at.p), ln.comp), "wire format launch")))
             return rc;
@@ -588,10 +733,15 @@ int submit_plan(RunCtx &X, Lane &ln, int chunk_index) {
         // small batches: the decoder's tables and flag bytes too are read where the host wrote them
         ln.plan.seq_in_host_memory = X.direct && !r.want_segments && !X.full && !r.score_out;
     }
-    if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.comp, false))) return rc;
+    if (ck.piece) {  // a stretch of ONE long contig, scored as a contig of its own
+        const int32_t span[2] = {ck.u0, ck.u1};
+        if ((rc = plan_build(m, ln.device, span, 1, X.W, X.step, X.pad, ln.plan, ln.comp, false))) return rc;
+    } else if ((rc = plan_build(m, ln.device, r.contig_ptr + ck.c0, nc, X.W, X.step, X.pad, ln.plan, ln.comp, false))) {
+        return rc;
+    }
     // (the whole-contig tables too are fetched by a launch on the compute stream; the refiner builds its contig flags on the device)
     if ((X.viterbi || X.full) && (rc = plan_ensure_seq(ln.plan, ln.comp, false))) return rc;
-    S.stats.host_plan_seconds += now_s() - t0;
+    ln.st->host_plan_seconds += now_s() - t0;
     tm.lap("plan_build", chunk_index);
     if (X.direct) {  // (nothing is on the upload stream; the host has read the CSR's extent itself)
         ln.plan.csr_begin = ln.up_a0;
@@ -604,7 +754,6 @@ int submit_plan(RunCtx &X, Lane &ln, int chunk_index) {
 // Direct path: every launch of the (one) chunk on the compute stream, on the addresses submit_direct_arrays chose; the host then
 // waits for that stream (retire_begin) -- no copy command, no event, no second stream.  A 50-gene contig: one launch.
 int submit_direct(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
-    Session &S = X.S;
     const BatchRequest &r = X.r;
     Chunk &ck = X.chunks[chunk_index];
     int rc;
@@ -656,7 +805,7 @@ int submit_direct(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
             return rc;
     }
     if (r.p_out && !p_to_host) {  // (p lives in device memory: the refiner reads it, or a window kernel with atomic maxima wrote it)
-        S.stats.d2h_bytes += int64_t(ng) * 8;
+        ln.st->d2h_bytes += int64_t(ng) * 8;
         if ((rc = check_hip(hipMemcpyAsync(r.p_out + ck.g0, d_p, size_t(ng) * 8, hipMemcpyDeviceToHost, ln.comp), "D2H p"))) return rc;
         ln.x_p_host = nullptr;
     }
@@ -671,7 +820,7 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
     const Model &m = *S.model;
     int rc = check_hip(hipSetDevice(ln.device), "hipSetDevice");
     if (rc) return rc;
-    const int32_t nc = ck.c1 - ck.c0, ng = ck.g1 - ck.g0;
+    const int32_t nc = ck.c1 - ck.c0, ng = ck.u1 - ck.u0;  // (ng: the genes the chunk scores -- a piece's halo included)
     TraceMark tm;
     ln.chunk = chunk_index;
     ln.up_chunk = -1;
@@ -714,7 +863,7 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
         if ((rc = check_hip(hipEventRecord(ln.ev_comp, ln.comp), "hipEventRecord"))) return rc;
         if ((rc = check_hip(hipStreamWaitEvent(ln.down, ln.ev_comp, 0), "hipStreamWaitEvent"))) return rc;
         if (prev && (rc = finish_pending(X, D))) return rc;
-        S.stats.d2h_bytes += int64_t(ng) * 8;
+        ln.st->d2h_bytes += int64_t(ng) * 8;
         if ((rc = check_hip(hipMemcpyAsync(r.p_out + ck.g0, d_p, size_t(ng) * 8, hipMemcpyDeviceToHost, ln.down), "D2H p"))) return rc;
         D.pending = &ln;  // (its labels and its `done` come with the device's next launch, or with the flush)
         tm.lap("launch", chunk_index);
@@ -773,10 +922,10 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
     if ((rc = check_hip(hipEventRecord(ln.ev_comp, ln.comp), "hipEventRecord"))) return rc;
     if ((rc = check_hip(hipStreamWaitEvent(ln.down, ln.ev_comp, 0), "hipStreamWaitEvent"))) return rc;
     auto d2h = [&](void *dst, const void *src, size_t bytes, const char *what) {
-        S.stats.d2h_bytes += int64_t(bytes);
+        ln.st->d2h_bytes += int64_t(bytes);
         return bytes ? check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ln.down), what) : GECCO_CRF_OK;
     };
-    if (c_p && (rc = d2h(r.p_out + ck.g0, d_p, size_t(ng) * 8, "D2H p"))) return rc;
+    if (c_p && (rc = d2h(r.p_out + ck.g0, d_p + (ck.g0 - ck.u0), size_t(ck.g1 - ck.g0) * 8, "D2H p"))) return rc;  // (a piece keeps its inner genes)
     if (c_y && (rc = d2h(r.y_out + ck.g0, d_y, size_t(ng), "D2H labels"))) return rc;
     if (c_score && (rc = d2h(r.score_out + ck.c0, d_score, size_t(nc) * 8, "D2H scores"))) return rc;
     if (c_marg && (rc = d2h(r.marg_out + size_t(ck.g0) * L, d_marg, size_t(ng) * L * 8, "D2H marginals"))) return rc;
@@ -829,7 +978,7 @@ int retire_begin(RunCtx &X, Lane &ln) {
             }
             if (ck.seg_p_count) {
                 if ((rc = check_hip(hipSetDevice(ln.device), "hipSetDevice"))) return rc;
-                X.S.stats.d2h_bytes += ck.seg_p_count * 8;
+                ln.st->d2h_bytes += ck.seg_p_count * 8;
                 if ((rc = check_hip(hipMemcpyAsync(dst, ln.d_segp.p, size_t(ck.seg_p_count) * 8, hipMemcpyDeviceToHost, ln.down), "D2H cluster probabilities")))
                     return rc;
                 if ((rc = check_hip(hipEventRecord(ln.done, ln.down), "hipEventRecord"))) return rc;
@@ -933,12 +1082,14 @@ int session_run(Session &S, const BatchRequest &r) {
     if (direct) {
         Chunk ck;
         ck.c1 = r.n_contigs;
-        ck.g1 = int32_t(n_genes);
+        ck.g1 = ck.u1 = int32_t(n_genes);
         chunks.push_back(std::move(ck));
     } else {
         // cluster calls launch eight more (short) kernels per chunk and download next to nothing: twice the chunk size
+        // (a contig too long for one chunk is cut into pieces with a W - 1 gene halo when only its windowed marginals are asked for)
+        const bool may_split = windowed && !viterbi && !full && !r.want_segments;
         cut_chunks(r, r.want_segments ? int32_t(std::min<int64_t>(2 * int64_t(S.chunk_genes), 1 << 28)) : S.chunk_genes, int(S.devs.size()),
-                   chunks);
+                   chunks, may_split ? r.window : 0, may_split ? r.step : 1);
         deal_chunks(chunks, int(S.devs.size()));
     }
     S.stats.n_chunks = int32_t(chunks.size());
@@ -966,18 +1117,22 @@ int session_run(Session &S, const BatchRequest &r) {
             if (r.lognorm_out) r.lognorm_out[c] = 0.0;
         }
     }
-    std::vector<size_t> head(S.devs.size(), 0);
-    int rc = GECCO_CRF_OK;
-    for (bool any = true; any && !rc;) {
-        any = false;
-        for (size_t d = 0; d < S.devs.size() && !rc; ++d) {
-            if (head[d] >= queue[d].size()) continue;
-            any = true;
-            DeviceCtx &D = *S.devs[d];
+    // Every device entry is driven by a thread of its own (the calling thread takes the first, the session's workers the
+    // others): a 2^19-gene chunk is ~90 us of PCIe, its submission a dozen HIP API calls and a layout -- one thread feeding
+    // eight devices round-robin would be their limiter (crf/__init__.py:244: contigs are independent, so are the queues).
+    auto device_job = [&](int d) {
+        DeviceCtx &D = *S.devs[size_t(d)];
+        const std::vector<int> &q = queue[size_t(d)];
+        D.stats = SessionStats{};
+        D.err.clear();
+        int rc = GECCO_CRF_OK;
+        double issue = 0.0;
+        for (size_t head = 0; head < q.size() && !rc; ++head) {
             Lane &ln = D.lanes[D.next_lane];
             D.next_lane = (D.next_lane + 1) % kLanes;
-            if ((rc = retire(X, ln))) break;
-            const int mine = queue[d][head[d]++];
+            if ((rc = retire(X, ln))) break;  // (waits for the lane's previous chunk: not counted as issue time)
+            const double t_issue = now_s();
+            const int mine = q[head];
             if (X.direct) {
                 if ((rc = submit_direct_arrays(X, ln, mine))) break;
             } else if (ln.up_chunk != mine && (rc = submit_uploads(X, ln, mine))) {
@@ -988,39 +1143,54 @@ int session_run(Session &S, const BatchRequest &r) {
             // idle -- or has finished meanwhile: it is then retired here instead of at its own turn --: they are on their way
             // while the host launches this chunk and lays out the next
             Lane &nl = D.lanes[D.next_lane];
-            if (head[d] < queue[d].size() && &nl != &ln) {
+            if (head + 1 < q.size() && &nl != &ln) {
                 if (nl.chunk >= 0 && &nl != D.pending && hipEventQuery(nl.done) == hipSuccess && (rc = retire(X, nl))) break;
                 (void)hipGetLastError();  // (hipErrorNotReady of the query is not an error of this call)
-                if (nl.chunk < 0 && (rc = submit_uploads(X, nl, queue[d][head[d]]))) break;
+                if (nl.chunk < 0 && (rc = submit_uploads(X, nl, q[head + 1]))) break;
             }
             rc = submit(X, D, ln, mine);
+            issue += now_s() - t_issue;
         }
+        if (!rc) rc = flush_pending(X, D);
+        D.pending = nullptr;
+        // drain (also after an error: nothing of this call may still be in flight when it returns)
+        for (int pass = 0; pass < 2; ++pass)
+            for (Lane &ln : D.lanes) {
+                if (rc) {  // the failed submission may have left work behind an unrecorded event
+                    const std::string keep = last_error();
+                    if (hipSetDevice(ln.device) == hipSuccess) (void)hipDeviceSynchronize();
+                    ln.chunk = -1;
+                    ln.segp_in_flight = false;
+                    set_error(keep);
+                    continue;
+                }
+                rc = pass == 0 ? retire_begin(X, ln) : retire_end(X, ln);  // (all downloads are issued before any is waited for)
+            }
+        D.stats.host_issue_seconds = issue;
+        D.rc = rc;
+        if (rc) D.err = last_error();  // (the error text is thread-local: handed to the calling thread below)
+    };
+    const int n_dev = int(S.devs.size());
+    int busy = 0;
+    for (int d = 0; d < n_dev; ++d) busy += queue[size_t(d)].empty() ? 0 : 1;
+    if (busy <= 1 || n_dev == 1) {
+        for (int d = 0; d < n_dev; ++d) device_job(d);
+        S.stats.host_threads = 1;
+    } else {
+        S.workers.run(n_dev, device_job);
+        S.stats.host_threads = n_dev;
     }
+    int rc = GECCO_CRF_OK;
     for (auto &d : S.devs) {
-        if (!rc) rc = flush_pending(X, *d);
-        d->pending = nullptr;
+        S.stats.h2d_bytes += d->stats.h2d_bytes;
+        S.stats.d2h_bytes += d->stats.d2h_bytes;
+        S.stats.host_plan_seconds += d->stats.host_plan_seconds;
+        S.stats.host_issue_seconds += d->stats.host_issue_seconds;
+        if (d->rc && !rc) {
+            rc = d->rc;
+            set_error(d->err);
+        }
     }
-    // drain (also after an error: nothing of this call may still be in flight when it returns)
-    for (auto &d : S.devs)
-        for (Lane &ln : d->lanes) {
-            if (rc) {  // the failed submission may have left work behind an unrecorded event
-                if (hipSetDevice(ln.device) == hipSuccess) (void)hipDeviceSynchronize();
-                ln.chunk = -1;
-                ln.segp_in_flight = false;
-                continue;
-            }
-            rc = retire_begin(X, ln);  // (the downloads of all lanes are issued before any of them is waited for)
-        }
-    for (auto &d : S.devs)
-        for (Lane &ln : d->lanes) {
-            if (rc) {
-                if (hipSetDevice(ln.device) == hipSuccess) (void)hipDeviceSynchronize();
-                ln.chunk = -1;
-                ln.segp_in_flight = false;
-                continue;
-            }
-            rc = retire_end(X, ln);
-        }
     if (prev_device >= 0) (void)hipSetDevice(prev_device);
     if (rc) return rc;
 

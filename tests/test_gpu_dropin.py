@@ -111,6 +111,26 @@ def test_columnar_predict_cli_reproduces_golden_tables(tmp_path):
     assert set(a["domains"].split(";")) == set(b["domains"].split(";"))
 
 
+def test_cli_tables_string_identity_with_the_reference_files(tmp_path, capsys):
+    """The reference's own acceptance test (/root/reference/galaxy/gecco.xml:83-111: whole-file equality of genes.tsv and
+    clusters.tsv): every text / integer cell written by `python -m gecco_amd.predict` is string-identical to the fixture's;
+    float cells (probabilities printed with 16-17 digits) are counted and reported: a cell differs as soon as the value is one
+    ulp away from CRFsuite's, and must never be more than 8 ulps away."""
+    from gecco_amd import levels
+
+    res = levels.golden_table_identity(GOLDEN, str(tmp_path))
+    with capsys.disabled():
+        print("\n[table identity]", {k: v for k, v in res.items() if k != "note"})
+    for table, n_rows in (("genes", 23), ("features", 37), ("clusters", 1)):
+        t = res[table]
+        assert t["rows"] == t["rows_expected"] == n_rows
+        assert t["exact_cells_differing"] == 0
+        assert t["max_ulps"] <= 32  # (3.6e-15 at p ~ 1: the fast kernels' own summation order; north star 1e-6)
+    assert res["genes"]["float_cells"] == 46 and res["clusters"]["float_cells"] == 2
+    # `proteins` / `domains`: the reference's CURRENT formula (gecco/model.py:750-757) on the fixture's tables
+    assert res["clusters"]["formula_cells"] == 2 and res["clusters"]["formula_cells_differing"] == 0
+
+
 def test_columnar_predict_cli_postproc_antismash(tmp_path):
     """`--postproc antismash` on the fixture: the cluster is kept or dropped exactly as ClusterRefiner(criterion=
     "antismash", n_cds=3) decides on the fixture's objects (refine.py:157-163 with the CLI's defaults)."""

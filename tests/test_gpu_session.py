@@ -53,7 +53,7 @@ def _threshold(p):
 
 def _same(got, exp):
     np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
-    assert np.abs(np.nan_to_num(got) - np.nan_to_num(exp)).max() <= TOL
+    assert len(got) == 0 or np.abs(np.nan_to_num(got) - np.nan_to_num(exp)).max() <= TOL
 
 
 @pytest.mark.parametrize("chunk,pad,pinned", [(1024, True, False), (5000, False, False), (20000, True, True), (1 << 19, True, False)])
@@ -76,8 +76,13 @@ def test_session_windowed_chunks(nat, real_model, oracle_model, chunk, pad, pinn
         assert st["direct"] == 1 and st["n_chunks"] == 1 and st["d2h_bytes"] == 0
         return
     assert st["direct"] == 0
-    assert st["n_chunks"] == max(1, min(len(cptr) - 1, (int(cptr[-1]) + chunk // 2) // chunk))
     assert st["d2h_bytes"] == 8 * len(exp)
+    if int(np.diff(cptr).max()) > 1.5 * chunk:
+        # the 3 000-gene contig is cut into pieces of about a chunk, with a 19-gene halo either side (uploaded twice)
+        assert st["n_chunks"] > (int(cptr[-1]) + chunk // 2) // chunk - 8
+        assert st["h2d_bytes"] > 4 * (len(gptr) + len(attr))
+        return
+    assert st["n_chunks"] == max(1, min(len(cptr) - 1, (int(cptr[-1]) + chunk // 2) // chunk))
     assert st["h2d_bytes"] == 4 * (len(gptr) + st["n_chunks"] - 1 + len(attr))
 
 

@@ -727,3 +727,16 @@ def test_objpath_extension_equals_python_statements(monkeypatch):
     o.__dict__.update(contigs[0][0].__dict__) if contigs[0] else None
     if contigs[1]:
         assert native.annotate_all([contigs[1][0], o], [0.1, 0.2], w1, Gene, Protein, Domain) is None
+
+
+def test_committed_profiles_parse():
+    """Every profiles/*.json is one JSON document (launcher log lines in front of a bench line made two of them unreadable)."""
+    import glob
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "*.json")))
+    assert files
+    for f in files:
+        with open(f) as fh:
+            json.load(fh)
