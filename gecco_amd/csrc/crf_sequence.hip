@@ -454,17 +454,17 @@ __global__ void __launch_bounds__(kT) v_replay(const SeqArgs A) {
     if (slot == 0) A.vBlockMap[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(kT) v_labels(const SeqArgs A) {
+__device__ __forceinline__ void v_labels_block(const SeqArgs &A, const int blk, const int n_blocks) {
     const int slot = threadIdx.x;
-    const int g0 = (blockIdx.x * kT + slot) * kGPL;
+    const int g0 = (blk * kT + slot) * kGPL;
     const int cnt = min(kGPL, A.n_genes - g0);
-    const uint32_t block_suf = lookahead_suffix(A.vBlockMap, blockIdx.x, gridDim.x);
+    const uint32_t block_suf = lookahead_suffix(A.vBlockMap, blk, n_blocks);
     if (cnt <= 0) return;
     // suffix map of everything to the right of this lane, applied to a dummy label (the last gene
     // of the batch ends a contig, so the composition is constant)
-    const uint32_t suf = MapOp::combine(A.vLaneMap[blockIdx.x * kT + slot], block_suf);
+    const uint32_t suf = MapOp::combine(A.vLaneMap[blk * kT + slot], block_suf);
     uint32_t lab = suf & 1u;
-    const uint32_t maps = A.vMaps[blockIdx.x * kT + slot];
+    const uint32_t maps = A.vMaps[blk * kT + slot];
     uint64_t packed = 0;
 #pragma unroll
     for (int k = kGPL - 1; k >= 0; --k) {
@@ -479,6 +479,7 @@ __global__ void __launch_bounds__(kT) v_labels(const SeqArgs A) {
         for (int k = 0; k < cnt; ++k) A.y[g0 + k] = int8_t((packed >> (8 * k)) & 0xff);
     }
 }
+__global__ void __launch_bounds__(kT) v_labels(const SeqArgs A) { v_labels_block(A, blockIdx.x, gridDim.x); }
 
 // long contigs: vd_replay flags the contigs that hold a decision inside the margin, this kernel decodes them again.
 // Two LDS buffers: lanes 64.. sum the state scores of the next chunk while lane 0 walks the current one (the walk,
@@ -638,11 +639,11 @@ __device__ __forceinline__ void vd_flag_contigs(const SeqArgs &A, int g_lo, int 
     }
     for (int c = lo; c < A.n_contigs && A.contig_ptr[c] < g_hi; ++c) A.fix_flag[c] = 1;
 }
-__global__ void __launch_bounds__(kT) vd_refine(const SeqArgs A) {
+__device__ __forceinline__ void vd_refine_block(const SeqArgs &A, const int blk, const int n_blocks) {
     const uint32_t count = *reinterpret_cast<const uint32_t *>(A.vBound + 1);
     const double ulpM = __longlong_as_double(static_cast<long long>(A.vBound[0])) * kVdEps;
     const double margin = vd_margin(1023.0, ulpM);
-    for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < count; i += gridDim.x * kT) {
+    for (uint32_t i = blk * kT + threadIdx.x; i < count; i += n_blocks * kT) {
         const SeqArgs::VdCand rec = A.vCand[i];
         const int lane = int(rec.lane & 0x7fffffffu), g0 = lane * kGPL;
         if (rec.lane & 0x80000000u) {  // 512 genes without a reset: r is not bounded by 1023 there
@@ -682,6 +683,20 @@ __global__ void __launch_bounds__(kT) vd_refine(const SeqArgs A) {
             if (A.vd_stats) atomicAdd(A.vd_stats + 1, 1u);
         }
     }
+}
+
+// The labels of the batch and the judgement of vd_replay's candidates in ONE launch (they do not depend on each other; both
+// come before vd_exact_fix): the first `nb` workgroups write labels, the last kRefineBlocks judge -- a launch less in the
+// chain fold -> replay -> labels + refine -> exact_fix that a batch of long contigs waits for.  (vd_exact_fix stays a launch of
+// its own: it overwrites labels and reads flags other workgroups wrote, and inside one launch that ordering needs a
+// `__threadfence()` per workgroup -- a write-back of an L2 that another stream's tiles are filling: 350 instead of 83 us
+// per C5 step, measured in round 5.)
+constexpr int kRefineBlocks = 8;
+__global__ void __launch_bounds__(kT) v_labels_refine(const SeqArgs A, const int nb) {
+    if (int(blockIdx.x) < nb)
+        v_labels_block(A, blockIdx.x, nb);
+    else
+        vd_refine_block(A, int(blockIdx.x) - nb, kRefineBlocks);
 }
 
 // short contigs: ONE launch per decoder (crf_vd_short.hpp)
@@ -1159,8 +1174,10 @@ hipError_t launch_seq_viterbi_delta(const SeqArgs &a, hipStream_t stream) {
     // vd_exact_fix at the end of every decode)
     hipLaunchKernelGGL(vd_fold, dim3(nb), dim3(kT), 0, stream, b);
     hipLaunchKernelGGL(vd_replay, dim3(nb), dim3(kT), 0, stream, b);
-    if (exact) hipLaunchKernelGGL(vd_refine, dim3(8), dim3(kT), 0, stream, b);
-    hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, b);
+    if (exact)
+        hipLaunchKernelGGL(v_labels_refine, dim3(nb + kRefineBlocks), dim3(kT), 0, stream, b, nb);
+    else
+        hipLaunchKernelGGL(v_labels, dim3(nb), dim3(kT), 0, stream, b);
     // contigs that vd_replay flagged (a decision inside the rounding margin): CRFsuite's own recursion
     if (exact) hipLaunchKernelGGL(vd_exact_fix, dim3(min(a.n_contigs, 1024)), dim3(kT), 0, stream, b);
     return hipGetLastError();
