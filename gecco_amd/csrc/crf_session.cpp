@@ -119,6 +119,8 @@ struct Lane {
     int64_t up_a0 = 0, up_nnz = 0, up_b0 = 0;
     DevBuf d_gp, d_at, d_at16, d_p, d_y, d_ann, d_score, d_marg, d_lognorm, d_bp, d_bi, d_seg, d_deg, d_deg_ws, d_segp;
     SessionStats *st = nullptr;  // the device's share of the batch's figures (merged when the batch is done)
+    int8_t *y_dst = nullptr;     // where the decoder writes the chunk's labels: the lane's device buffer, or the caller's pinned array
+    bool y_to_host = false;      // ... the latter: no download of labels
     HostBuf h_io;   // direct path (small batches): the chunk's arrays and outputs in pinned, device-visible memory
     // direct path: device-visible addresses of the chunk's arrays (the staging block, or the caller's own pinned buffers) and
     // what the host copies out of the staging block once the launch has completed
@@ -348,6 +350,8 @@ void cut_chunks(const BatchRequest &r, int32_t target, int n_devices, std::vecto
         for (int32_t c = 0; c < nc && !any_long; ++c) any_long = int64_t(r.contig_ptr[c + 1]) - r.contig_ptr[c] > long_genes;
     if (!any_long) {
         want = std::min<int64_t>(want, nc);
+        // (a half-sized first and last chunk -- the first download starts and the last one ends half a chunk earlier, for one
+        // chunk more -- was measured in round 5: 0.63 against 0.60 ms per C3 call)
         const double per_c = double(n) / double(want);
         int32_t c = 0;
         for (int64_t k = 0; k < want && c < nc; ++k) {
@@ -470,9 +474,12 @@ int finish_pending(RunCtx &X, DeviceCtx &D) {
     D.pending = nullptr;
     const Chunk &pk = X.chunks[pl.chunk];
     const size_t ng = size_t(pk.g1 - pk.g0);
-    pl.st->d2h_bytes += int64_t(ng);
-    int rc = check_hip(hipMemcpyAsync(X.r.y_out + pk.g0, pl.d_y.p, ng, hipMemcpyDeviceToHost, pl.down), "D2H labels");
-    if (rc) return rc;
+    int rc = GECCO_CRF_OK;
+    if (!pl.y_to_host) {  // (labels written into the caller's pinned array by the decoder itself need no copy)
+        pl.st->d2h_bytes += int64_t(ng);
+        rc = check_hip(hipMemcpyAsync(X.r.y_out + pk.g0, pl.d_y.p, ng, hipMemcpyDeviceToHost, pl.down), "D2H labels");
+        if (rc) return rc;
+    }
     return check_hip(hipEventRecord(pl.done, pl.down), "hipEventRecord");
 }
 
@@ -482,7 +489,7 @@ int flush_pending(RunCtx &X, DeviceCtx &D) {
     Lane &pl = *D.pending;
     int rc = check_hip(hipSetDevice(pl.device), "hipSetDevice");
     if (rc) return rc;
-    if ((rc = plan_run_decode_pipelined(nullptr, nullptr, nullptr, X.r.label, nullptr, &pl.plan, reinterpret_cast<int8_t *>(pl.d_y.p), pl.comp)))
+    if ((rc = plan_run_decode_pipelined(nullptr, nullptr, nullptr, X.r.label, nullptr, &pl.plan, pl.y_dst, pl.comp)))
         return rc;
     if ((rc = check_hip(hipEventRecord(pl.ev_comp, pl.comp), "hipEventRecord"))) return rc;
     if ((rc = check_hip(hipStreamWaitEvent(pl.down, pl.ev_comp, 0), "hipStreamWaitEvent"))) return rc;
@@ -841,13 +848,44 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
     const int32_t *d_at = reinterpret_cast<const int32_t *>(ln.d_at.p) - a0;
     double *d_p = nullptr, *d_score = nullptr;
     int8_t *d_y = nullptr;
+    // Where the tiles write p: the lane's device buffer, downloaded by a copy.  GECCO_CRF_P_TO_HOST=1 (experiment, round 5): into
+    // the caller's own array when it is pinned and nothing on the device reads p again -- the probabilities then cross PCIe as
+    // the tiles' posted writes and the chunk has no download of 8 bytes per gene.  Not faster: the tiles' stores share the link
+    // with the next chunk's upload less gracefully than the copy engine does (tools/ubench/pcie_bw.hip: 19 MB up + 16 MB down
+    // at once 354 us by copies, 432 us with the download done by a kernel's stores).
+    bool p_to_host = false;
     if (X.windowed) {
-        if ((rc = ln.d_p.reserve(size_t(ng) * 8, "hipMalloc p"))) return rc;
-        d_p = reinterpret_cast<double *>(ln.d_p.p);
+        static const bool allowed = [] {  // (off by default: measured on C3, pinned buffers: 0.619 ms against 0.609 through a copy)
+            const char *env = std::getenv("GECCO_CRF_P_TO_HOST");
+            return env && env[0] == '1';
+        }();
+        double *m_p = nullptr;
+        if (allowed && r.p_out && !r.want_segments && !ck.piece && !ln.plan.general && ln.plan.fast_ok) m_p = mapped_or_null(r.p_out + ck.g0);
+        if (m_p) {
+            d_p = m_p;
+            p_to_host = true;
+        } else {
+            if ((rc = ln.d_p.reserve(size_t(ng) * 8, "hipMalloc p"))) return rc;
+            d_p = reinterpret_cast<double *>(ln.d_p.p);
+        }
     }
     if (X.viterbi) {
-        if ((rc = ln.d_y.reserve(size_t(ng) + 8, "hipMalloc labels"))) return rc;
-        d_y = reinterpret_cast<int8_t *>(ln.d_y.p);
+        // Labels (a byte per gene) go straight into the caller's array when it is pinned: a chunk's 0.5 MB of them cost a copy
+        // command and its ~12 us of engine turnaround each -- on the download stream, which is the critical path of a decode
+        // call on the compact wire format -- and nothing as stores of the decoder.  GECCO_CRF_Y_TO_HOST=0: always a copy.
+        static const bool y_allowed = [] {
+            const char *env = std::getenv("GECCO_CRF_Y_TO_HOST");
+            return !(env && env[0] == '0');
+        }();
+        int8_t *m_y = (y_allowed && r.y_out && !ck.piece) ? mapped_or_null(r.y_out + ck.g0) : nullptr;
+        ln.y_to_host = m_y != nullptr;
+        if (m_y) {
+            d_y = m_y;
+        } else {
+            if ((rc = ln.d_y.reserve(size_t(ng) + 8, "hipMalloc labels"))) return rc;
+            d_y = reinterpret_cast<int8_t *>(ln.d_y.p);
+        }
+        ln.y_dst = d_y;
         if (r.score_out) {
             if ((rc = ln.d_score.reserve(size_t(nc) * 8, "hipMalloc scores"))) return rc;
             d_score = reinterpret_cast<double *>(ln.d_score.p);
@@ -858,13 +896,15 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
         // ONE launch per chunk: this chunk's window tiles + the Viterbi workgroups of the chunk this device scored before
         Lane *prev = D.pending;
         rc = plan_run_decode_pipelined(&ln.plan, d_gp, d_at, r.label, d_p, prev ? &prev->plan : nullptr,
-                                       prev ? reinterpret_cast<int8_t *>(prev->d_y.p) : nullptr, ln.comp);
+                                       prev ? prev->y_dst : nullptr, ln.comp);
         if (rc) return rc;
         if ((rc = check_hip(hipEventRecord(ln.ev_comp, ln.comp), "hipEventRecord"))) return rc;
         if ((rc = check_hip(hipStreamWaitEvent(ln.down, ln.ev_comp, 0), "hipStreamWaitEvent"))) return rc;
         if (prev && (rc = finish_pending(X, D))) return rc;
-        ln.st->d2h_bytes += int64_t(ng) * 8;
-        if ((rc = check_hip(hipMemcpyAsync(r.p_out + ck.g0, d_p, size_t(ng) * 8, hipMemcpyDeviceToHost, ln.down), "D2H p"))) return rc;
+        if (!p_to_host) {
+            ln.st->d2h_bytes += int64_t(ng) * 8;
+            if ((rc = check_hip(hipMemcpyAsync(r.p_out + ck.g0, d_p, size_t(ng) * 8, hipMemcpyDeviceToHost, ln.down), "D2H p"))) return rc;
+        }
         D.pending = &ln;  // (its labels and its `done` come with the device's next launch, or with the flush)
         tm.lap("launch", chunk_index);
         return GECCO_CRF_OK;
@@ -917,7 +957,7 @@ int submit(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
             return rc;
     }
     tm.lap("launch", chunk_index);
-    const bool c_p = r.p_out, c_y = r.y_out, c_score = r.score_out, c_marg = r.marg_out, c_ln = r.lognorm_out;
+    const bool c_p = r.p_out && !p_to_host, c_y = r.y_out && !ln.y_to_host, c_score = r.score_out, c_marg = r.marg_out, c_ln = r.lognorm_out;
     if (!(c_p || c_y || c_score || c_marg || c_ln)) return check_hip(hipEventRecord(ln.done, ln.comp), "hipEventRecord");
     if ((rc = check_hip(hipEventRecord(ln.ev_comp, ln.comp), "hipEventRecord"))) return rc;
     if ((rc = check_hip(hipStreamWaitEvent(ln.down, ln.ev_comp, 0), "hipStreamWaitEvent"))) return rc;
