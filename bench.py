@@ -658,6 +658,7 @@ def main() -> None:
             from gecco_amd import levels as _lv
 
             golden_tables = _lv.golden_table_identity(os.path.join(ROOT, "tests", "golden"))
+            golden_tables["reference_bits_mode"] = _lv.golden_table_identity(os.path.join(ROOT, "tests", "golden"), reference_bits=True)
         except Exception as err:
             golden_tables = {"error": f"{type(err).__name__}: {err}"}
         out["parity"] = {

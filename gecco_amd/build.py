@@ -12,8 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgecco_crf.so")
-SOURCES = ["crf_model.cpp", "crf_plan.cpp", "crf_session.cpp", "crf_tables.cpp", "capi.cpp", "crf_kernels.hip", "crf_sequence.hip", "crf_segment.hip", "crf_general.hip", "crf_composition.hip"]
-HEADERS = ["crf_model.hpp", "crf_plan.hpp", "crf_device.hpp", "crf_scan.hpp", "crf_vd_short.hpp", "crf_session.hpp", "crf_tables.hpp", os.path.join("..", "..", "include", "gecco_crf.h")]
+SOURCES = ["crf_model.cpp", "crf_plan.cpp", "crf_session.cpp", "crf_tables.cpp", "capi.cpp", "crf_kernels.hip", "crf_sequence.hip", "crf_segment.hip", "crf_general.hip", "crf_composition.hip", "crf_exact.hip"]
+HEADERS = ["crf_model.hpp", "crf_plan.hpp", "crf_device.hpp", "crf_scan.hpp", "crf_vd_short.hpp", "crf_session.hpp", "crf_tables.hpp", "crf_exact_exp.hpp", os.path.join("..", "..", "include", "gecco_crf.h")]
+# reference-bits mode and the correctly rounded exp rely on every multiply and add being rounded on its own: no fused multiply-add
+# where the source has none
+EXTRA_FLAGS = {"crf_exact.hip": ["-ffp-contract=off"], "capi.cpp": ["-ffp-contract=off"]}
 ARCH = "gfx950"
 
 
@@ -42,7 +45,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
               "-Wno-unused-parameter"]
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, *common, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *common, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

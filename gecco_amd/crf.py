@@ -489,6 +489,10 @@ class ClusterCRF(object):
         if ses is None or ses[0] != devices or ses[1].model is not native:
             ses = (devices, _native.Session(native, devices))
             self._ses = ses
+        # `reference_bits` (attribute, or GECCO_AMD_REFERENCE_BITS=1): CRFsuite's own operation order with a correctly rounded
+        # exp -- genes.tsv / features.tsv / clusters.tsv come out with the reference's bits (the reference's own acceptance
+        # test compares whole files, galaxy/gecco.xml:83-111) at about forty times the fast kernels' time
+        ses[1].set_reference_bits(bool(getattr(self, "reference_bits", False)) or os.environ.get("GECCO_AMD_REFERENCE_BITS") == "1")
         return ses[1]
 
     def _score(self, batch: "packing.PackedBatch", W: int, step: int, label: int, pad: bool,

@@ -8,6 +8,7 @@
 #include <string>
 
 #include "../../include/gecco_crf.h"
+#include "crf_exact_exp.hpp"
 #include "crf_model.hpp"
 #include "crf_plan.hpp"
 #include "crf_session.hpp"
@@ -353,6 +354,16 @@ GECCO_API int gecco_crf_session_set_chunk_genes(gecco_crf_session *s, int32_t ge
 GECCO_API int gecco_crf_session_set_direct_genes(gecco_crf_session *s, int32_t genes) {
     if (!s || genes < 0) return GECCO_CRF_EINVAL;
     session_set_direct_genes(*s->s, genes);
+    return GECCO_CRF_OK;
+}
+GECCO_API int gecco_crf_session_set_reference_bits(gecco_crf_session *s, int32_t on) {
+    if (!s) return GECCO_CRF_EINVAL;
+    session_set_reference_bits(*s->s, on != 0);
+    return GECCO_CRF_OK;
+}
+GECCO_API int gecco_crf_exp_correctly_rounded(const double *x, int64_t n, double *out) {
+    if (n < 0 || (n > 0 && (!x || !out))) return GECCO_CRF_EINVAL;
+    for (int64_t i = 0; i < n; ++i) out[i] = gecco::ddx::exp_correctly_rounded(x[i]);
     return GECCO_CRF_OK;
 }
 GECCO_API int gecco_crf_session_stats(const gecco_crf_session *s, int32_t *n_chunks, int64_t *h2d_bytes, int64_t *d2h_bytes,

@@ -317,6 +317,11 @@ hipError_t launch_composition(const int32_t *d_seg, int n_seg, const int32_t *d_
                               const double *d_dom_w, double *d_tmp, int n_cols, int normalize, double *d_out,
                               hipStream_t stream);
 
+// ---- reference-bits mode (crf_exact.hip): CRFsuite's operation order, correctly rounded exp ----------------------
+bool reference_bits_ok(int L, int W);
+size_t reference_scratch_bytes(int n_genes);
+hipError_t launch_windowed_reference(const WinArgs &w, const double2 *wtab01, const double *exp_trans_host, void *scratch, hipStream_t stream);
+
 const char *windowed_kernel_name(int W, int L, bool fast);
 // tile_out = output slots per workgroup for the kernel that (W, L) dispatches to.
 int windowed_tile_out(int W, int L, int tiles_per_wg);

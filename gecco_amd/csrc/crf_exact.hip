@@ -1,0 +1,164 @@
+// Reference-bits mode: windowed marginals of a 2-label model in CRFsuite's OWN operation order, so that the probabilities --
+// and with them genes.tsv / features.tsv / clusters.tsv -- come out with the reference's bits, not merely within 1e-12 of them.
+//
+// The fast kernels (crf_kernels.hip) reorganise the arithmetic (ratio form, one reciprocal per window, a table-driven exp): their
+// results sit within a few ulps of CRFsuite's (<= 13 ulps on the BGC0001866 fixture, where every one of the 48 printed
+// probabilities differs in its last digits from the reference's files).  The reference's own acceptance test compares whole
+// files (/root/reference/galaxy/gecco.xml:83-111), so this mode restates [EXT] crf1dc_exp_state / crf1dc_alpha_score /
+// crf1dc_beta_score / crf1dc_marginal_point literally, as oracle/crf_oracle.c does (separate multiply and add roundings, the
+// per-step 1 / sum scaling as an IEEE division, alpha * beta / scale) around the window loop of
+// /root/reference/gecco/crf/__init__.py:244-258 -- with ONE substitution: libm's exp becomes the correctly rounded exp
+// (crf_exact_exp.hpp), which is what libm returns for all but ~0.07 % of arguments (glibc: 0.51 ulp).  exp(trans) comes from
+// the host's libm, as in the reference.  One lane per window start, alpha and the scale factors of a window in registers
+// (W <= 32), per-gene maximum by atomic maximum on the bit pattern (probabilities are non-negative: order-independent, exact).
+// Speed is not the point (about forty times the fast kernel's time); selected per session / plan (gecco_crf_session_set_reference_bits,
+// GECCO_CRF_REFERENCE_BITS=1).
+#include "crf_device.hpp"
+#include "crf_exact_exp.hpp"
+
+namespace gecco {
+namespace {
+
+constexpr int kRefT = 256;
+constexpr int kRefMaxW = 32;
+
+#pragma clang fp contract(off)
+
+// exp of the state scores of every gene: E[g] = (exp(s[g][0]), exp(s[g][1])), s summed attribute by attribute in CSR order
+// ([EXT] crf1dt_state_score: state[t][y] += w[a][y] * 1.0)
+__global__ void __launch_bounds__(kRefT) ref_exp_states(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
+                                                        const double2 *__restrict__ wtab01, int n_attrs, int n_genes, double2 *__restrict__ E) {
+    const int g = blockIdx.x * kRefT + threadIdx.x;
+    if (g >= n_genes) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = gene_ptr[g]; k < gene_ptr[g + 1]; ++k) {
+        const int a = attr_id[k];
+        if (unsigned(a) < unsigned(n_attrs)) {  // (names CRFsuite does not know carry no weight)
+            const double2 w = wtab01[a];
+            s0 += w.x;
+            s1 += w.y;
+        }
+    }
+    E[g] = make_double2(ddx::exp_correctly_rounded(s0), ddx::exp_correctly_rounded(s1));
+}
+
+struct RefArgs {
+    const double2 *E;          // [n_genes] exp of the state scores, label order
+    const int32_t *c_slot, *c_gene, *c_n;
+    const uint64_t *start_bits;
+    double *p_out;             // zeroed (genes no window covers keep 0.0), skipped contigs NaN
+    int32_t K, S, W, label;
+    double t00, t01, t10, t11; // exp(trans), host libm
+};
+
+__global__ void __launch_bounds__(kRefT, 2) crf_windowed_reference_l2(const RefArgs A) {
+    const int q = blockIdx.x * kRefT + threadIdx.x;
+    if (q >= A.S) return;
+    if (!((A.start_bits[q >> 6] >> (q & 63)) & 1ull)) return;
+    int lo = 0, hi = A.K - 1;  // contig of this window: largest k with c_slot[k] <= q
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (A.c_slot[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    const int s0 = A.c_slot[lo], np = A.c_slot[lo + 1] - s0, n = A.c_n[lo], g0 = A.c_gene[lo];
+    const int pos = q - s0, lpad = (np - n) >> 1;  // delta // 2 empty items in front (crf/__init__.py:227)
+    const int W = A.W;
+    auto gene_of = [&](int k) {
+        const int gl = pos + k - lpad;
+        return (gl >= 0 && gl < n) ? g0 + gl : -1;
+    };
+    auto exp_state = [&](int k) {
+        const int g = gene_of(k);
+        return g >= 0 ? A.E[g] : make_double2(1.0, 1.0);  // a padding item has no attribute: state 0, exp 1
+    };
+    double a0[kRefMaxW], a1[kRefMaxW], sc[kRefMaxW];
+    // ---- [EXT] crf1dc_alpha_score
+    {
+        const double2 e = exp_state(0);
+        double x0 = e.x, x1 = e.y;
+        const double sum = x0 + x1;
+        const double c = (sum != 0.) ? 1. / sum : 1.;
+        x0 *= c;
+        x1 *= c;
+        a0[0] = x0;
+        a1[0] = x1;
+        sc[0] = c;
+    }
+#pragma unroll
+    for (int t = 1; t < kRefMaxW; ++t) {
+        if (t < W) {
+            const double2 e = exp_state(t);
+            const double p0 = a0[t - 1], p1 = a1[t - 1];
+            double x0 = p0 * A.t00, x1 = p0 * A.t01;  // cur[j] = 0 + prev[0] * trans[0][j]
+            x0 = x0 + p1 * A.t10;                     //        + prev[1] * trans[1][j]
+            x1 = x1 + p1 * A.t11;
+            x0 *= e.x;
+            x1 *= e.y;
+            const double sum = x0 + x1;
+            const double c = (sum != 0.) ? 1. / sum : 1.;
+            x0 *= c;
+            x1 *= c;
+            a0[t] = x0;
+            a1[t] = x1;
+            sc[t] = c;
+        }
+    }
+    // ---- [EXT] crf1dc_beta_score + crf1dc_marginal_point, back to front
+    double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+    for (int t = kRefMaxW - 1; t >= 0; --t) {
+        if (t < W) {
+            if (t == W - 1) {
+                b0 = b1 = sc[t];
+            } else {
+                const double2 e = exp_state(t + 1);
+                const double r0 = b0 * e.x, r1 = b1 * e.y;  // row[j] = next[j] * exp_state[t + 1][j]
+                double y0 = A.t00 * r0, y1 = A.t10 * r0;    // s = 0 + trans[i][0] * row[0]
+                y0 = y0 + A.t01 * r1;                       //       + trans[i][1] * row[1]
+                y1 = y1 + A.t11 * r1;
+                b0 = y0 * sc[t];
+                b1 = y1 * sc[t];
+            }
+            const int g = gene_of(t);
+            if (g >= 0) {
+                const double m = (A.label ? a1[t] * b1 : a0[t] * b0) / sc[t];  // alpha * beta / scale
+                atomicMax(reinterpret_cast<unsigned long long *>(A.p_out + g), static_cast<unsigned long long>(__double_as_longlong(m)));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool reference_bits_ok(int L, int W) { return L == 2 && W >= 1 && W <= kRefMaxW; }
+
+size_t reference_scratch_bytes(int n_genes) { return (size_t(n_genes) + 1) * sizeof(double2); }
+
+// p_out zeroed by the caller (and NaN in skipped contigs); wtab01: the weight pairs in LABEL order (w[a][0], w[a][1]);
+// exp_trans_host: exp(trans[i][j]) row-major, from the host's libm; `scratch`: reference_scratch_bytes(n_genes)
+hipError_t launch_windowed_reference(const WinArgs &w, const double2 *wtab01, const double *exp_trans_host, void *scratch, hipStream_t stream) {
+    if (!reference_bits_ok(w.L, w.W)) return hipErrorNotSupported;
+    if (w.n_genes <= 0 || w.S <= 0) return hipSuccess;
+    double2 *E = static_cast<double2 *>(scratch);
+    hipLaunchKernelGGL(ref_exp_states, dim3((w.n_genes + kRefT - 1) / kRefT), dim3(kRefT), 0, stream, w.gene_ptr, w.attr_id, wtab01, w.A,
+                       w.n_genes, E);
+    RefArgs a{};
+    a.E = E;
+    a.c_slot = w.c_slot;
+    a.c_gene = w.c_gene;
+    a.c_n = w.c_n;
+    a.start_bits = w.start_bits;
+    a.p_out = w.p_out;
+    a.K = w.K;
+    a.S = w.S;
+    a.W = w.W;
+    a.label = w.label;
+    a.t00 = exp_trans_host[0];
+    a.t01 = exp_trans_host[1];
+    a.t10 = exp_trans_host[2];
+    a.t11 = exp_trans_host[3];
+    hipLaunchKernelGGL(crf_windowed_reference_l2, dim3((w.S + kRefT - 1) / kRefT), dim3(kRefT), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace gecco

@@ -299,6 +299,23 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     }
     p.fast_ok = (!p.general && W <= kWinMaxW && rescale_mask_for(m, W, &p.rescale_mask));
     {
+        static const bool env_reference = [] {
+            const char *env = std::getenv("GECCO_CRF_REFERENCE_BITS");
+            return env && env[0] == '1';
+        }();
+        p.reference_now = p.reference_bits || env_reference;
+        if (p.reference_now) {
+            if (!reference_bits_ok(m.L, W)) {
+                set_error("reference-bits mode serves 2-label models and windows of at most 32 genes");
+                return GECCO_CRF_EUNSUPPORTED;
+            }
+            // (the fast kernels' by-products -- score differences for the decoder, p in host memory -- are theirs alone: the
+            // decoder sums its state scores itself, p goes through device memory)
+            p.general = false;
+            p.fast_ok = false;
+        }
+    }
+    {
         const char *env = std::getenv("GECCO_CRF_FORCE_GENERIC");
         p.force_generic = env && env[0] == '1';
     }
@@ -338,7 +355,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
         p.gen_small = true;
         p.tile_out = gen_small_tile_out(W);
     } else {
-        p.kernel_name = p.general ? "gl_windowed" : windowed_kernel_name(W, m.L, p.fast_ok);
+        p.kernel_name = p.reference_now ? "crf_windowed_reference_l2" : p.general ? "gl_windowed" : windowed_kernel_name(W, m.L, p.fast_ok);
         p.tile_out = windowed_tile_out(W, m.L, p.tiles_per_wg);
     }
     p.ntiles = p.S > 0 ? (p.S + p.tile_out - 1) / p.tile_out : 0;
@@ -639,6 +656,19 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     }
     a.csr_begin = int32_t(p.csr_begin);  // (row pointers are 32-bit)
     a.csr_end = int32_t(p.csr_end);
+    if (p.reference_now) {
+        {
+            std::lock_guard<std::mutex> lock(p.ws_mutex);
+            if ((rc = grow_ws(p.d_win_scratch, p.win_scratch_cap, reference_scratch_bytes(p.n_genes), "hipMalloc reference scratch"))) return rc;
+        }
+        // atomic-max accumulation starts from 0.0 (numpy.zeros, crf/__init__.py:251)
+        if ((rc = check_hip(hipMemsetAsync(d_p_out, 0, size_t(p.n_genes) * 8, stream), "memset p"))) return rc;
+        if (!p.skipped.empty())
+            if ((rc = check_hip(launch_fill_nan(d_p_out, p.d_skipped, int(p.skipped.size()), stream), "fill_nan launch"))) return rc;
+        double et[4];
+        for (int i = 0; i < 4; ++i) et[i] = std::exp(m.trans[size_t(i)]);  // (the host's libm, as the reference's CRFsuite calls it)
+        return check_hip(launch_windowed_reference(a, p.tables_model->wtab2[1], et, p.d_win_scratch, stream), "reference-bits launch");
+    }
     a.generic = p.fast_ok ? 0 : 1;
     if (a.generic) {
         {

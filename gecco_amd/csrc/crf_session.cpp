@@ -231,6 +231,7 @@ struct Session {
     // 10 000, 62 / 97 at 65 000, 105 / 140 at 200 000; cluster rows 62 / 72, 63 / 91, 91 / 94, 121 / 113: the refiner's seven
     // short launches sit in one stream behind the tiles either way, so cluster calls stop at half the size.
     int32_t direct_genes = 1 << 17;
+    bool reference_bits = false;  // windowed marginals in CRFsuite's operation order (crf_exact.hip): the reference's bits
     SessionStats stats;
     ~Session();
 };
@@ -320,6 +321,10 @@ void session_destroy(Session *s) { delete s; }
 void session_set_chunk_genes(Session &s, int32_t genes) {
     std::lock_guard<std::mutex> lock(s.mu);
     s.chunk_genes = std::max(1024, genes);
+}
+void session_set_reference_bits(Session &s, bool on) {
+    std::lock_guard<std::mutex> lock(s.mu);
+    s.reference_bits = on;
 }
 void session_set_direct_genes(Session &s, int32_t genes) {
     std::lock_guard<std::mutex> lock(s.mu);
@@ -739,6 +744,7 @@ int submit_plan(RunCtx &X, Lane &ln, int chunk_index) {
         ln.plan.tables_by_kernel = true;
         // small batches: the decoder's tables and flag bytes too are read where the host wrote them
         ln.plan.seq_in_host_memory = X.direct && !r.want_segments && !X.full && !r.score_out;
+        ln.plan.reference_bits = X.S.reference_bits && X.windowed;
     }
     if (ck.piece) {  // a stretch of ONE long contig, scored as a contig of its own
         const int32_t span[2] = {ck.u0, ck.u1};

@@ -62,6 +62,7 @@ void session_destroy(Session *s);
 int session_run(Session &s, const BatchRequest &r);
 void session_set_chunk_genes(Session &s, int32_t genes);
 void session_set_direct_genes(Session &s, int32_t genes);
+void session_set_reference_bits(Session &s, bool on);
 SessionStats session_stats(const Session &s);
 
 }  // namespace gecco

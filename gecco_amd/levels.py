@@ -237,7 +237,7 @@ _CLUSTER_COLUMNS = ("sequence_id", "cluster_id", "start", "end", "average_p", "m
 _FLOAT_COLUMNS = {"average_p", "max_p", "cluster_probability"}
 
 
-def golden_table_identity(golden_dir, out_dir=None):
+def golden_table_identity(golden_dir, out_dir=None, reference_bits=False):
     """The reference's own acceptance test (/root/reference/galaxy/gecco.xml:83-111 asserts whole-file equality of
     genes.tsv / clusters.tsv): write the three tables of the BGC0001866 fixture through `python -m gecco_amd.predict` and
     count the cells that are not STRING-identical to the fixture's -- probabilities are printed with repr()'s 16-17 digits,
@@ -259,7 +259,8 @@ def golden_table_identity(golden_dir, out_dir=None):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             predict.main(["--genes", os.path.join(golden_dir, "BGC0001866.genes.tsv"), "--features",
-                          os.path.join(golden_dir, "BGC0001866.features.tsv"), "--model", golden_dir, "-o", tmp])
+                          os.path.join(golden_dir, "BGC0001866.features.tsv"), "--model", golden_dir, "-o", tmp]
+                         + (["--reference-bits"] if reference_bits else []))
         for table in ("genes", "features", "clusters"):
             got, ref = rows(os.path.join(tmp, f"BGC0001866.{table}.tsv")), rows(os.path.join(golden_dir, f"BGC0001866.{table}.tsv"))
             cols = _CLUSTER_COLUMNS if table == "clusters" else tuple(ref[0].keys())
@@ -292,6 +293,7 @@ def golden_table_identity(golden_dir, out_dir=None):
                         t["exact_cells"] += 1
                         t["exact_cells_differing"] += int(a[c] != b[c])
             res[table] = t
+    res["mode"] = "reference bits (CRFsuite's operation order, correctly rounded exp)" if reference_bits else "fast kernels"
     res["note"] = ("cells of the tables written by `python -m gecco_amd.predict` on the BGC0001866 fixture that are not string-identical "
                    "to the reference's own output files (tests/golden = /root/reference/tests/test_cli/data): text and integer "
                    "columns must be identical; float columns differ where the probability is an ulp or two away from CRFsuite's "

@@ -246,6 +246,18 @@ int gecco_crf_session_set_direct_genes(gecco_crf_session *s, int32_t genes);
 /* Figures of the last batch (any pointer may be NULL). */
 int gecco_crf_session_stats(const gecco_crf_session *s, int32_t *n_chunks, int64_t *h2d_bytes,
                             int64_t *d2h_bytes, double *host_plan_seconds, double *wall_seconds);
+/* REFERENCE-BITS MODE.  The fast kernels reorganise CRFsuite's arithmetic; their probabilities lie within a few ulps of the
+ * reference's (<= 13 on the BGC0001866 fixture) -- enough for bit-identical cluster calls, not for the reference's own acceptance
+ * test, which compares whole output files (/root/reference/galaxy/gecco.xml:83-111; probabilities are printed with 16-17
+ * digits).  With this switch on, the session's windowed marginals -- and so its cluster calls and the p of its decode calls --
+ * are computed in CRFsuite's OWN operation order ([EXT] crf1dc_exp_state / alpha_score / beta_score / marginal_point as
+ * restated in oracle/crf_oracle.c) with a correctly rounded exp in place of libm's: the reference's bits wherever its libm
+ * rounds correctly (glibc: all but ~0.07 % of arguments), at about forty times the fast kernels' time.  2-label models, windows
+ * of at most 32 genes (GECCO_CRF_EUNSUPPORTED otherwise).  GECCO_CRF_REFERENCE_BITS=1 switches it on for every session and plan. */
+int gecco_crf_session_set_reference_bits(gecco_crf_session *s, int32_t on);
+/* The exp that mode uses, on the host (a double-double evaluation; same code as the device's): out[i] = the double nearest to
+ * exp(x[i]). */
+int gecco_crf_exp_correctly_rounded(const double *x, int64_t n, double *out);
 /* The same and more as one struct: whether the batch took the direct path, and the time the submitting host threads spent
  * issuing work (HIP API calls + chunk layouts), which is what bounds a session over many devices. */
 typedef struct {

@@ -29,6 +29,15 @@
 
 #define ORACLE_API __attribute__((visibility("default")))
 
+/* exp of the state scores ([EXT] crf1dc_exp_state).  Mode 0 (default): libm's exp, what CRFsuite calls.  Mode 1: the correctly
+ * rounded exp -- libquadmath's expq (113-bit) rounded to double --, the checker of the product's reference-bits mode
+ * (gecco_amd/csrc/crf_exact.hip), whose own correctly rounded exp is a double-double evaluation: the two are independent
+ * implementations of the same mathematical function, and glibc's exp agrees with both on all but ~0.07 % of arguments. */
+#include <quadmath.h>
+static int g_exp_mode = 0;
+ORACLE_API void oracle_set_exp_mode(int mode) { g_exp_mode = mode; }
+static inline double oracle_exp(double x) { return g_exp_mode ? (double)expq((__float128)x) : exp(x); }
+
 /* ---- row S: [EXT] crf1dt_state_score -------------------------------------------
  * state[t][y] += w[a][y] * value, value == 1.0 for GECCO's {name: True} items
  * (gecco/crf/features.py:31-35).  Attributes are visited in item order. */
@@ -73,7 +82,7 @@ static double forward_backward(fb_ctx *c, const double *state, const double *exp
 {
     const int L = c->L;
     double *a = c->alpha, *b = c->beta, *sc = c->scale, *es = c->exp_state;
-    for (size_t i = 0; i < (size_t)T * L; ++i) es[i] = exp(state[i]);
+    for (size_t i = 0; i < (size_t)T * L; ++i) es[i] = oracle_exp(state[i]);
 
     /* alpha */
     double sum = 0.0;

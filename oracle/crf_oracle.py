@@ -37,6 +37,17 @@ def lib():
     return _lib
 
 
+class correctly_rounded_exp:
+    """``with correctly_rounded_exp(): ...``: the state scores' exp as the correctly rounded function (libquadmath's expq
+    rounded to double) instead of libm's -- the checker of the product's reference-bits mode.  Not thread-safe."""
+
+    def __enter__(self):
+        lib().oracle_set_exp_mode(1)
+
+    def __exit__(self, *exc):
+        lib().oracle_set_exp_mode(0)
+
+
 def _p(a, t):
     return a.ctypes.data_as(ctypes.POINTER(t))
 

@@ -1,0 +1,138 @@
+"""Reference-bits mode (gecco_amd/csrc/crf_exact.hip): windowed marginals in CRFsuite's own operation order with a correctly
+rounded exp.  Checked BIT FOR BIT against the oracle run with its own correctly rounded exp (libquadmath's expq -- an
+independent implementation), and against the reference's output files: every one of the 46 + 37 + 2 probabilities the
+BGC0001866 fixture prints comes out string-identical (/root/reference/galaxy/gecco.xml:83-111 compares whole files)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402,F401  (before libgecco_crf.so: the wheel's own HIP runtime has to be the first one loaded)
+
+from gecco_amd import latency  # noqa: E402
+from tests.helpers import GOLDEN, golden_csr, read_tsv, synth_contigs, synth_model  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from gecco_amd import _native
+
+    assert _native.device_count() >= 1, "no HIP device: the GPU suite must run on an MI355X"
+    return _native
+
+
+@pytest.fixture(scope="module")
+def real_model(nat):
+    return nat.Model.from_lcrf(latency.real_blob())
+
+
+def _bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_reference_bits_reproduce_the_fixture_strings(nat, real_model, oracle_model):
+    """The 23 probabilities of BGC0001866.genes.tsv, as printed: repr() of the device's doubles == the file's strings."""
+    ids, cptr, gptr, attr, exp, ann = golden_csr(oracle_model["attr_index"])
+    genes = read_tsv(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))
+    ses = nat.Session(real_model, [0])
+    fast = ses.windowed_marginals(cptr, gptr, attr, 20)
+    ses.set_reference_bits(True)
+    p = ses.windowed_marginals(cptr, gptr, attr, 20)
+    assert [repr(float(x)) for x in p] == [g["average_p"] for g in genes]
+    assert float(np.abs(p - fast).max()) <= 1e-14  # (and the fast kernels are an ulp or a dozen away)
+    ses.set_reference_bits(False)
+    _bits(ses.windowed_marginals(cptr, gptr, attr, 20), fast)
+
+
+@pytest.mark.parametrize("lengths,W,pad,step,direct", [
+    ([50], 20, True, 1, True), ([7, 19, 20, 21, 0, 400, 1], 20, True, 1, True), ([7, 19, 20, 21, 0, 400, 1], 20, False, 1, False),
+    ([300, 5, 60], 20, True, 3, True), ([2500, 30, 2049], 20, True, 1, False), ([120, 40, 9], 25, True, 1, True), ([90, 12], 32, False, 2, True),
+    ([200] * 40, 20, True, 1, False),
+])
+def test_reference_bits_equal_the_oracle_with_a_correctly_rounded_exp(nat, real_model, oracle_model, lengths, W, pad, step, direct):
+    """Bit for bit, for padded / skipped / empty / long contigs, window sizes and steps other than GECCO's, through the direct
+    path and through chunks; decode calls deliver the same p and CRFsuite's labels; cluster calls cut the same rows."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(len(lengths) * 100 + W)
+    cptr, gptr, attr = synth_contigs(rng, lengths, real_model.num_attrs)
+    with orc.correctly_rounded_exp():
+        ep = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, W, step, 1, pad)
+    ep_libm = orc.windowed_marginals(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr, W, step, 1, pad)
+    ey, _ = orc.viterbi(oracle_model["state"], oracle_model["trans"], cptr, gptr, attr)
+    ses = nat.Session(real_model, [0])
+    ses.set_reference_bits(True)
+    if not direct:
+        ses.set_chunk_genes(1024)
+    p = ses.windowed_marginals(cptr, gptr, attr, W, step=step, pad=pad)
+    assert ses.stats()["direct"] == (1 if direct or int(cptr[-1]) <= 1024 else 0)
+    _bits(p, ep)
+    # against libm's exp: the same bits on all but a handful of genes (where glibc's exp is not the correctly rounded one)
+    differ = int(np.sum(~((p == ep_libm) | (np.isnan(p) & np.isnan(ep_libm)))))
+    assert differ <= max(2, len(p) // 50), differ
+    p2, y = ses.decode(cptr, gptr, attr, W, step=step, pad=pad)
+    _bits(p2, ep)
+    np.testing.assert_array_equal(y.astype(np.int32), ey)
+    ann = (np.diff(gptr) > 0).astype(np.uint8)
+    finite = np.sort(ep[~np.isnan(ep)])
+    if len(finite) > 4:
+        thr = float(0.5 * (finite[len(finite) // 2] + finite[len(finite) // 2 + 1]))
+        seg, seg_p, seg_off, pp = ses.clusters(cptr, gptr, attr, ann, W, step=step, pad=pad, threshold=thr, n_cds=2, want_p=True)
+        _bits(pp, ep)
+        np.testing.assert_array_equal(seg, orc.segment(ep, ann, cptr, thr, 2, 0, True))
+        for k, row in enumerate(seg):
+            _bits(seg_p[seg_off[k]:seg_off[k + 1]], ep[row[2]:row[3]])
+
+
+def test_reference_bits_on_a_synthetic_model(nat):
+    """SURVEY.md 8d's weight law (windows that overflow the fast kernels' ratio form included): still the oracle's bits."""
+    from oracle import crf_oracle as orc
+
+    rng = np.random.default_rng(8)
+    w, trans = synth_model(3000, rng)
+    model = nat.Model.from_tables(w, trans)
+    cptr, gptr, attr = synth_contigs(rng, [150] * 30 + [17, 800], 3000)
+    with orc.correctly_rounded_exp():
+        ep = orc.windowed_marginals(w, trans, cptr, gptr, attr, 20, 1, 1, True)
+    ses = nat.Session(model, [0])
+    ses.set_reference_bits(True)
+    _bits(ses.windowed_marginals(cptr, gptr, attr, 20), ep)
+    # label 0 queried
+    with orc.correctly_rounded_exp():
+        e0 = orc.windowed_marginals(w, trans, cptr, gptr, attr, 20, 1, 0, True)
+    _bits(ses.windowed_marginals(cptr, gptr, attr, 20, label=0), e0)
+
+
+def test_reference_bits_unsupported_shapes(nat):
+    rng = np.random.default_rng(9)
+    w, trans = synth_model(50, rng, L=3)
+    cptr, gptr, attr = synth_contigs(rng, [60], 50)
+    ses = nat.Session(nat.Model.from_tables(w, trans), [0])
+    ses.set_reference_bits(True)
+    with pytest.raises(nat.NativeError):
+        ses.windowed_marginals(cptr, gptr, attr, 20)
+    w2, t2 = synth_model(50, rng)
+    ses2 = nat.Session(nat.Model.from_tables(w2, t2), [0])
+    ses2.set_reference_bits(True)
+    with pytest.raises(nat.NativeError):
+        ses2.windowed_marginals(cptr, gptr, attr, 40)
+
+
+def test_cli_tables_are_the_reference_files_in_reference_bits_mode(tmp_path, capsys):
+    """`python -m gecco_amd.predict --reference-bits` on the fixture: every cell of genes.tsv, features.tsv and of the CRF's
+    columns of clusters.tsv is string-identical to the reference's file (`proteins` / `domains`: to the reference's current
+    formula -- the fixture file predates it)."""
+    from gecco_amd import levels
+
+    res = levels.golden_table_identity(GOLDEN, str(tmp_path), reference_bits=True)
+    with capsys.disabled():
+        print("\n[table identity, reference bits]", {k: v for k, v in res.items() if k not in ("note", "mode")})
+    for table, n_float in (("genes", 46), ("features", 37), ("clusters", 2)):
+        t = res[table]
+        assert t["rows"] == t["rows_expected"]
+        assert t["exact_cells_differing"] == 0
+        assert t["float_cells"] == n_float and t["float_cells_differing"] == 0
+    assert res["clusters"]["formula_cells_differing"] == 0

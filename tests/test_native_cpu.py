@@ -158,3 +158,22 @@ def test_pipelined_decode_kernel_keeps_its_window_tiles_out_of_scratch():
 
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_tile_path.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_exp_correctly_rounded_against_decimal():
+    """The exp of reference-bits mode (gecco_crf_exp_correctly_rounded: the host build of the device's double-double code)
+    returns the double nearest to exp(x): 12 000 random arguments over the range state scores take, and the edges."""
+    import random
+    from decimal import Decimal, getcontext
+
+    from gecco_amd import _native
+
+    getcontext().prec = 60
+    random.seed(5)
+    xs = [0.0, 1.0, -1.0, 700.0, -700.0, 709.7, -744.0, 1e-300, 12.65, -6.3] + [random.uniform(-60, 60) for _ in range(8000)] + \
+         [random.uniform(-700, 700) for _ in range(2000)] + [random.gauss(0, 3) for _ in range(2000)]
+    got = _native.exp_correctly_rounded(np.array(xs))
+    want = np.array([float(Decimal(x).exp()) for x in xs])
+    assert got.tobytes() == want.tobytes()
+    assert np.isnan(_native.exp_correctly_rounded(np.array([np.nan]))[0])
+    assert _native.exp_correctly_rounded(np.array([800.0]))[0] == np.inf and _native.exp_correctly_rounded(np.array([-800.0]))[0] == 0.0
