@@ -621,12 +621,18 @@ def main() -> None:
         nc = min(len(wl["contig_ptr"]) - 1, 10000)
         cp = wl["contig_ptr"][: nc + 1]
         ng = int(cp[-1])
-        t0 = time.perf_counter()
-        p_ref = orc.windowed_marginals(wl["w"], wl["trans"], cp, wl["gene_ptr"][: ng + 1], wl["attr_id"], W, STEP, LABEL, True)
-        dt_win = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        y_ref, _ = orc.viterbi(wl["w"], wl["trans"], cp, wl["gene_ptr"][: ng + 1], wl["attr_id"])
-        dt_vit = time.perf_counter() - t0
+        # (a batch the port finishes in microseconds -- C1 -- is repeated until a fifth of a second has been measured)
+        reps_cpu, dt_win, dt_vit = 0, 0.0, 0.0
+        while reps_cpu == 0 or (dt_win + dt_vit < 0.2 and reps_cpu < 100000):
+            t0 = time.perf_counter()
+            p_ref = orc.windowed_marginals(wl["w"], wl["trans"], cp, wl["gene_ptr"][: ng + 1], wl["attr_id"], W, STEP, LABEL, True)
+            dt_win += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            y_ref, _ = orc.viterbi(wl["w"], wl["trans"], cp, wl["gene_ptr"][: ng + 1], wl["attr_id"])
+            dt_vit += time.perf_counter() - t0
+            reps_cpu += 1
+        dt_win /= reps_cpu
+        dt_vit /= reps_cpu
         dt = dt_win + (0.0 if args.windowed_only else dt_vit)
         res.d_y.fill_(7)  # (the parity check below reads the labels this step delivers, not older ones)
         res.step()
@@ -638,8 +644,9 @@ def main() -> None:
             "unit": "genes/s",
             "cores": 1,
             "kind": "port",
-            "sample": f"first {nc} contigs ({ng} genes) of the same workload: windowed marginals {dt_win:.2f} s"
-                      + ("" if args.windowed_only else f" + Viterbi {dt_vit:.2f} s") + ", C oracle driven window by window like the reference",
+            "sample": f"first {nc} contigs ({ng} genes) of the same workload" + (f", mean of {reps_cpu} repetitions" if reps_cpu > 1 else "")
+                      + f": windowed marginals {dt_win:.3g} s" + ("" if args.windowed_only else f" + Viterbi {dt_vit:.3g} s")
+                      + ", C oracle driven window by window like the reference",
         }
         # SURVEY.md 8d also asks for the same restatement on all host cores (contigs over threads)
         ncpu, cpu_note = _usable_host_threads()

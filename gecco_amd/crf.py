@@ -366,10 +366,21 @@ class ClusterCRF(object):
             raise ValueError(f"invalid feature type: {self.feature_type!r}")
 
         # :199-206 -- sort (mutating the caller's domain lists, as the reference does), group
-        genes = sorted(genes, key=operator.attrgetter("source.id", "start"))
-        for gene in genes:
-            gene.protein.domains.sort(key=operator.attrgetter("start"))
-        contigs: List[List[Any]] = [list(g) for _, g in itertools.groupby(genes, key=operator.attrgetter("source.id"))]
+        contigs: Optional[List[List[Any]]] = None
+        if self.feature_type == "protein":
+            from ._objpath_loader import module as _objpath
+
+            native = _objpath()  # csrc/objpath.c: one pass that checks the order, sorts what is not, and groups
+            if native is not None:
+                genes = genes if isinstance(genes, (list, tuple)) else list(genes)
+                got = native.sort_group(genes, operator.attrgetter("start"))
+                if got is not None:
+                    genes, contigs = got
+        if contigs is None:
+            genes = sorted(genes, key=operator.attrgetter("source.id", "start"))
+            for gene in genes:
+                gene.protein.domains.sort(key=operator.attrgetter("start"))
+            contigs = [list(g) for _, g in itertools.groupby(genes, key=operator.attrgetter("source.id"))]
 
         # :209-236 -- features -> CSR items; decide padding / skipping per contig
         W, step = self.window_size, self.window_step

@@ -298,7 +298,136 @@ static PyObject *annotate_all(PyObject *self, PyObject *args)
     return out;
 }
 
+/* sort_group(genes, start_key) -> (genes as a list, contigs as a list of lists) or None.
+ * gecco/crf/__init__.py:199-206: genes sorted by (source.id, start), every gene's domain list sorted by start IN PLACE, genes
+ * grouped by source.id.  Annotation pipelines emit genes in that order already, and sorted() is stable: when the input is
+ * non-decreasing in (source.id, start) the sorted list IS the input, and only the (rare) unsorted domain lists are sorted
+ * (list.sort(key=start_key), the reference's own call).  Anything else -- an unsorted input, keys that do not compare --
+ * returns None and the caller runs the Python statements. */
+static PyObject *s_source, *s_id, *s_start, *s_sort, *s_key;
+static PyObject *sort_group(PyObject *self, PyObject *args)
+{
+    PyObject *genes, *start_key;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "OO", &genes, &start_key)) return NULL;
+    PyObject *seq = PySequence_Fast(genes, "genes must be iterable");
+    if (!seq) return NULL;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    PyObject *out_genes = PyList_New(n), *contigs = PyList_New(0), *cur = NULL, *prev_id = NULL, *prev_start = NULL, *result = NULL;
+    int sorted_input = 1;
+    if (!out_genes || !contigs) goto done;
+    for (Py_ssize_t i = 0; i < n && sorted_input; ++i) {
+        PyObject *g = PySequence_Fast_GET_ITEM(seq, i);
+        Py_INCREF(g);
+        PyList_SET_ITEM(out_genes, i, g);
+        PyObject *src = PyObject_GetAttr(g, s_source);
+        PyObject *id = src ? PyObject_GetAttr(src, s_id) : NULL;
+        Py_XDECREF(src);
+        PyObject *start = id ? PyObject_GetAttr(g, s_start) : NULL;
+        if (!start) {
+            Py_XDECREF(id);
+            goto done;
+        }
+        int same = 0;
+        if (prev_id) {
+            const int lt = PyObject_RichCompareBool(prev_id, id, Py_LT);
+            same = lt == 0 ? PyObject_RichCompareBool(prev_id, id, Py_EQ) : 0;
+            if (lt < 0 || same < 0) {
+                Py_DECREF(id);
+                Py_DECREF(start);
+                goto done;
+            }
+            if (!lt && !same) sorted_input = 0;
+            if (same) {
+                const int le = PyObject_RichCompareBool(prev_start, start, Py_LE);
+                if (le < 0) {
+                    Py_DECREF(id);
+                    Py_DECREF(start);
+                    goto done;
+                }
+                if (!le) sorted_input = 0;
+            }
+        }
+        if (!same) {  /* a new contig */
+            cur = PyList_New(0);
+            if (!cur || PyList_Append(contigs, cur) < 0) {
+                Py_XDECREF(cur);
+                Py_DECREF(id);
+                Py_DECREF(start);
+                goto done;
+            }
+            Py_DECREF(cur);  /* (the list of contigs holds it) */
+        }
+        if (PyList_Append(cur, g) < 0) {
+            Py_DECREF(id);
+            Py_DECREF(start);
+            goto done;
+        }
+        Py_XDECREF(prev_id);
+        Py_XDECREF(prev_start);
+        prev_id = id;
+        prev_start = start;
+        /* the gene's domains by start, in place */
+        PyObject *prot = PyObject_GetAttr(g, s_protein);
+        PyObject *doms = prot ? PyObject_GetAttr(prot, s_domains) : NULL;
+        Py_XDECREF(prot);
+        if (!doms) goto done;
+        if (!PyList_CheckExact(doms)) {  /* (the reference calls .sort on whatever it is: leave that to Python) */
+            Py_DECREF(doms);
+            sorted_input = 0;
+            break;
+        }
+        int dom_sorted = 1;
+        PyObject *ps = NULL;
+        for (Py_ssize_t j = 0; j < PyList_GET_SIZE(doms) && dom_sorted > 0; ++j) {
+            PyObject *ds = PyObject_GetAttr(PyList_GET_ITEM(doms, j), s_start);
+            if (!ds) {
+                dom_sorted = -1;
+                break;
+            }
+            if (ps) {
+                const int le = PyObject_RichCompareBool(ps, ds, Py_LE);
+                dom_sorted = le < 0 ? -1 : le;
+            }
+            Py_XDECREF(ps);
+            ps = ds;
+        }
+        Py_XDECREF(ps);
+        if (dom_sorted < 0) {
+            Py_DECREF(doms);
+            goto done;
+        }
+        if (!dom_sorted) {
+            PyObject *meth = PyObject_GetAttr(doms, s_sort), *kw = PyDict_New(), *empty = PyTuple_New(0), *r = NULL;
+            if (meth && kw && empty && PyDict_SetItem(kw, s_key, start_key) == 0) r = PyObject_Call(meth, empty, kw);
+            Py_XDECREF(meth);
+            Py_XDECREF(kw);
+            Py_XDECREF(empty);
+            if (!r) {
+                Py_DECREF(doms);
+                goto done;
+            }
+            Py_DECREF(r);
+        }
+        Py_DECREF(doms);
+    }
+    if (!sorted_input) {
+        result = Py_None;
+        Py_INCREF(result);
+    } else {
+        result = PyTuple_Pack(2, out_genes, contigs);
+    }
+done:
+    Py_XDECREF(prev_id);
+    Py_XDECREF(prev_start);
+    Py_XDECREF(out_genes);
+    Py_XDECREF(contigs);
+    Py_DECREF(seq);
+    return result;
+}
+
 static PyMethodDef methods[] = {
+    {"sort_group", sort_group, METH_VARARGS, "sort_group(genes, start_key) -> (genes, contigs) when the input is in (source.id, start) order, else None"},
     {"pack_protein", pack_protein, METH_VARARGS, "pack_protein(contigs, attr_index) -> (item_ptr, attr_ptr, attr_id) as bytes"},
     {"annotate_all", annotate_all, METH_VARARGS, "annotate_all(genes, probs, w1, gene_cls, prot_cls, dom_cls) -> list or None"},
     {NULL, NULL, 0, NULL}};
@@ -316,6 +445,12 @@ PyMODINIT_FUNC PyInit__objpath(void)
     s_qualifiers = PyUnicode_InternFromString("qualifiers");
     s__probability = PyUnicode_InternFromString("_probability");
     s_copy = PyUnicode_InternFromString("copy");
+    s_source = PyUnicode_InternFromString("source");
+    s_id = PyUnicode_InternFromString("id");
+    s_start = PyUnicode_InternFromString("start");
+    s_sort = PyUnicode_InternFromString("sort");
+    s_key = PyUnicode_InternFromString("key");
+    if (!s_source || !s_id || !s_start || !s_sort || !s_key) return NULL;
     if (!s_protein || !s_domains || !s_name || !s_probability || !s_cluster_weight || !s_qualifiers || !s__probability || !s_copy)
         return NULL;
     return PyModule_Create(&moduledef);

@@ -155,8 +155,9 @@ def object_level(model_dir, n_contigs=250, per=200, seed=0):
         breakdown = object_breakdown(crf, genes)
     return {"genes": len(genes), "ms": dt * 1e3, "genes_per_s": len(genes) / dt, "breakdown_us_per_gene": breakdown,
             "note": "ClusterCRF.predict_probabilities: sort + pack Gene objects + one-shot ABI + new Gene/Domain objects; breakdown = "
-                    "the same steps timed one by one (sort: sorted() by (source.id, start) + every gene's domain list; group: "
-                    "itertools.groupby into contigs; pack: objects -> CSR (csrc/objpath.c); abi: the batch driver call, host buffers "
+                    "the same steps timed one by one (sort: the order check / sort by (source.id, start) + every gene's domain list -- one "
+                    "native pass that also groups when the input is in order, as annotation pipelines emit it; group: "
+                    "itertools.groupby into contigs otherwise; pack: objects -> CSR (csrc/objpath.c); abi: the batch driver call, host buffers "
                     "in and out; clone: new Gene / Protein / Domain objects with probability and cluster weight)"}
 
 
@@ -169,14 +170,23 @@ def object_breakdown(crf, genes):
 
     from . import packing
 
+    from ._objpath_loader import module as _objpath
+
     n = max(len(genes), 1)
+    native = _objpath()
     t = [time.perf_counter()]
-    gs = sorted(genes, key=operator.attrgetter("source.id", "start"))
-    for g in gs:
-        g.protein.domains.sort(key=operator.attrgetter("start"))
-    t.append(time.perf_counter())
-    contigs = [list(g) for _, g in itertools.groupby(gs, key=operator.attrgetter("source.id"))]
-    t.append(time.perf_counter())
+    got = native.sort_group(genes, operator.attrgetter("start")) if native is not None else None
+    if got is not None:  # (input already in order: one native pass checks, sorts the domain lists that need it, groups)
+        gs, contigs = got
+        t.append(time.perf_counter())
+        t.append(time.perf_counter())
+    else:
+        gs = sorted(genes, key=operator.attrgetter("source.id", "start"))
+        for g in gs:
+            g.protein.domains.sort(key=operator.attrgetter("start"))
+        t.append(time.perf_counter())
+        contigs = [list(g) for _, g in itertools.groupby(gs, key=operator.attrgetter("source.id"))]
+        t.append(time.perf_counter())
     batch = packing.pack_contigs(contigs, crf.model._attr_index, crf.feature_type)
     t.append(time.perf_counter())
     label = crf.model.native.label_id("1")

@@ -740,3 +740,45 @@ def test_committed_profiles_parse():
     for f in files:
         with open(f) as fh:
             json.load(fh)
+
+
+def test_objpath_sort_group_equals_the_python_statements():
+    """csrc/objpath.c sort_group against gecco/crf/__init__.py:199-206 as Python states it: an input already in
+    (source.id, start) order comes back as it is, grouped, with unsorted domain lists sorted in place; any other input
+    returns None (the caller then runs the Python statements)."""
+    import itertools
+    import operator
+
+    from gecco_amd import _objpath_loader
+    from gecco_amd.model import Domain, Gene, Protein, Source, Strand
+
+    native = _objpath_loader.module()
+    assert native is not None, "gecco_amd/csrc/objpath.c did not build"
+
+    def make(order):
+        srcs = {k: Source(k) for k in "abc"}
+        out = []
+        for sid, start, dstarts in order:
+            doms = [Domain(f"PF{d:05d}", d, d + 5, "Pfam", 1e-10, 1e-12) for d in dstarts]
+            out.append(Gene(srcs[sid], start, start + 90, Strand.Coding, Protein(f"{sid}_{start}", None, doms)))
+        return out
+
+    ordered = [("a", 1, [3, 1, 2]), ("a", 1, []), ("a", 7, [5]), ("b", 2, [9, 9, 4]), ("c", 0, [1, 2])]
+    genes = make(ordered)
+    ref = make(ordered)
+    ref_sorted = sorted(ref, key=operator.attrgetter("source.id", "start"))
+    for g in ref_sorted:
+        g.protein.domains.sort(key=operator.attrgetter("start"))
+    ref_contigs = [list(g) for _, g in itertools.groupby(ref_sorted, key=operator.attrgetter("source.id"))]
+    got = native.sort_group(genes, operator.attrgetter("start"))
+    assert got is not None
+    out_genes, contigs = got
+    assert [id(g) for g in out_genes] == [id(g) for g in genes]  # (stable: the input order)
+    assert [[g.protein.id for g in c] for c in contigs] == [[g.protein.id for g in c] for c in ref_contigs]
+    assert [[d.start for d in g.protein.domains] for g in out_genes] == [[d.start for d in g.protein.domains] for g in ref_sorted]
+    # unsorted inputs: contig ids out of order, starts out of order inside a contig, a generator
+    assert native.sort_group(make([("b", 1, []), ("a", 2, [])]), operator.attrgetter("start")) is None
+    assert native.sort_group(make([("a", 5, []), ("a", 2, [])]), operator.attrgetter("start")) is None
+    got = native.sort_group(iter(make(ordered)), operator.attrgetter("start"))
+    assert got is not None and len(got[0]) == 5 and len(got[1]) == 3
+    assert native.sort_group([], operator.attrgetter("start")) == ([], [])
