@@ -663,6 +663,96 @@ __global__ void __launch_bounds__(kGT) gl_chunk_rows(GenArgs a) {
     if (!MAXPLUS && j == 0) a.chEx[static_cast<size_t>(ci) * L + i] = ex;
 }
 
+// The same transfer matrices for 9 to 32 labels on the fp64 matrix cores.  The L rows of a chunk's matrix are L forward
+// recursions from the unit vectors: sixteen of them at once are the columns of X^T in  X'^T = diag(E_t) M^T X^T  -- the step
+// of gl_windowed_mfma with "sixteen windows" replaced by "sixteen start labels of one chunk": result register r of a lane IS
+// its B operand of K-slice r in the next step, the slices of M^T are per-lane constants, nothing crosses lanes between steps.
+// One wave per (chunk, group of sixteen rows); ceil(L / 16) * ceil(L / 4) MFMAs per gene and wave against L broadcast reads
+// from LDS per lane and step in the lane-group kernel above.  A column's power-of-two rescaling (maximum over its labels:
+// the lane's registers, then the four lanes that share the column) is taken every `period` steps (1, or 4 when four
+// un-normalised steps cannot leave the range: 4 max|trans| < 600).  Summation order differs from gl_chunk_rows: 1e-12, not bits.
+template <int TILES, int NS>
+__global__ void __launch_bounds__(kGT) gl_chunk_rows_mfma(GenArgs a, const int period) {
+    const int L = a.L;
+    const int lane = threadIdx.x & 63, w = lane & 15, g = lane >> 4;
+    const int groups = (L + 15) / 16;
+    const long long wv = static_cast<long long>(blockIdx.x) * (kGT / 64) + (threadIdx.x >> 6);
+    if (wv >= static_cast<long long>(a.n_chunks) * groups) return;
+    const int ci = int(wv / groups), cg = int(wv % groups);
+    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int cfirst = a.contig_ptr[a.ch_contig[ci]];
+    const int col = 16 * cg + w;  // the start label of this lane's column
+    double Af[TILES][NS];         // slices of M^T: row = output label, column = summed label
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            const int row = 16 * t + w, k = 4 * sidx + g;
+            Af[t][sidx] = (row < L && k < L) ? a.exp_trans[k * L + row] : 0.0;
+        }
+    auto label_of = [&](int t, int r) { return 16 * t + 4 * r + g; };
+    gl_v4d D[TILES], E[TILES], En[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            D[t][r] = (label_of(t, r) == col && col < L) ? 1.0 : 0.0;
+            E[t][r] = label_of(t, r) < L ? a.E[static_cast<size_t>(g0) * L + label_of(t, r)] : 0.0;
+        }
+    int ex = 0;
+    for (int gi = g0; gi < g1; ++gi) {
+        // (the next gene's emissions are requested before this gene's products)
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) En[t][r] = (gi + 1 < g1 && label_of(t, r) < L) ? a.E[static_cast<size_t>(gi + 1) * L + label_of(t, r)] : 0.0;
+        if (gi == cfirst) {  // every row: the contig's first gene forgets what entered
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) D[t] = col < L ? E[t] : gl_v4d{0.0, 0.0, 0.0, 0.0};
+        } else {
+            gl_v4d N[TILES];
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                N[t] = gl_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int sidx = 0; sidx < NS; ++sidx) N[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[t][sidx], D[sidx / 4][sidx % 4], N[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) D[t][r] = N[t][r] * E[t][r];
+        }
+        if (period <= 1 || ((gi - g0) % period) == period - 1 || gi + 1 == g1) {  // exact power-of-two scaling of the column, exponent kept
+            double mx = 0.0;
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmax(mx, D[t][r]);
+            mx = fmax(mx, __shfl_xor(mx, 16));
+            mx = fmax(mx, __shfl_xor(mx, 32));
+            if (mx > 0.0) {
+                int e2;
+                (void)frexp(mx, &e2);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) D[t][r] = ldexp(D[t][r], -e2);
+                ex += e2;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) E[t] = En[t];
+    }
+    if (col < L) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (label_of(t, r) < L) a.chM[(static_cast<size_t>(ci) * L + col) * L + label_of(t, r)] = D[t][r];
+        if (g == 0) a.chEx[static_cast<size_t>(ci) * L + col] = ex;
+    }
+}
+
 // The walks over the chunks of a contig: forwards, the vector entering every chunk (normalised alpha / delta of the gene
 // before it); backwards (marginals), beta of the last gene of every chunk up to a factor.  One group of lanes per contig
 // and direction (blockIdx.y), n / chunk dependent steps.  A step is a few dozen instructions; what it waited for in
@@ -995,11 +1085,30 @@ __global__ void __launch_bounds__(kGT) gl_chunk_backtrack(GenArgs a) {
 template <int LP>
 hipError_t launch_chunked(int what, const GenArgs &a, hipStream_t stream) {
     constexpr int G = kGT / LP;
+    // GECCO_CRF_GENERAL_ROWS=groups: the lane-group kernel for every label count (A/B runs, tests)
+    static const bool rows_groups = [] {
+        const char *env = std::getenv("GECCO_CRF_GENERAL_ROWS");
+        return env && env[0] == 'g';
+    }();
+    const int rows_period = a.rows_rescale_period;
     auto blocks = [](long long items, int per) { return dim3(unsigned((items + per - 1) / per)); };
     const long long rows = static_cast<long long>(a.n_chunks) * a.L;
     if (a.n_chunks <= 0) return hipSuccess;
     if (what == 2) {
-        hipLaunchKernelGGL((gl_chunk_rows<LP, false>), blocks(rows, G), dim3(kGT), 0, stream, a);
+        if (LP >= 16 && a.L > 8 && !rows_groups) {  // 9 to 32 labels: sixteen rows of a chunk's transfer matrix per wave on the matrix cores
+            const int groups = (a.L + 15) / 16, ns = (a.L + 3) / 4;
+            const dim3 grid = blocks(static_cast<long long>(a.n_chunks) * groups, kGT / 64);
+            switch (ns) {
+            case 3: hipLaunchKernelGGL((gl_chunk_rows_mfma<1, 3>), grid, dim3(kGT), 0, stream, a, rows_period); break;
+            case 4: hipLaunchKernelGGL((gl_chunk_rows_mfma<1, 4>), grid, dim3(kGT), 0, stream, a, rows_period); break;
+            case 5: hipLaunchKernelGGL((gl_chunk_rows_mfma<2, 5>), grid, dim3(kGT), 0, stream, a, rows_period); break;
+            case 6: hipLaunchKernelGGL((gl_chunk_rows_mfma<2, 6>), grid, dim3(kGT), 0, stream, a, rows_period); break;
+            case 7: hipLaunchKernelGGL((gl_chunk_rows_mfma<2, 7>), grid, dim3(kGT), 0, stream, a, rows_period); break;
+            default: hipLaunchKernelGGL((gl_chunk_rows_mfma<2, 8>), grid, dim3(kGT), 0, stream, a, rows_period); break;
+            }
+        } else {
+            hipLaunchKernelGGL((gl_chunk_rows<LP, false>), blocks(rows, G), dim3(kGT), 0, stream, a);
+        }
         hipLaunchKernelGGL((gl_chunk_vecs<LP, false>), dim3(blocks(a.n_contigs, G).x, 2), dim3(kGT), 0, stream, a);
         hipLaunchKernelGGL(gl_chunk_fwd<LP>, blocks(a.n_chunks, G), dim3(kGT), 0, stream, a);
         hipLaunchKernelGGL(gl_chunk_bwd<LP>, blocks(a.n_chunks, G), dim3(kGT), 0, stream, a);

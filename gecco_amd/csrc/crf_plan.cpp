@@ -508,6 +508,7 @@ int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, 
     a.A = m.A;
     a.n_genes = p.n_genes;
     a.n_contigs = p.n_contigs;
+    a.rows_rescale_period = 4.0 * p.tables_model->tmax_abs < 600.0 ? 4 : 1;
     a.state = reinterpret_cast<double *>(w);
     a.E = reinterpret_cast<double *>(w + b_vec);
     a.alpha = reinterpret_cast<double *>(w + 2 * b_vec);
