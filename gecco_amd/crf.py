@@ -219,6 +219,8 @@ def _annotate_all(genes: List[Any], probs: List[float], w1: Dict[str, float]) ->
     native = module()  # csrc/objpath.c: the loop below against the CPython C API (tp_alloc + PyDict_Copy per object)
     if native is not None:
         return native.annotate_all(genes, probs, w1, gene_cls, prot_cls, dom_cls)
+    if not isinstance(probs, list):
+        probs = np.asarray(probs).tolist()
     wget = w1.get  # domain name -> weight of its ('name', '1') state feature
     new = object.__new__
     out = []
@@ -292,6 +294,7 @@ class ClusterCRF(object):
         self._options = st.get("_options", {"algorithm": self.algorithm})
         self._record = record
         self.devices = _default_devices()
+        self.reference_bits: Optional[bool] = None  # None: on when the mode covers the model (_reference_bits_now)
         crf_state = st["model"].state if st.get("model") is not None else None
         if crf_state is None:
             self.model = None
@@ -345,6 +348,7 @@ class ClusterCRF(object):
         self._options = {"algorithm": algorithm, **kwargs}
         self._record = None
         self.devices = _default_devices()
+        self.reference_bits: Optional[bool] = None  # None: on when the mode covers the model (_reference_bits_now)
 
     # ------------------------------------------------------------------ inference
     def predict_probabilities(self, genes: Iterable[Any], *, pad: bool = True,
@@ -367,15 +371,20 @@ class ClusterCRF(object):
 
         # :199-206 -- sort (mutating the caller's domain lists, as the reference does), group
         contigs: Optional[List[List[Any]]] = None
+        batch: Optional[packing.PackedBatch] = None
         if self.feature_type == "protein":
             from ._objpath_loader import module as _objpath
 
-            native = _objpath()  # csrc/objpath.c: one pass that checks the order, sorts what is not, and groups
+            # csrc/objpath.c: ONE pass that checks the order, sorts the domain lists that need it, groups and packs the
+            # features (:209-214) -- every object is visited once, while it is in cache
+            native = _objpath()
             if native is not None:
                 genes = genes if isinstance(genes, (list, tuple)) else list(genes)
-                got = native.sort_group(genes, operator.attrgetter("start"))
+                got = native.sort_group(genes, operator.attrgetter("start"), self.model._attr_index)
                 if got is not None:
-                    genes, contigs = got
+                    genes, contigs, ip, ap, at = got
+                    batch = packing.PackedBatch(np.frombuffer(ip, dtype=np.int64), np.frombuffer(ap, dtype=np.int64),
+                                                np.frombuffer(at, dtype=np.int32))
         if contigs is None:
             genes = sorted(genes, key=operator.attrgetter("source.id", "start"))
             for gene in genes:
@@ -384,29 +393,30 @@ class ClusterCRF(object):
 
         # :209-236 -- features -> CSR items; decide padding / skipping per contig
         W, step = self.window_size, self.window_step
-        batch = packing.pack_contigs(contigs, self.model._attr_index, self.feature_type)
+        if batch is None:
+            batch = packing.pack_contigs(contigs, self.model._attr_index, self.feature_type)
         scored = np.ones(len(contigs), dtype=bool)
         total = 0
-        for ci, contig in enumerate(contigs):
-            n_items = int(batch.item_ptr[ci + 1] - batch.item_ptr[ci])
-            if n_items < W:
-                if pad:
-                    unit = self.feature_type if W - n_items == 1 else f"{self.feature_type}s"
-                    warnings.warn(
-                        f"Contig {contig[0].source.id!r} does not contain enough"
-                        f" {self.feature_type}s ({len(contig)}) for sliding window"
-                        f" of size {W}, padding with"
-                        f" {W - n_items} {unit}"
-                    )
-                else:
-                    warnings.warn(
-                        f"Contig {contig[0].source.id!r} does not contain enough"
-                        f" {self.feature_type}s ({len(contig)}) for sliding window"
-                        f" of size {W}"
-                    )
-                    scored[ci] = False
-                    continue
-            total += max(n_items, W) - W + 1  # :239
+        items_per_contig = np.diff(batch.item_ptr)
+        for ci in np.flatnonzero(items_per_contig < W).tolist():  # (the warnings, in contig order)
+            contig = contigs[ci]
+            n_items = int(items_per_contig[ci])
+            if pad:
+                unit = self.feature_type if W - n_items == 1 else f"{self.feature_type}s"
+                warnings.warn(
+                    f"Contig {contig[0].source.id!r} does not contain enough"
+                    f" {self.feature_type}s ({len(contig)}) for sliding window"
+                    f" of size {W}, padding with"
+                    f" {W - n_items} {unit}"
+                )
+            else:
+                warnings.warn(
+                    f"Contig {contig[0].source.id!r} does not contain enough"
+                    f" {self.feature_type}s ({len(contig)}) for sliding window"
+                    f" of size {W}"
+                )
+                scored[ci] = False
+        total = int((np.maximum(items_per_contig[scored], W) - W + 1).sum())  # :239
         _progress(0, total)
 
         # :244-258 -- windowed marginals of label '1', batched over contigs
@@ -429,13 +439,19 @@ class ClusterCRF(object):
         gc_was_enabled = gc.isenabled()
         gc.disable()
         try:
-            self._annotate_contigs(contigs, scored, batch, p_items, weights, w1, predicted)
+            self._annotate_contigs(contigs, scored, batch, p_items, weights, w1, predicted,
+                                   genes if isinstance(genes, list) else None)
         finally:
             if gc_was_enabled:
                 gc.enable()
         return predicted
 
-    def _annotate_contigs(self, contigs, scored, batch, p_items, weights, w1, predicted) -> None:
+    def _annotate_contigs(self, contigs, scored, batch, p_items, weights, w1, predicted, genes=None) -> None:
+        if genes is not None and self.feature_type == "protein" and len(genes) == len(p_items) and bool(scored.all()):
+            fast = _annotate_all(genes, np.ascontiguousarray(p_items, dtype=np.float64), w1)  # one native pass over all contigs
+            if fast is not None:
+                predicted.extend(fast)
+                return
         for ci, contig in enumerate(contigs):
             if not scored[ci]:
                 predicted.extend(_annotate(gene, None, None, weights) for gene in contig)
@@ -500,11 +516,23 @@ class ClusterCRF(object):
         if ses is None or ses[0] != devices or ses[1].model is not native:
             ses = (devices, _native.Session(native, devices))
             self._ses = ses
-        # `reference_bits` (attribute, or GECCO_AMD_REFERENCE_BITS=1): CRFsuite's own operation order with a correctly rounded
-        # exp -- genes.tsv / features.tsv / clusters.tsv come out with the reference's bits (the reference's own acceptance
-        # test compares whole files, galaxy/gecco.xml:83-111) at about forty times the fast kernels' time
-        ses[1].set_reference_bits(bool(getattr(self, "reference_bits", False)) or os.environ.get("GECCO_AMD_REFERENCE_BITS") == "1")
+        ses[1].set_reference_bits(self._reference_bits_now())
         return ses[1]
+
+    def _reference_bits_now(self) -> bool:
+        """Whether this object's calls run in reference-bits mode (csrc/crf_exact.hip: CRFsuite's own operation order with a
+        correctly rounded exp, so that genes.tsv / features.tsv / clusters.tsv carry the reference's bits -- its acceptance test
+        compares whole files, /root/reference/galaxy/gecco.xml:83-111).  ``reference_bits`` True / False decides; None (the
+        default) means: ``GECCO_AMD_REFERENCE_BITS=0|1`` if set, else ON whenever the mode covers the model (2 labels, window
+        <= 32 items).  Every caller of this class is bound by its object or table handling (0.5 / 20 M genes/s), not by the
+        kernels, so the drop-in class answers with the reference's bits; the C ABI's default stays the fast kernels."""
+        want = getattr(self, "reference_bits", None)
+        if want is None:
+            env = os.environ.get("GECCO_AMD_REFERENCE_BITS")
+            if env in ("0", "1"):
+                want = env == "1"
+        covered = self.model is not None and self.model.native.num_labels == 2 and 1 <= int(self.window_size) <= 32
+        return covered if want is None else bool(want)
 
     def _score(self, batch: "packing.PackedBatch", W: int, step: int, label: int, pad: bool,
                progress: Callable[[int, int], None], total: int) -> np.ndarray:

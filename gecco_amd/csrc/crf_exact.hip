@@ -10,8 +10,8 @@
 // /root/reference/gecco/crf/__init__.py:244-258 -- with ONE substitution: libm's exp becomes the correctly rounded exp
 // (crf_exact_exp.hpp), which is what libm returns for all but ~0.07 % of arguments (glibc: 0.51 ulp).  exp(trans) comes from
 // the host's libm, as in the reference.  One lane per window start, alpha and the scale factors of a window in registers
-// (W <= 32), per-gene maximum by atomic maximum on the bit pattern (probabilities are non-negative: order-independent, exact).
-// Speed is not the point (about forty times the fast kernel's time); selected per session / plan (gecco_crf_session_set_reference_bits,
+// (W <= 32), per-gene maximum by atomic maximum on the bit pattern (probabilities are non-negative: order-independent, exact),
+// in LDS first.  Selected per session / plan (gecco_crf_session_set_reference_bits,
 // GECCO_CRF_REFERENCE_BITS=1).
 #include "crf_device.hpp"
 #include "crf_exact_exp.hpp"
@@ -51,80 +51,96 @@ struct RefArgs {
     double t00, t01, t10, t11; // exp(trans), host libm
 };
 
+// Round 5b: the per-gene maximum goes through LDS (one returnless ds_max_u64 per window position, conflict-free: lane i hits slot
+// i + t) and reaches memory once per slot of the tile -- 1.1 global atomics per gene instead of W; the exponentials of the tile's
+// slots (and the slot -> gene map) are staged in LDS once, padding items as (1, 1).  The arithmetic of a window is untouched.
 __global__ void __launch_bounds__(kRefT, 2) crf_windowed_reference_l2(const RefArgs A) {
-    const int q = blockIdx.x * kRefT + threadIdx.x;
-    if (q >= A.S) return;
-    if (!((A.start_bits[q >> 6] >> (q & 63)) & 1ull)) return;
-    int lo = 0, hi = A.K - 1;  // contig of this window: largest k with c_slot[k] <= q
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (A.c_slot[mid] <= q) lo = mid; else hi = mid - 1;
-    }
-    const int s0 = A.c_slot[lo], np = A.c_slot[lo + 1] - s0, n = A.c_n[lo], g0 = A.c_gene[lo];
-    const int pos = q - s0, lpad = (np - n) >> 1;  // delta // 2 empty items in front (crf/__init__.py:227)
+    __shared__ double2 Es[kRefT + kRefMaxW];
+    __shared__ unsigned long long best[kRefT + kRefMaxW];
+    __shared__ int gslot[kRefT + kRefMaxW];
     const int W = A.W;
-    auto gene_of = [&](int k) {
-        const int gl = pos + k - lpad;
-        return (gl >= 0 && gl < n) ? g0 + gl : -1;
-    };
-    auto exp_state = [&](int k) {
-        const int g = gene_of(k);
-        return g >= 0 ? A.E[g] : make_double2(1.0, 1.0);  // a padding item has no attribute: state 0, exp 1
-    };
-    double a0[kRefMaxW], a1[kRefMaxW], sc[kRefMaxW];
-    // ---- [EXT] crf1dc_alpha_score
-    {
-        const double2 e = exp_state(0);
-        double x0 = e.x, x1 = e.y;
-        const double sum = x0 + x1;
-        const double c = (sum != 0.) ? 1. / sum : 1.;
-        x0 *= c;
-        x1 *= c;
-        a0[0] = x0;
-        a1[0] = x1;
-        sc[0] = c;
+    const int q0 = blockIdx.x * kRefT, q = q0 + int(threadIdx.x);
+    for (int i = threadIdx.x; i < kRefT + W - 1; i += kRefT) {
+        const int s = q0 + i;
+        int g = -1;
+        if (s < A.S) {
+            int lo = 0, hi = A.K - 1;  // contig of this slot: largest k with c_slot[k] <= s
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (A.c_slot[mid] <= s) lo = mid; else hi = mid - 1;
+            }
+            const int s0 = A.c_slot[lo], np = A.c_slot[lo + 1] - s0, n = A.c_n[lo];
+            const int gl = s - s0 - ((np - n) >> 1);  // delta // 2 empty items in front (crf/__init__.py:227)
+            if (gl >= 0 && gl < n) g = A.c_gene[lo] + gl;
+        }
+        gslot[i] = g;
+        Es[i] = g >= 0 ? A.E[g] : make_double2(1.0, 1.0);  // a padding item has no attribute: state 0, exp 1
+        best[i] = 0ull;
     }
-#pragma unroll
-    for (int t = 1; t < kRefMaxW; ++t) {
-        if (t < W) {
-            const double2 e = exp_state(t);
-            const double p0 = a0[t - 1], p1 = a1[t - 1];
-            double x0 = p0 * A.t00, x1 = p0 * A.t01;  // cur[j] = 0 + prev[0] * trans[0][j]
-            x0 = x0 + p1 * A.t10;                     //        + prev[1] * trans[1][j]
-            x1 = x1 + p1 * A.t11;
-            x0 *= e.x;
-            x1 *= e.y;
+    __syncthreads();
+    const bool mine = q < A.S && ((A.start_bits[q >> 6] >> (q & 63)) & 1ull);
+    if (mine) {
+        const int base = threadIdx.x;
+        double al[kRefMaxW], sc[kRefMaxW];  // alpha of the asked label, scale factors
+        double p0, p1;
+        // ---- [EXT] crf1dc_alpha_score
+        {
+            const double2 e = Es[base];
+            double x0 = e.x, x1 = e.y;
             const double sum = x0 + x1;
             const double c = (sum != 0.) ? 1. / sum : 1.;
             x0 *= c;
             x1 *= c;
-            a0[t] = x0;
-            a1[t] = x1;
-            sc[t] = c;
+            p0 = x0;
+            p1 = x1;
+            al[0] = A.label ? x1 : x0;
+            sc[0] = c;
+        }
+#pragma unroll
+        for (int t = 1; t < kRefMaxW; ++t) {
+            if (t < W) {
+                const double2 e = Es[base + t];
+                double x0 = p0 * A.t00, x1 = p0 * A.t01;  // cur[j] = 0 + prev[0] * trans[0][j]
+                x0 = x0 + p1 * A.t10;                     //        + prev[1] * trans[1][j]
+                x1 = x1 + p1 * A.t11;
+                x0 *= e.x;
+                x1 *= e.y;
+                const double sum = x0 + x1;
+                const double c = (sum != 0.) ? 1. / sum : 1.;
+                x0 *= c;
+                x1 *= c;
+                p0 = x0;
+                p1 = x1;
+                al[t] = A.label ? x1 : x0;
+                sc[t] = c;
+            }
+        }
+        // ---- [EXT] crf1dc_beta_score + crf1dc_marginal_point, back to front
+        double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+        for (int t = kRefMaxW - 1; t >= 0; --t) {
+            if (t < W) {
+                if (t == W - 1) {
+                    b0 = b1 = sc[t];
+                } else {
+                    const double2 e = Es[base + t + 1];
+                    const double r0 = b0 * e.x, r1 = b1 * e.y;  // row[j] = next[j] * exp_state[t + 1][j]
+                    double y0 = A.t00 * r0, y1 = A.t10 * r0;    // s = 0 + trans[i][0] * row[0]
+                    y0 = y0 + A.t01 * r1;                       //       + trans[i][1] * row[1]
+                    y1 = y1 + A.t11 * r1;
+                    b0 = y0 * sc[t];
+                    b1 = y1 * sc[t];
+                }
+                const double m = (al[t] * (A.label ? b1 : b0)) / sc[t];  // alpha * beta / scale
+                atomicMax(&best[base + t], static_cast<unsigned long long>(__double_as_longlong(m)));
+            }
         }
     }
-    // ---- [EXT] crf1dc_beta_score + crf1dc_marginal_point, back to front
-    double b0 = 0.0, b1 = 0.0;
-#pragma unroll
-    for (int t = kRefMaxW - 1; t >= 0; --t) {
-        if (t < W) {
-            if (t == W - 1) {
-                b0 = b1 = sc[t];
-            } else {
-                const double2 e = exp_state(t + 1);
-                const double r0 = b0 * e.x, r1 = b1 * e.y;  // row[j] = next[j] * exp_state[t + 1][j]
-                double y0 = A.t00 * r0, y1 = A.t10 * r0;    // s = 0 + trans[i][0] * row[0]
-                y0 = y0 + A.t01 * r1;                       //       + trans[i][1] * row[1]
-                y1 = y1 + A.t11 * r1;
-                b0 = y0 * sc[t];
-                b1 = y1 * sc[t];
-            }
-            const int g = gene_of(t);
-            if (g >= 0) {
-                const double m = (A.label ? a1[t] * b1 : a0[t] * b0) / sc[t];  // alpha * beta / scale
-                atomicMax(reinterpret_cast<unsigned long long *>(A.p_out + g), static_cast<unsigned long long>(__double_as_longlong(m)));
-            }
-        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kRefT + W - 1; i += kRefT) {
+        const int g = gslot[i];
+        const unsigned long long v = best[i];
+        if (g >= 0 && v != 0ull) atomicMax(reinterpret_cast<unsigned long long *>(A.p_out + g), v);
     }
 }
 

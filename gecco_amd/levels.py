@@ -156,8 +156,8 @@ def object_level(model_dir, n_contigs=250, per=200, seed=0):
     return {"genes": len(genes), "ms": dt * 1e3, "genes_per_s": len(genes) / dt, "breakdown_us_per_gene": breakdown,
             "note": "ClusterCRF.predict_probabilities: sort + pack Gene objects + one-shot ABI + new Gene/Domain objects; breakdown = "
                     "the same steps timed one by one (sort: the order check / sort by (source.id, start) + every gene's domain list -- one "
-                    "native pass that also groups when the input is in order, as annotation pipelines emit it; group: "
-                    "itertools.groupby into contigs otherwise; pack: objects -> CSR (csrc/objpath.c); abi: the batch driver call, host buffers "
+                    "native pass that also groups AND packs when the input is in order, as annotation pipelines emit it (group and "
+                    "pack are then 0); group: itertools.groupby into contigs otherwise; pack: objects -> CSR (csrc/objpath.c); abi: the batch driver call, host buffers "
                     "in and out; clone: new Gene / Protein / Domain objects with probability and cluster weight)"}
 
 
@@ -175,11 +175,11 @@ def object_breakdown(crf, genes):
     n = max(len(genes), 1)
     native = _objpath()
     t = [time.perf_counter()]
-    got = native.sort_group(genes, operator.attrgetter("start")) if native is not None else None
-    if got is not None:  # (input already in order: one native pass checks, sorts the domain lists that need it, groups)
-        gs, contigs = got
-        t.append(time.perf_counter())
-        t.append(time.perf_counter())
+    got = native.sort_group(genes, operator.attrgetter("start"), crf.model._attr_index) if native is not None else None
+    if got is not None:  # (input already in order: ONE native pass checks, sorts the domain lists that need it, groups and packs)
+        gs, contigs, ip, ap, at = got
+        batch = packing.PackedBatch(np.frombuffer(ip, dtype=np.int64), np.frombuffer(ap, dtype=np.int64), np.frombuffer(at, dtype=np.int32))
+        t += [time.perf_counter()] * 3
     else:
         gs = sorted(genes, key=operator.attrgetter("source.id", "start"))
         for g in gs:
@@ -187,8 +187,8 @@ def object_breakdown(crf, genes):
         t.append(time.perf_counter())
         contigs = [list(g) for _, g in itertools.groupby(gs, key=operator.attrgetter("source.id"))]
         t.append(time.perf_counter())
-    batch = packing.pack_contigs(contigs, crf.model._attr_index, crf.feature_type)
-    t.append(time.perf_counter())
+        batch = packing.pack_contigs(contigs, crf.model._attr_index, crf.feature_type)
+        t.append(time.perf_counter())
     label = crf.model.native.label_id("1")
     p = crf._score(batch, crf.window_size, crf.window_step, label, True, lambda a, b: None, 0)
     t.append(time.perf_counter())
@@ -196,12 +196,13 @@ def object_breakdown(crf, genes):
     was = gc.isenabled()
     gc.disable()
     try:
-        crf._annotate_contigs(contigs, np.ones(len(contigs), dtype=bool), batch, p, crf.model.state_features_, crf.model.cluster_weights_, out)
+        crf._annotate_contigs(contigs, np.ones(len(contigs), dtype=bool), batch, p, crf.model.state_features_, crf.model.cluster_weights_, out,
+                              gs if isinstance(gs, list) else None)
     finally:
         if was:
             gc.enable()
     t.append(time.perf_counter())
-    names = ("sort", "group", "pack", "abi", "clone")
+    names = ("sort", "group", "pack", "abi", "clone")  # (one native pass: all of sort + group + pack is under "sort")
     return {k: (b - a) * 1e6 / n for k, a, b in zip(names, t[:-1], t[1:])}
 
 
@@ -270,7 +271,7 @@ def golden_table_identity(golden_dir, out_dir=None, reference_bits=False):
             warnings.simplefilter("ignore")
             predict.main(["--genes", os.path.join(golden_dir, "BGC0001866.genes.tsv"), "--features",
                           os.path.join(golden_dir, "BGC0001866.features.tsv"), "--model", golden_dir, "-o", tmp]
-                         + (["--reference-bits"] if reference_bits else []))
+                         + (["--reference-bits"] if reference_bits else ["--fast-kernels"]))
         for table in ("genes", "features", "clusters"):
             got, ref = rows(os.path.join(tmp, f"BGC0001866.{table}.tsv")), rows(os.path.join(golden_dir, f"BGC0001866.{table}.tsv"))
             cols = _CLUSTER_COLUMNS if table == "clusters" else tuple(ref[0].keys())

@@ -219,15 +219,17 @@ def main(argv: Optional[List[str]] = None) -> int:
                     help="e-value cutoff for protein domains to be included (gecco predict -e)")
     ap.add_argument("-p", "--p-filter", type=float, default=1e-9,
                     help="p-value cutoff for protein domains to be included (gecco predict -p, default 1e-9)")
-    ap.add_argument("--reference-bits", action="store_true",
+    ap.add_argument("--reference-bits", dest="reference_bits", action="store_true", default=None,
                     help="probabilities in CRFsuite's own operation order with a correctly rounded exp: the reference's output "
-                         "files bit for bit (about forty times the fast kernels' time)")
+                         "files bit for bit (the default whenever the model has 2 labels and a window of <= 32 items)")
+    ap.add_argument("--fast-kernels", dest="reference_bits", action="store_false",
+                    help="the reorganised arithmetic of the fast kernels: probabilities within a few ulps of the reference's")
     ap.add_argument("--composition-domains", default=None,
                     help="file with one domain accession per line (the type classifier's domains.tsv): also write "
                          "<base>.compositions.npy, the classifier's input matrix")
     args = ap.parse_args(argv)
     crf = ClusterCRF.trained(args.model)
-    crf.reference_bits = bool(args.reference_bits)
+    crf.reference_bits = args.reference_bits  # None: ClusterCRF's default
     genes_t = tables.GeneTable.load(args.genes)
     feats_t = filter_features(tables.FeatureTable.load(args.features), args.e_filter, args.p_filter)
     comp_domains = None

@@ -136,3 +136,39 @@ def test_cli_tables_are_the_reference_files_in_reference_bits_mode(tmp_path, cap
         assert t["exact_cells_differing"] == 0
         assert t["float_cells"] == n_float and t["float_cells_differing"] == 0
     assert res["clusters"]["formula_cells_differing"] == 0
+
+
+def test_the_drop_in_class_answers_with_the_reference_bits_by_default(tmp_path, monkeypatch):
+    """`ClusterCRF.reference_bits` None (the default): on whenever the mode covers the model -- GECCO's own model: yes; the
+    CLI without a flag writes the reference's files; `--fast-kernels`, `reference_bits = False` and GECCO_AMD_REFERENCE_BITS=0
+    turn it off; a window the mode does not cover falls back to the fast kernels instead of failing."""
+    import filecmp
+
+    from gecco_amd import predict
+    from gecco_amd.crf import ClusterCRF
+
+    monkeypatch.delenv("GECCO_AMD_REFERENCE_BITS", raising=False)
+    crf = ClusterCRF.trained(GOLDEN)
+    assert crf.reference_bits is None and crf._reference_bits_now()
+    _, cptr, gptr, attr, _, _ = golden_csr(crf.model._attr_index)
+    p_default = crf.predict_probabilities_csr(cptr, gptr, attr)
+    ses = crf._session()
+    ses.set_reference_bits(True)
+    _bits(p_default, ses.windowed_marginals(cptr, gptr, attr, 20))
+    crf.reference_bits = False
+    assert not crf._reference_bits_now()
+    p_fast = crf.predict_probabilities_csr(cptr, gptr, attr)
+    assert p_fast.tobytes() != p_default.tobytes() and np.max(np.abs(p_fast - p_default)) < 1e-14
+    crf.reference_bits = None
+    monkeypatch.setenv("GECCO_AMD_REFERENCE_BITS", "0")
+    assert not crf._reference_bits_now()
+    monkeypatch.delenv("GECCO_AMD_REFERENCE_BITS")
+    crf.window_size = 40  # (not covered: W <= 32)
+    assert not crf._reference_bits_now()
+    assert np.isfinite(crf.predict_probabilities_csr(cptr, gptr, attr)).all()
+    # the CLI without a flag: genes.tsv and features.tsv are the reference's files, byte for byte
+    rc = predict.main(["--genes", os.path.join(GOLDEN, "BGC0001866.genes.tsv"), "--features",
+                       os.path.join(GOLDEN, "BGC0001866.features.tsv"), "--model", GOLDEN, "-o", str(tmp_path)])
+    assert rc == 0
+    for table in ("genes", "features"):
+        assert filecmp.cmp(str(tmp_path / f"BGC0001866.{table}.tsv"), os.path.join(GOLDEN, f"BGC0001866.{table}.tsv"), shallow=False)

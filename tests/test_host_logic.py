@@ -782,3 +782,92 @@ def test_objpath_sort_group_equals_the_python_statements():
     got = native.sort_group(iter(make(ordered)), operator.attrgetter("start"))
     assert got is not None and len(got[0]) == 5 and len(got[1]) == 3
     assert native.sort_group([], operator.attrgetter("start")) == ([], [])
+
+
+def test_objpath_fused_pass_and_buffer_annotation_equal_the_separate_steps():
+    """sort_group(genes, key, attr_index) -- the pass that also packs -- returns pack_protein's arrays of the grouped contigs
+    (after the in-place domain sorts: feature order follows the SORTED domain list, duplicates and unknown names dropped; equal
+    source ids on different Source objects are one contig; objects with properties and slots go through getattr), and
+    annotate_all on a float64 buffer builds the objects annotate_all builds from a list of floats."""
+    import operator
+
+    import numpy as np
+
+    from gecco_amd import _objpath_loader, packing
+    from gecco_amd.model import Domain, Gene, Protein, Source, Strand
+
+    native = _objpath_loader.module()
+    assert native is not None
+    rng = np.random.default_rng(5)
+    names = [f"PF{k:05d}" for k in range(40)]
+    index = {nm: i for i, nm in enumerate(names[:30])}  # (the last ten names: unknown to the model)
+    genes = []
+    for c in range(6):
+        for i in range(int(rng.integers(1, 30))):
+            src = Source(f"contig_{c}")  # a fresh Source per gene: equal ids, different objects
+            k = int(rng.integers(0, 5))
+            doms = [Domain(names[int(a)], int(s), int(s) + 5, "Pfam", 1e-10, 1e-12)
+                    for a, s in zip(rng.integers(0, 40, size=k), rng.integers(0, 50, size=k))]
+            genes.append(Gene(src, 10 * i, 10 * i + 9, Strand.Coding, Protein(f"c{c}_{i}", None, doms)))
+    key = operator.attrgetter("start")
+    out_genes, contigs, ip, ap, at = native.sort_group(genes, key, index)
+    assert all(a is b for a, b in zip(out_genes, genes)) and len(contigs) == 6
+    for g in genes:
+        starts = [d.start for d in g.protein.domains]
+        assert starts == sorted(starts)
+    ip2, ap2, at2 = native.pack_protein(contigs, index)
+    assert (ip, ap, at) == (ip2, ap2, at2)
+    py = packing.pack_contigs.__wrapped__(contigs, index) if hasattr(packing.pack_contigs, "__wrapped__") else None
+    assert py is None or py.attr_id.tobytes() == at
+    # the same arrays as the Python statements of features.py:31-35
+    attr, aptr = [], [0]
+    for g in genes:
+        seen = []
+        for d in g.protein.domains:
+            if d.name not in seen:
+                seen.append(d.name)
+                if d.name in index:
+                    attr.append(index[d.name])
+        aptr.append(len(attr))
+    assert np.frombuffer(at, dtype=np.int32).tolist() == attr and np.frombuffer(ap, dtype=np.int64).tolist() == aptr
+    assert np.frombuffer(ip, dtype=np.int64).tolist() == np.cumsum([0] + [len(c) for c in contigs]).tolist()
+    assert native.sort_group([], key, index) == ([], [], np.zeros(1, np.int64).tobytes(), np.zeros(1, np.int64).tobytes(), b"")
+
+    # objects whose attributes are properties / slots: served through getattr, same result
+    class SlotSource:
+        __slots__ = ("_id",)
+
+        def __init__(self, i):
+            self._id = i
+
+        @property
+        def id(self):
+            return self._id
+
+    class PropGene:
+        def __init__(self, g):
+            self.__dict__["source"] = "shadowed"  # a data descriptor of the class wins over the instance dictionary
+            self._g = g
+
+        source = property(lambda self: SlotSource(self._g.source.id))
+        start = property(lambda self: self._g.start)
+        protein = property(lambda self: self._g.protein)
+
+    wrapped = [PropGene(g) for g in genes]
+    got = native.sort_group(wrapped, key, index)
+    assert got is not None and (got[2], got[3], got[4]) == (ip, ap, at) and [len(c) for c in got[1]] == [len(c) for c in contigs]
+
+    # annotate_all: list of floats == float64 buffer
+    p = rng.random(len(genes))
+    w1 = {nm: float(i) for i, nm in enumerate(names[:25])}
+    a = native.annotate_all(genes, p.tolist(), w1, Gene, Protein, Domain)
+    b = native.annotate_all(genes, p, w1, Gene, Protein, Domain)
+    assert a == b and all(x is not y for x, y in zip(a, genes))
+    assert [g._probability for g in b] == p.tolist() and all(type(g._probability) is float for g in b)
+    assert all(d.probability == g._probability and d.cluster_weight == w1.get(d.name) for g in b for d in g.protein.domains)
+    import pytest
+
+    with pytest.raises(ValueError):
+        native.annotate_all(genes, p[:-1], w1, Gene, Protein, Domain)
+    with pytest.raises(ValueError):
+        native.annotate_all(genes, p.astype(np.float32), w1, Gene, Protein, Domain)
