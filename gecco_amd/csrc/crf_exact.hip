@@ -10,8 +10,8 @@
 // /root/reference/gecco/crf/__init__.py:244-258 -- with ONE substitution: libm's exp becomes the correctly rounded exp
 // (crf_exact_exp.hpp), which is what libm returns for all but ~0.07 % of arguments (glibc: 0.51 ulp).  exp(trans) comes from
 // the host's libm, as in the reference.  One lane per window start, alpha and the scale factors of a window in registers
-// (W <= 32), per-gene maximum by atomic maximum on the bit pattern (probabilities are non-negative: order-independent, exact),
-// in LDS first.  Selected per session / plan (gecco_crf_session_set_reference_bits,
+// (W <= 32), per-gene maximum by maximum on the bit pattern (probabilities are non-negative: order-independent, exact) in LDS.
+// Selected per session / plan (gecco_crf_session_set_reference_bits,
 // GECCO_CRF_REFERENCE_BITS=1).
 #include "crf_device.hpp"
 #include "crf_exact_exp.hpp"
@@ -21,15 +21,12 @@ namespace {
 
 constexpr int kRefT = 256;
 constexpr int kRefMaxW = 32;
+constexpr int kRefOwnExpTiles = 32;  // up to here (~7 500 slots) the tiles exponentiate their own scores: one launch
 
 #pragma clang fp contract(off)
 
-// exp of the state scores of every gene: E[g] = (exp(s[g][0]), exp(s[g][1])), s summed attribute by attribute in CSR order
-// ([EXT] crf1dt_state_score: state[t][y] += w[a][y] * 1.0)
-__global__ void __launch_bounds__(kRefT) ref_exp_states(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
-                                                        const double2 *__restrict__ wtab01, int n_attrs, int n_genes, double2 *__restrict__ E) {
-    const int g = blockIdx.x * kRefT + threadIdx.x;
-    if (g >= n_genes) return;
+__device__ inline double2 exp_state_of(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
+                                       const double2 *__restrict__ wtab01, int n_attrs, int g) {
     double s0 = 0.0, s1 = 0.0;
     for (int k = gene_ptr[g]; k < gene_ptr[g + 1]; ++k) {
         const int a = attr_id[k];
@@ -39,31 +36,51 @@ __global__ void __launch_bounds__(kRefT) ref_exp_states(const int32_t *__restric
             s1 += w.y;
         }
     }
-    E[g] = make_double2(ddx::exp_correctly_rounded(s0), ddx::exp_correctly_rounded(s1));
+    return make_double2(ddx::exp_correctly_rounded(s0), ddx::exp_correctly_rounded(s1));
+}
+
+// exp of the state scores of every gene: E[g] = (exp(s[g][0]), exp(s[g][1])), s summed attribute by attribute in CSR order
+// ([EXT] crf1dt_state_score: state[t][y] += w[a][y] * 1.0)
+__global__ void __launch_bounds__(kRefT) ref_exp_states(const int32_t *__restrict__ gene_ptr, const int32_t *__restrict__ attr_id,
+                                                        const double2 *__restrict__ wtab01, int n_attrs, int n_genes, double2 *__restrict__ E) {
+    const int g = blockIdx.x * kRefT + threadIdx.x;
+    if (g >= n_genes) return;
+    E[g] = exp_state_of(gene_ptr, attr_id, wtab01, n_attrs, g);
 }
 
 struct RefArgs {
-    const double2 *E;          // [n_genes] exp of the state scores, label order
+    const double2 *E;          // [n_genes] exp of the state scores, label order (OWN_EXP: unused)
+    const int32_t *gene_ptr, *attr_id;  // OWN_EXP: the tiles exponentiate their own slots' scores
+    const double2 *wtab01;
+    int32_t n_attrs;
     const int32_t *c_slot, *c_gene, *c_n;
     const uint64_t *start_bits;
-    double *p_out;             // zeroed (genes no window covers keep 0.0), skipped contigs NaN
+    double *p_out;             // device or host memory; skipped contigs NaN (the caller's)
     int32_t K, S, W, label;
     double t00, t01, t10, t11; // exp(trans), host libm
 };
 
-// Round 5b: the per-gene maximum goes through LDS (one returnless ds_max_u64 per window position, conflict-free: lane i hits slot
-// i + t) and reaches memory once per slot of the tile -- 1.1 global atomics per gene instead of W; the exponentials of the tile's
-// slots (and the slot -> gene map) are staged in LDS once, padding items as (1, 1).  The arithmetic of a window is untouched.
+// A tile = 256 window starts; it OWNS the 256 - (W - 1) slots every one of whose windows starts inside it (the W - 1 starts in
+// front are recomputed by the tile before: 8 % more arithmetic at W = 20, and no tile ever needs another's result).  The per-gene
+// maximum goes through LDS (one returnless ds_max_u64 per window position, conflict-free: lane i hits slot i + t; probabilities
+// are non-negative, so the order of their bit patterns is theirs) and every gene is stored once, by its owner: no atomics on
+// memory, no zeroed array (a gene no window covers gets its 0.0 here: numpy.zeros, crf/__init__.py:251), and p may live in host
+// memory.  The exponentials of the tile's slots (and the slot -> gene map) are staged in LDS once, padding items as (1, 1).
+// OWN_EXP (a handful of tiles: one launch instead of two, the W - 1 front slots exponentiated twice).
+template <bool OWN_EXP>
 __global__ void __launch_bounds__(kRefT, 2) crf_windowed_reference_l2(const RefArgs A) {
     __shared__ double2 Es[kRefT + kRefMaxW];
     __shared__ unsigned long long best[kRefT + kRefMaxW];
     __shared__ int gslot[kRefT + kRefMaxW];
     const int W = A.W;
-    const int q0 = blockIdx.x * kRefT, q = q0 + int(threadIdx.x);
+    const int out = kRefT - (W - 1);                  // slots this tile owns
+    const int own0 = blockIdx.x * out;                // the first of them
+    const int q0 = own0 - (W - 1);                    // slot of lane 0's window start, and of LDS index 0
+    const int q = q0 + int(threadIdx.x);
     for (int i = threadIdx.x; i < kRefT + W - 1; i += kRefT) {
         const int s = q0 + i;
         int g = -1;
-        if (s < A.S) {
+        if (s >= 0 && s < A.S) {
             int lo = 0, hi = A.K - 1;  // contig of this slot: largest k with c_slot[k] <= s
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
@@ -74,11 +91,12 @@ __global__ void __launch_bounds__(kRefT, 2) crf_windowed_reference_l2(const RefA
             if (gl >= 0 && gl < n) g = A.c_gene[lo] + gl;
         }
         gslot[i] = g;
-        Es[i] = g >= 0 ? A.E[g] : make_double2(1.0, 1.0);  // a padding item has no attribute: state 0, exp 1
+        // a padding item has no attribute: state 0, exp 1
+        Es[i] = g < 0 ? make_double2(1.0, 1.0) : OWN_EXP ? exp_state_of(A.gene_ptr, A.attr_id, A.wtab01, A.n_attrs, g) : A.E[g];
         best[i] = 0ull;
     }
     __syncthreads();
-    const bool mine = q < A.S && ((A.start_bits[q >> 6] >> (q & 63)) & 1ull);
+    const bool mine = q >= 0 && q < A.S && ((A.start_bits[q >> 6] >> (q & 63)) & 1ull);
     if (mine) {
         const int base = threadIdx.x;
         double al[kRefMaxW], sc[kRefMaxW];  // alpha of the asked label, scale factors
@@ -137,10 +155,9 @@ __global__ void __launch_bounds__(kRefT, 2) crf_windowed_reference_l2(const RefA
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kRefT + W - 1; i += kRefT) {
+    for (int i = (W - 1) + int(threadIdx.x); i < (W - 1) + out; i += kRefT) {  // the owned slots
         const int g = gslot[i];
-        const unsigned long long v = best[i];
-        if (g >= 0 && v != 0ull) atomicMax(reinterpret_cast<unsigned long long *>(A.p_out + g), v);
+        if (g >= 0) A.p_out[g] = __longlong_as_double(static_cast<long long>(best[i]));
     }
 }
 
@@ -150,16 +167,23 @@ bool reference_bits_ok(int L, int W) { return L == 2 && W >= 1 && W <= kRefMaxW;
 
 size_t reference_scratch_bytes(int n_genes) { return (size_t(n_genes) + 1) * sizeof(double2); }
 
-// p_out zeroed by the caller (and NaN in skipped contigs); wtab01: the weight pairs in LABEL order (w[a][0], w[a][1]);
+// p_out: every gene of slot space is stored once (skipped contigs: NaN, filled by the caller); wtab01: the weight pairs in LABEL order (w[a][0], w[a][1]);
 // exp_trans_host: exp(trans[i][j]) row-major, from the host's libm; `scratch`: reference_scratch_bytes(n_genes)
 hipError_t launch_windowed_reference(const WinArgs &w, const double2 *wtab01, const double *exp_trans_host, void *scratch, hipStream_t stream) {
     if (!reference_bits_ok(w.L, w.W)) return hipErrorNotSupported;
     if (w.n_genes <= 0 || w.S <= 0) return hipSuccess;
     double2 *E = static_cast<double2 *>(scratch);
-    hipLaunchKernelGGL(ref_exp_states, dim3((w.n_genes + kRefT - 1) / kRefT), dim3(kRefT), 0, stream, w.gene_ptr, w.attr_id, wtab01, w.A,
-                       w.n_genes, E);
+    const int out = kRefT - (w.W - 1), tiles = (w.S + out - 1) / out;
+    const bool own_exp = tiles <= kRefOwnExpTiles;
+    if (!own_exp)
+        hipLaunchKernelGGL(ref_exp_states, dim3((w.n_genes + kRefT - 1) / kRefT), dim3(kRefT), 0, stream, w.gene_ptr, w.attr_id, wtab01, w.A,
+                           w.n_genes, E);
     RefArgs a{};
     a.E = E;
+    a.gene_ptr = w.gene_ptr;
+    a.attr_id = w.attr_id;
+    a.wtab01 = wtab01;
+    a.n_attrs = w.A;
     a.c_slot = w.c_slot;
     a.c_gene = w.c_gene;
     a.c_n = w.c_n;
@@ -173,7 +197,10 @@ hipError_t launch_windowed_reference(const WinArgs &w, const double2 *wtab01, co
     a.t01 = exp_trans_host[1];
     a.t10 = exp_trans_host[2];
     a.t11 = exp_trans_host[3];
-    hipLaunchKernelGGL(crf_windowed_reference_l2, dim3((w.S + kRefT - 1) / kRefT), dim3(kRefT), 0, stream, a);
+    if (own_exp)
+        hipLaunchKernelGGL(crf_windowed_reference_l2<true>, dim3(tiles), dim3(kRefT), 0, stream, a);
+    else
+        hipLaunchKernelGGL(crf_windowed_reference_l2<false>, dim3(tiles), dim3(kRefT), 0, stream, a);
     return hipGetLastError();
 }
 

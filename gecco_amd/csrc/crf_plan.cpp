@@ -662,8 +662,7 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
             std::lock_guard<std::mutex> lock(p.ws_mutex);
             if ((rc = grow_ws(p.d_win_scratch, p.win_scratch_cap, reference_scratch_bytes(p.n_genes), "hipMalloc reference scratch"))) return rc;
         }
-        // atomic-max accumulation starts from 0.0 (numpy.zeros, crf/__init__.py:251)
-        if ((rc = check_hip(hipMemsetAsync(d_p_out, 0, size_t(p.n_genes) * 8, stream), "memset p"))) return rc;
+        // (every gene of slot space is stored once by the tile that owns its slot: nothing to zero)
         if (!p.skipped.empty())
             if ((rc = check_hip(launch_fill_nan(d_p_out, p.d_skipped, int(p.skipped.size()), stream), "fill_nan launch"))) return rc;
         double et[4];
