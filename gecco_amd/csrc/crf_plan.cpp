@@ -110,7 +110,8 @@ int Arena::reserve(size_t bytes, const char *what) {
     if (bytes <= cap && h) return GECCO_CRF_OK;
     release();
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);  // head room: chunks of one batch differ a little
-    int rc = check_hip(hipHostMalloc(reinterpret_cast<void **>(&h), want, hipHostMallocDefault), what);
+    // (mapped + portable: the kernels of ANY device of a session may read the block where the host wrote it)
+    int rc = check_hip(hipHostMalloc(reinterpret_cast<void **>(&h), want, hipHostMallocMapped | hipHostMallocPortable), what);
     if (rc) return rc;
     if ((rc = check_hip(hipMalloc(reinterpret_cast<void **>(&d), want), what))) {
         (void)hipHostFree(h);

@@ -51,7 +51,7 @@ static int buf_push(buf_t *b, const void *src, size_t n)
  * dictionary directly; anything else -- and a miss -- goes through PyObject_GetAttr.  New reference. */
 static inline PyObject *attr_of(PyObject *o, PyObject *name)
 {
-    PyObject **dp = _PyObject_GetDictPtr(o);
+    PyObject **dp = Py_TYPE(o)->tp_getattro == PyObject_GenericGetAttr ? _PyObject_GetDictPtr(o) : NULL; /* (no __getattribute__ of its own) */
     if (dp && *dp) {
         PyObject *descr = _PyType_Lookup(Py_TYPE(o), name); /* borrowed; the type's method cache answers */
         if (!descr || !Py_TYPE(descr)->tp_descr_set) {

@@ -857,6 +857,19 @@ def test_objpath_fused_pass_and_buffer_annotation_equal_the_separate_steps():
     got = native.sort_group(wrapped, key, index)
     assert got is not None and (got[2], got[3], got[4]) == (ip, ap, at) and [len(c) for c in got[1]] == [len(c) for c in contigs]
 
+    class Proxy:  # __getattribute__ of its own: the instance dictionary (which lies) must not be consulted
+        def __init__(self, g):
+            object.__setattr__(self, "_g", g)
+            self.__dict__.update(start=-1, source=None, protein=None)
+
+        def __getattribute__(self, name):
+            if name in ("start", "source", "protein"):
+                return getattr(object.__getattribute__(self, "_g"), name)
+            return object.__getattribute__(self, name)
+
+    got = native.sort_group([Proxy(g) for g in genes], key, index)
+    assert got is not None and (got[2], got[3], got[4]) == (ip, ap, at)
+
     # annotate_all: list of floats == float64 buffer
     p = rng.random(len(genes))
     w1 = {nm: float(i) for i, nm in enumerate(names[:25])}
