@@ -731,14 +731,17 @@ __global__ void __launch_bounds__(kWinThreads, 4) crf_windowed_small_l2(const Wi
 // -- chains of dependent memory operations that leave the CUs idle when they run alone (vd_short: 10.5 us for 18 MB) --
 // run under the VALU-bound tiles: 32 us for both against 24.3 + 10.5 us and a kernel boundary (C3: 40.7 -> 36.4 us per
 // batch on the first measurement).  K batches take K + 1 launches (plan_run_decode_pipelined: the last call flushes).
+// TILES: window tiles per workgroup, as in crf_windowed_l2 (1 for batches too small to fill the CUs' wave slots: a workgroup's
+// tiles run one after the other, and with a wave or two per SIMD the chain of one tile is all the latency hiding there is).
+template <int TILES>
 __global__ void __launch_bounds__(kWinThreads, 8) crf_decode_pipelined(const WinArgs P, const SeqArgs A, const int nvd8) {
-    using Smem = WinSmem<20, kWinThreads, 2, true>;
+    using Smem = WinSmem<20, kWinThreads, TILES, true>;
     constexpr size_t kBytes = sizeof(Smem) > sizeof(VdShortSmem) ? sizeof(Smem) : sizeof(VdShortSmem);
     static_assert(kBytes <= 20480, "eight workgroups per CU");
     __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
     const int b = blockIdx.x;
     if (b >= nvd8) {
-        windowed_tile<20, true, false, kWinThreads, 2, true>(P, *reinterpret_cast<Smem *>(raw), xcd_remap(b - nvd8, P.ntiles));
+        windowed_tile<20, true, false, kWinThreads, TILES, true>(P, *reinterpret_cast<Smem *>(raw), xcd_remap(b - nvd8, P.ntiles));
         return;
     }
     if (b >= A.n_cblocks) return;
@@ -873,14 +876,17 @@ hipError_t launch_windowed(const WinArgs &a, hipStream_t stream) {
 }
 
 bool decode_pipelined_ok(const WinArgs &w, const SeqArgs &s) {
-    return w.ntiles > 0 && w.W == 20 && w.rescale_mask == 0 && w.tiles_per_wg == 2 && !w.generic && w.L == 2 && !w.state_out &&
+    return w.ntiles > 0 && w.W == 20 && w.rescale_mask == 0 && (w.tiles_per_wg == 1 || w.tiles_per_wg == 2) && !w.generic && w.L == 2 && !w.state_out &&
            s.short_contigs && s.n_cblocks > 0 && s.n_genes > 0;
 }
 
 hipError_t launch_decode_pipelined(const WinArgs &w, const SeqArgs &s, hipStream_t stream) {
     if (!decode_pipelined_ok(w, s)) return hipErrorNotSupported;
     const int nvd8 = (s.n_cblocks + 7) & ~7;
-    hipLaunchKernelGGL(crf_decode_pipelined, dim3(nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, w, s, nvd8);
+    if (w.tiles_per_wg == 1)
+        hipLaunchKernelGGL(crf_decode_pipelined<1>, dim3(nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, w, s, nvd8);
+    else
+        hipLaunchKernelGGL(crf_decode_pipelined<2>, dim3(nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, w, s, nvd8);
     return hipGetLastError();
 }
 

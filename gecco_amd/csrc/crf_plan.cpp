@@ -324,6 +324,14 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     {
         const char *env = std::getenv("GECCO_CRF_TILES_PER_WG");
         p.tiles_per_wg = (env && env[0] >= '1' && env[0] <= '3' && !env[1]) ? env[0] - '0' : kWinTilesPerWg;
+        // A batch that leaves most wave slots of the chip empty runs ONE tile per workgroup: the two tiles of a workgroup are a
+        // chain, and with a wave or two per SIMD nothing else hides a tile's latency (C2, 0.2 M genes: window kernel 10.0 -> 7.9 us).
+        // A batch of one workgroup keeps two (crf_windowed_small_l2).  GECCO_CRF_TILES1_MAX_SLOTS moves the limit (tests / A/B).
+        static const int64_t tiles1_max = [] {
+            const char *e = std::getenv("GECCO_CRF_TILES1_MAX_SLOTS");
+            return e ? std::atoll(e) : int64_t(kWinTiles1MaxSlots);
+        }();
+        if (!env && !p.general && W == 20 && p.S > 2 * (kWinThreads - (W - 1)) && p.S <= tiles1_max) p.tiles_per_wg = 1;
     }
     // window-start flags per slot (_meta.py:131: starts at 0, step, 2*step, ... <= n' - W)
     // one zero word in front (slots -64 .. -1: the lead-in of the first workgroup) and kStartBitsTail behind (the reach of
