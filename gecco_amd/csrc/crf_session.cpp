@@ -772,8 +772,9 @@ int submit_direct(RunCtx &X, DeviceCtx &D, Lane &ln, int chunk_index) {
     int rc;
     const int32_t ng = ck.g1 - ck.g0;
     const int32_t *d_gp = ln.x_gp, *d_at = ln.x_at - ln.up_a0;  // (gene_ptr keeps the caller's offsets)
-    // the register-resident 2-label kernel stores every gene's probability exactly once: it may write to host memory.  The
-    // other window kernels accumulate with atomic maxima on a zeroed array: device memory, copied out on the same stream.
+    // the register-resident 2-label kernel and the reference-bits kernel store every gene's probability exactly once: they may
+    // write to host memory.  The other window kernels accumulate with atomic maxima on a zeroed array: device memory, copied
+    // out on the same stream.
     const bool p_to_host = ln.x_p && !ln.plan.general && (ln.plan.fast_ok || ln.plan.reference_now);
     double *d_p = nullptr;
     if (X.windowed) {
