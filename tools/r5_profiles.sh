@@ -41,5 +41,10 @@ timeout 120 tools/ubench/pcie_bw > $O/pcie_bw.txt 2>&1
 bash tools/r5_tl.sh > $O/tl_run.log 2>&1
 cp $R/gpurun_out/r5_tl/timeline_decode_*.txt $O/ 2>/dev/null
 python tools/multi_entry_probe.py 1 2 4 8 > $O/multi_entry.txt 2>&1
+# reference-bits mode against the fast kernels (resident, one-shot, C1, the class's levels) + its two kernels' durations
+timeout 900 python tools/refbits_bench.py 2> /dev/null | grep '^{' > $O/reference_bits.jsonl
+GECCO_CRF_REFERENCE_BITS=1 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_ref -o kt -- python tools/refbits_bench.py resident > $O/kt_ref.log 2>&1
+python tools/prof_summary.py $O/kt_ref "" | cut -c1-260 | head -4 > $O/kt_reference_bits.txt; rm -rf $O/kt_ref
+timeout 300 python tools/tiles_sweep.py > $O/tiles_sweep.txt 2>&1
 tail -1 $O/bench_c3_driver.json | cut -c1-300
 ls $O | head -80
