@@ -733,8 +733,8 @@ __global__ void __launch_bounds__(kWinThreads, 4) crf_windowed_small_l2(const Wi
 // batch on the first measurement).  K batches take K + 1 launches (plan_run_decode_pipelined: the last call flushes).
 // TILES: window tiles per workgroup, as in crf_windowed_l2 (1 for batches too small to fill the CUs' wave slots: a workgroup's
 // tiles run one after the other, and with a wave or two per SIMD the chain of one tile is all the latency hiding there is).
-template <int TILES>
-__global__ void __launch_bounds__(kWinThreads, 8) crf_decode_pipelined(const WinArgs P, const SeqArgs A, const int nvd8) {
+template <int TILES, int WGS>
+__global__ void __launch_bounds__(kWinThreads, WGS) crf_decode_pipelined(const WinArgs P, const SeqArgs A, const int nvd8) {
     using Smem = WinSmem<20, kWinThreads, TILES, true>;
     constexpr size_t kBytes = sizeof(Smem) > sizeof(VdShortSmem) ? sizeof(Smem) : sizeof(VdShortSmem);
     static_assert(kBytes <= 20480, "eight workgroups per CU");
@@ -884,9 +884,9 @@ hipError_t launch_decode_pipelined(const WinArgs &w, const SeqArgs &s, hipStream
     if (!decode_pipelined_ok(w, s)) return hipErrorNotSupported;
     const int nvd8 = (s.n_cblocks + 7) & ~7;
     if (w.tiles_per_wg == 1)
-        hipLaunchKernelGGL(crf_decode_pipelined<1>, dim3(nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, w, s, nvd8);
+        hipLaunchKernelGGL((crf_decode_pipelined<1, 6>), dim3(nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, w, s, nvd8);
     else
-        hipLaunchKernelGGL(crf_decode_pipelined<2>, dim3(nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, w, s, nvd8);
+        hipLaunchKernelGGL((crf_decode_pipelined<2, 8>), dim3(nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, w, s, nvd8);
     return hipGetLastError();
 }
 

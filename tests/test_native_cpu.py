@@ -97,7 +97,9 @@ def test_host_only_plan_layout(blob):
     # 310 slots (the 10-gene contig is padded to 20); a 256-lane workgroup runs two DP phases of
     # 256-(W-1) output slots each
     assert p.num_tiles == 1 and "crf_windowed" in p.kernel_name
-    assert nat.Plan(m, [0, 5000], 20, 1, True, device=-1).num_tiles == -(-5000 // (2 * (256 - 19)))
+    # ... for batches of up to 0.45 M slots ONE phase per workgroup (crf_plan.cpp: a batch that does not fill the chip), two beyond
+    assert nat.Plan(m, [0, 5000], 20, 1, True, device=-1).num_tiles == -(-5000 // (256 - 19))
+    assert nat.Plan(m, [0, 600000], 20, 1, True, device=-1).num_tiles == -(-600000 // (2 * (256 - 19)))
     p = nat.Plan(m, [0, 50, 60, 300], 20, 1, False, device=-1)
     assert p.num_windows == 252
     p = nat.Plan(m, [0], 20, device=-1)

@@ -18,7 +18,14 @@ def main():
                                "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "gecco_amd", "csrc", "crf_kernels.hip"), "-o", out],
                               stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN5gecco12_GLOBAL__N_120crf_decode_pipelined"))
+    # the one-tile shape (batches that do not fill the chip) is compiled for seven workgroups per CU: no scratch at all
+    meta = "\n".join(lines)
+    meta = meta[meta.index("amdhsa.kernels:"):]
+    one = next(b for b in meta.split("  - .agpr_count")[1:] if "crf_decode_pipelinedILi1E" in b)
+    if ".private_segment_fixed_size: 0" not in one:
+        sys.exit("crf_decode_pipelined<1> uses scratch")
+    # the two-tile shape (eight workgroups per CU, 64 registers)
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN5gecco12_GLOBAL__N_120crf_decode_pipelinedILi2E"))
     end = next(i for i in range(start, len(lines)) if ".amdhsa_kernel" in lines[i])
     body = lines[start:end]
     # the tile path: from the first conditional branch (block index against the number of Viterbi blocks) to the label it skips to
