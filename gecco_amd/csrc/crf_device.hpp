@@ -50,7 +50,7 @@ struct WinArgs {
 constexpr int kWinThreads = 256;  // lanes (= window starts) per workgroup: 4 waves, 8 workgroups per CU at <= 64 VGPRs
 constexpr int kWinMaxW = 32;      // largest window the register-resident kernel handles
 constexpr int kWinTilesPerWg = 2; // default DP phases per workgroup (GECCO_CRF_TILES_PER_WG=1..3 overrides; A/B runs)
-constexpr int kWinTiles1MaxSlots = 450000;  // batches of up to this many slots: one tile per workgroup (tools/tiles_sweep.py: wins up to 0.4 M genes, loses from 0.6 M)
+constexpr int kWinTiles1MaxSlots = 350000;  // batches of up to this many slots: one tile per workgroup (tools/tiles_sweep.py: the window kernel wins up to 0.4 M genes, the pipelined launch -- seven workgroups per CU -- up to 0.3 M)
 
 // ---- shared device helpers ----------------------------------------------------------------------
 // exp(-t) for t >= 0: n = rint(t log2 e), r = n ln2 - t in two pieces (|r| <= ln2/2), degree-13
