@@ -587,6 +587,184 @@ __global__ void __launch_bounds__(kGT) gl_viterbi_seq(GenArgs a) {
     }
 }
 
+// ---- row V for 17 to 32 labels, batches of many contigs: one WAVE per contig ------------------------------------------
+// The chunked recursions below pay for their parallelism inside a contig with L x the arithmetic (a chunk's transfer matrix is
+// L forward recursions): 32 x at L = 32, where a batch of a thousand contigs has all the parallelism the chip can use in its
+// contigs alone (C2's shape, L = 32: 1.42 ms chunked).  Here a contig is a wave walking it gene by gene, CRFsuite's own
+// recursion ([EXT] crf1dc_viterbi: strict `<` update, first arg max).  The batch then takes as long as its LONGEST contig,
+// and a lone wave issues one instruction every four cycles whatever the instruction is -- so the step is built to be short in
+// instructions (~95 at L <= 32: 0.36 us), not in flops:
+//   * lane (j, h), h = lane % H, holds target label j and the source labels [h PER, (h + 1) PER): H = 64 / LP partial maxima
+//     per target in ONE quad of lanes, merged over h in ascending order by DPP quad permutes (ties keep the lower source
+//     label, as the sequential loop does); a lane's maximum is a v_max_f64 chain, its first arg max a compare-select chain;
+//   * no exec-mask juggling: lanes of labels that do not exist repeat label 0's work, every store is unconditional;
+//   * the state scores of the next sixteen genes are loaded while the current sixteen are walked (one round trip to memory
+//     per sixteen steps, hidden), the previous delta goes through one LDS slot per label;
+//   * back-pointers leave as one dword per label and FOUR genes (a contig's region of `back`, dword-aligned inside it: the
+//     regions of neighbouring contigs cannot meet); the last, incomplete quad never leaves its register;
+//   * back-tracking reads sixteen quads per round (prefetched) and walks them on the scalar unit: the label is wave-uniform,
+//     a step is v_readlane_b32 + s_bfe -- no dependent memory access.
+// Measured (1 000 contigs, 0.22 M genes, longest 1 519; chunked -> wave): L = 32 1.42 -> 0.55 ms, L = 24 0.96 -> 0.55 ms;
+// L = 16 0.30 -> 0.37 ms, L = 9 0.20 -> 0.36 ms: the plan takes this kernel above 16 labels when the longest contig is short
+// against the batch (plan_run_viterbi), and tests force it from 9 labels up.
+constexpr int kWaveK = 16;      // genes per staged block of state scores
+constexpr int kWaveQuads = 16;  // back-pointer quads per back-tracking round
+
+// lane l <- lane l ^ 1 / l ^ 2 inside its quad (DPP quad_perm: no LDS round trip)
+template <int X>
+__device__ __forceinline__ int gl_quad_xor(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, X == 1 ? 0xB1 : 0x4E, 0xF, 0xF, true);
+}
+template <int X>
+__device__ __forceinline__ double gl_quad_xor(double v) {
+    return __hiloint2double(gl_quad_xor<X>(__double2hiint(v)), gl_quad_xor<X>(__double2loint(v)));
+}
+
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_viterbi_wave(GenArgs a) {
+    constexpr int H = 64 / LP, PER = LP / H, K = kWaveK, Q = kWaveQuads;
+    __shared__ double vecs[kGT / 64][LP];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const long long ci = static_cast<long long>(blockIdx.x) * (kGT / 64) + wave;
+    if (ci >= a.n_contigs) return;
+    const int L = a.L, h = lane & (H - 1), j = lane / H;  // (the H lanes of a target label share a quad)
+    const int g0 = __builtin_amdgcn_readfirstlane(a.contig_ptr[ci]);
+    const int T = __builtin_amdgcn_readfirstlane(a.contig_ptr[ci + 1]) - g0;
+    if (T <= 0) {
+        if (lane == 0 && a.score) a.score[ci] = 0.0;
+        return;
+    }
+    // lanes of labels that do not exist (L < LP) repeat label 0's work: their stores then carry label 0's values, and no store
+    // needs a test (a single wave issues an instruction every four cycles whatever it is: exec-mask juggling costs as much as
+    // arithmetic here)
+    const bool on = j < L;
+    const int jj = on ? j : 0;
+    double tcol[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = h * PER + k;
+        tcol[k] = i < L ? a.trans[i * L + jj] : -DBL_MAX;  // (a label that does not exist never wins a strict `<`)
+    }
+    double *vec = vecs[wave];
+    double *vout = vec + j;  // (slots of missing labels: written with label 0's value -- finite --, read against -DBL_MAX)
+    const double *vin = vec + h * PER;
+    const double *st = a.state + static_cast<size_t>(g0) * L + jj;
+    // the contig's back-pointer quads: dwords [q * L + j], from the first dword boundary inside its n * L bytes
+    const size_t byte0 = (static_cast<size_t>(g0) * L + 3) & ~size_t(3);
+    uint32_t *backq = reinterpret_cast<uint32_t *>(a.back + byte0) + jj;
+    const bool writer = on && h == 0;
+    double d = st[0];
+    double nxt[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) nxt[k] = 1 + k < T ? st[static_cast<size_t>(1 + k) * L] : 0.0;
+    uint32_t acc = 0;  // back-pointers of the quad in progress (byte t & 3 = row t)
+    // one step of [EXT] crf1dc_viterbi for target label j: delta_t[j] = max_i (delta_{t-1}[i] + trans[i][j]) + state_t[j],
+    // back-pointer = the FIRST source label that attains the maximum
+    auto step = [&](const int t, const double s_t, const int sh) {
+        *vout = d;  // (the H lanes of a label hold the same value)
+        __builtin_amdgcn_wave_barrier();
+        double sc[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) sc[u] = vin[u] + tcol[u];
+        __builtin_amdgcn_wave_barrier();
+        double best = sc[0];
+#pragma unroll
+        for (int u = 1; u < PER; ++u) best = fmax(best, sc[u]);
+        int arg = h * PER + PER - 1;  // the first source label of the lane's range that attains its maximum
+#pragma unroll
+        for (int u = PER - 2; u >= 0; --u) arg = sc[u] == best ? h * PER + u : arg;
+        // merge the partial maxima of the quad's lanes, the lower source range first (ties keep the lower label)
+        if (H >= 2) {
+            const double ob = gl_quad_xor<1>(best);
+            const int oa = gl_quad_xor<1>(arg);
+            const bool take = (lane & 1) ? !(ob < best) : (best < ob);
+            best = take ? ob : best;
+            arg = take ? oa : arg;
+        }
+        if (H >= 4) {
+            const double ob = gl_quad_xor<2>(best);
+            const int oa = gl_quad_xor<2>(arg);
+            const bool take = (lane & 2) ? !(ob < best) : (best < ob);
+            best = take ? ob : best;
+            arg = take ? oa : arg;
+        }
+        d = best + s_t;
+        const uint32_t bp = uint32_t(arg);
+        acc = sh == 0 ? bp : (acc | (bp << sh));
+        if (sh == 24) backq[static_cast<size_t>(t >> 2) * L] = acc;  // (every lane of the label, the same dword)
+    };
+    int tb = 1;
+    for (; tb + K <= T; tb += K) {  // whole blocks of sixteen genes: nothing to test inside
+        double cur[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) cur[k] = nxt[k];
+        if (tb + K < T) {
+            const double *sp = st + static_cast<size_t>(tb + K) * L;
+#pragma unroll
+            for (int k = 0; k < K; ++k) nxt[k] = tb + K + k < T ? sp[static_cast<size_t>(k) * L] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) step(tb + k, cur[k], ((1 + k) & 3) * 8);  // (tb = 1 mod 16)
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (tb + k < T) step(tb + k, nxt[k], ((1 + k) & 3) * 8);  // the last, partial block (wave-uniform tests)
+    // end label = first arg max (every lane computes it: wave-uniform)
+    *vout = d;
+    __builtin_amdgcn_wave_barrier();
+    int y = 0;
+    {
+        double best = -DBL_MAX;
+        for (int i = 0; i < L; ++i) {
+            const double v = vec[i];
+            if (best < v) {
+                best = v;
+                y = i;
+            }
+        }
+        if (lane == 0 && a.score) a.score[ci] = best;
+    }
+    y = __builtin_amdgcn_readfirstlane(y);
+    int8_t *yout = a.y + g0;
+    if (lane == 0) yout[T - 1] = static_cast<int8_t>(y);
+    if (T == 1) return;
+    __threadfence();  // (the quads this wave stored are read back through other lanes)
+    // rows T - 1 .. 1; quad q = rows 4 q .. 4 q + 3; the top quad is `acc` when it is incomplete
+    const int q_top = (T - 1) >> 2;
+    const bool top_in_reg = ((T - 1) & 3) != 3;
+    auto load_quads = [&](int q_hi, uint32_t (&w)[Q]) {  // quads q_hi - Q + 1 .. q_hi (those below 0: unused)
+#pragma unroll
+        for (int r = 0; r < Q; ++r) {
+            const int q = q_hi - (Q - 1) + r;
+            const bool stored = q >= 0 && (q < q_top || !top_in_reg);
+            w[r] = (stored && writer) ? backq[static_cast<size_t>(q) * L] : 0u;
+        }
+    };
+    uint32_t wn[Q];
+    load_quads(q_top, wn);
+    for (int q_hi = q_top; q_hi >= 0; q_hi -= Q) {
+        uint32_t w[Q];
+#pragma unroll
+        for (int r = 0; r < Q; ++r) w[r] = wn[r];
+        if (q_hi == q_top && top_in_reg) w[Q - 1] = acc;
+        if (q_hi - Q >= 0) load_quads(q_hi - Q, wn);
+#pragma unroll
+        for (int r = Q - 1; r >= 0; --r) {
+            const int q = q_hi - (Q - 1) + r;
+            if (q < 0) continue;  // (wave-uniform)
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                const int t = 4 * q + b;
+                if (t >= 1 && t <= T - 1) {  // (wave-uniform)
+                    const uint32_t word = uint32_t(__builtin_amdgcn_readlane(int(w[r]), y * H));  // row t as label y_t's lane holds it
+                    y = int((word >> (8 * b)) & 0xffu);                                       // = label of gene t - 1
+                    if (lane == 0) yout[t - 1] = static_cast<int8_t>(y);
+                }
+            }
+        }
+    }
+}
+
 // ==================================================================================================
 // Long contigs, any number of labels ("matrix-product scan for C5").  The kernels
 // above give a whole contig to ONE group of lanes: a 50 000-gene contig is a 50 000-step dependent chain
@@ -1251,6 +1429,16 @@ hipError_t launch_gen_windowed(const GenArgs &a, hipStream_t stream) {
 }
 hipError_t launch_gen_marginals(const GenArgs &a, hipStream_t stream) { return launch_any(2, a, stream); }
 hipError_t launch_gen_viterbi(const GenArgs &a, hipStream_t stream) { return launch_any(3, a, stream); }
+hipError_t launch_gen_viterbi_wave(const GenArgs &a, hipStream_t stream) {
+    if (a.L <= 8 || a.L > kGenMaxL) return hipErrorNotSupported;
+    if (a.n_contigs <= 0) return hipSuccess;
+    const dim3 grid(unsigned((a.n_contigs + kGT / 64 - 1) / (kGT / 64)));
+    if (a.L <= 16)
+        hipLaunchKernelGGL(gl_viterbi_wave<16>, grid, dim3(kGT), 0, stream, a);
+    else
+        hipLaunchKernelGGL(gl_viterbi_wave<32>, grid, dim3(kGT), 0, stream, a);
+    return hipGetLastError();
+}
 int gen_chunk_genes() { return kChunk; }
 
 }  // namespace gecco

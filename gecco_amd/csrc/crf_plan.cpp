@@ -444,6 +444,8 @@ inline size_t align256g(size_t x) { return (x + 255) & ~size_t(255); }
 // A contig longer than this sends the whole batch through the chunked whole-contig kernels (crf_general.hip):
 // below it, one group of lanes per contig walking it sequentially is the cheaper arrangement.
 constexpr int32_t kGenLongContig = 2048;
+// gl_viterbi_wave is taken when (longest contig) x ratio <= genes of the batch (plan_run_viterbi)
+constexpr int64_t kGenWaveRatio32 = 60, kGenWaveRatio24 = 85;
 
 int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, GenArgs &a, bool whole_contig = false,
                   hipStream_t stream = nullptr) {
@@ -1035,13 +1037,28 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
         return GECCO_CRF_EINVAL;
     }
     if (p.general) {
+        // 17 to 32 labels: a wave per contig (gl_viterbi_wave) when the batch has its parallelism in its contigs -- the walk of
+        // the longest contig, T_max steps of ~0.36 us (a single wave issues an instruction every four cycles), against the
+        // chunked kernels' L x the arithmetic over all n genes (6.3 / 4.3 ns per gene at L = 32 / 24; measured on 1 000 contigs,
+        // 0.22 M genes, longest 1 519: 1.42 -> 0.55 ms at L = 32, 0.96 -> 0.55 at L = 24; at L = 16 the chunked kernels win,
+        // 0.30 against 0.37 ms).  GECCO_CRF_GENERAL_VITERBI=wave|chunked forces either for 9 <= L <= 32 (tests, A/B).
+        bool wave = false;
+        if (p.model->L > 8) {
+            const char *env = std::getenv("GECCO_CRF_GENERAL_VITERBI");  // (read per call: the tests switch it)
+            const int forced = !env ? -1 : env[0] == 'w' ? 1 : env[0] == 'c' ? 0 : -1;
+            int32_t t_max = 0;
+            for (int32_t c = 0; c < p.n_contigs; ++c) t_max = std::max(t_max, p.contig_ptr[c + 1] - p.contig_ptr[c]);
+            const int64_t ratio = p.model->L >= 28 ? kGenWaveRatio32 : kGenWaveRatio24;
+            wave = forced == 1 || (forced < 0 && p.model->L > 16 && int64_t(t_max) * ratio <= int64_t(p.n_genes));
+        }
         GenArgs g;
-        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g, true, stream))) return rc;
+        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g, !wave, stream))) return rc;
         g.y = d_y;
         g.score = d_score;
         g.E = nullptr;
         g.smax = nullptr;
         if ((rc = check_hip(launch_gen_state(g, stream), "state score launch"))) return rc;
+        if (wave) return check_hip(launch_gen_viterbi_wave(g, stream), "viterbi launch");
         return check_hip(launch_gen_viterbi(g, stream), "viterbi launch");
     }
     a.y = d_y;

@@ -231,6 +231,51 @@ def test_contig_sequential_kernels(nat, L, monkeypatch):
     assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
 
 
+@pytest.mark.parametrize("L", [9, 13, 16, 17, 24, 32])
+@pytest.mark.parametrize("mode", ["wave", "chunked"])
+def test_viterbi_wave_per_contig(nat, L, mode, monkeypatch):
+    """9 to 32 labels: one wave per contig (gl_viterbi_wave: partial maxima merged in ascending source order, back-pointers as
+    quads, scalar back-tracking) and the chunked kernels give CRFsuite's labels and scores -- contigs of 1 .. 1 500 genes (every
+    remainder of the quads and of the sixteen-quad rounds), and integer weights, where ties decide (strict `<`, first arg max)."""
+    from oracle import crf_oracle as orc
+
+    monkeypatch.setenv("GECCO_CRF_GENERAL_VITERBI", mode)
+    w, trans, cptr, gptr, attr = _case(L, 700 + L, extra=60)
+    model = nat.Model.from_tables(w, trans)
+    y, sc = model.viterbi(cptr, gptr, attr)
+    ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+    assert np.array_equal(y.astype(np.int32), ey)
+    assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
+    # ties: small integer weights (every sum exact), many equal path scores
+    rng = np.random.default_rng(800 + L)
+    wi = rng.integers(-2, 3, size=(40, L)).astype(np.float64)
+    ti = rng.integers(-1, 2, size=(L, L)).astype(np.float64)
+    c2, g2, a2 = synth_contigs(rng, [1, 2, 3, 4, 5, 8, 9, 63, 64, 65, 66, 127, 128, 129, 300] + [int(x) for x in rng.integers(1, 90, size=40)], 40)
+    mi = nat.Model.from_tables(wi, ti)
+    y2, s2 = mi.viterbi(c2, g2, a2)
+    e2, es2 = orc.viterbi(wi, ti, c2, g2, a2)
+    assert np.array_equal(y2.astype(np.int32), e2)
+    assert np.array_equal(s2, es2)
+
+
+def test_viterbi_wave_is_chosen_for_batches_of_many_contigs(nat, monkeypatch):
+    """The plan takes the wave-per-contig kernel when (longest contig) x 85 <= genes of the batch (17 <= L < 28; x 60 above), the
+    chunked kernels otherwise: both give the oracle's labels; the choice only shows in the time."""
+    from oracle import crf_oracle as orc
+
+    monkeypatch.delenv("GECCO_CRF_GENERAL_VITERBI", raising=False)
+    rng = np.random.default_rng(77)
+    L = 20
+    w, trans = synth_model(200, rng, L=L)
+    model = nat.Model.from_tables(w, trans)
+    for lengths in ([50] * 400, [3000, 20, 20]):  # (many short contigs, 50 x 85 <= 20 000: wave; one long contig: chunked)
+        cptr, gptr, attr = synth_contigs(rng, lengths, 200)
+        y, sc = model.viterbi(cptr, gptr, attr)
+        ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+        assert np.array_equal(y.astype(np.int32), ey)
+        assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())
+
+
 def test_three_labels_against_path_enumeration(nat):
     from oracle import crf_oracle as orc
 
