@@ -296,6 +296,7 @@ struct GenArgs {
     double *chZ;               // [n_chunks]     partial log-partition
     uint8_t *chMap;            // [n_chunks*L]   label of the chunk's last gene -> label of the gene before the chunk
     int8_t *chY;               // [n_chunks]     label of the chunk's last gene
+    int32_t wave_tmax;            // gl_viterbi_wave: contigs longer than this are left to the chunked kernels (0: none is)
     int32_t rows_rescale_period;  // gl_chunk_rows_mfma: steps between two power-of-two rescalings of a column (1 or 4; host: 4 max|trans| < 600)
     // windowed path: slot space of the plan
     const int32_t *c_slot, *c_gene, *c_n;

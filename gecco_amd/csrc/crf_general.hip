@@ -37,6 +37,12 @@ __device__ __forceinline__ double group_max(double v) {
     return v;
 }
 
+// last gene + 1 of chunk ci: where the next chunk starts, or where its contig ends (the chunk table may list the long contigs
+// of a batch only: the next chunk then belongs to a contig further on)
+__device__ __forceinline__ int gl_chunk_end(const GenArgs &a, long long ci) {
+    return min(a.ch_g0[ci + 1], a.contig_ptr[a.ch_contig[ci] + 1]);
+}
+
 // ---- row S: state scores of every gene (CSR order, bit-identical to sequential addition) ----
 // state[g][y] = sum_a w[a][y]; E[g][y] = exp(state - max_y); smax[g] = max_y state.
 template <int LP>
@@ -634,6 +640,7 @@ __global__ void __launch_bounds__(kGT) gl_viterbi_wave(GenArgs a) {
         if (lane == 0 && a.score) a.score[ci] = 0.0;
         return;
     }
+    if (a.wave_tmax > 0 && T > a.wave_tmax) return;  // (the batch's long tail: decoded by the chunked kernels before this launch)
     // lanes of labels that do not exist (L < LP) repeat label 0's work: their stores then carry label 0's values, and no store
     // needs a test (a single wave issues an instruction every four cycles whatever it is: exec-mask juggling costs as much as
     // arithmetic here)
@@ -795,7 +802,7 @@ __global__ void __launch_bounds__(kGT) gl_chunk_rows(GenArgs a) {
     const long long q = static_cast<long long>(blockIdx.x) * G + grp;
     if (q >= static_cast<long long>(a.n_chunks) * L) return;
     const int ci = int(q / L), i = int(q % L);
-    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int g0 = a.ch_g0[ci], g1 = gl_chunk_end(a, ci);
     const int cfirst = a.contig_ptr[a.ch_contig[ci]];  // the contig's first gene has no transition into it
     const bool on = j < L;
     const int jj = on ? j : 0;
@@ -857,7 +864,7 @@ __global__ void __launch_bounds__(kGT) gl_chunk_rows_mfma(GenArgs a, const int p
     const long long wv = static_cast<long long>(blockIdx.x) * (kGT / 64) + (threadIdx.x >> 6);
     if (wv >= static_cast<long long>(a.n_chunks) * groups) return;
     const int ci = int(wv / groups), cg = int(wv % groups);
-    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int g0 = a.ch_g0[ci], g1 = gl_chunk_end(a, ci);
     const int cfirst = a.contig_ptr[a.ch_contig[ci]];
     const int col = 16 * cg + w;  // the start label of this lane's column
     double Af[TILES][NS];         // slices of M^T: row = output label, column = summed label
@@ -1043,7 +1050,7 @@ __global__ void __launch_bounds__(kGT) gl_chunk_vecs(GenArgs a) {
     if (ct >= a.n_contigs) return;
     // a contig without genes has no chunk, so none of the chunk kernels writes its log-partition / path score: 0, as the
     // contig-sequential kernels give it
-    if (j == 0 && blockIdx.y == 0 && a.cc_ptr[ct + 1] == a.cc_ptr[ct]) {
+    if (j == 0 && blockIdx.y == 0 && a.cc_ptr[ct + 1] == a.cc_ptr[ct] && a.wave_tmax == 0) {  // (split batches: the waves' contigs)
         if (!MAXPLUS && a.lognorm) a.lognorm[ct] = 0.0;
         if (MAXPLUS && a.score) a.score[ct] = 0.0;
     }
@@ -1063,7 +1070,7 @@ __global__ void __launch_bounds__(kGT) gl_chunk_fwd(GenArgs a) {
     const int L = a.L;
     const long long ci = static_cast<long long>(blockIdx.x) * G + grp;
     if (ci >= a.n_chunks) return;
-    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int g0 = a.ch_g0[ci], g1 = gl_chunk_end(a, ci);
     const int cfirst = a.contig_ptr[a.ch_contig[ci]];
     const bool on = j < L;
     const int jj = on ? j : 0;
@@ -1106,7 +1113,7 @@ __global__ void __launch_bounds__(kGT) gl_chunk_bwd(GenArgs a) {
     const int L = a.L;
     const long long ci = static_cast<long long>(blockIdx.x) * G + grp;
     if (ci >= a.n_chunks) return;
-    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int g0 = a.ch_g0[ci], g1 = gl_chunk_end(a, ci);
     const bool on = j < L;
     const int jj = on ? j : 0;
     double mrow[LP];
@@ -1149,7 +1156,7 @@ __global__ void __launch_bounds__(kGT) gl_chunk_vit(GenArgs a) {
     const int L = a.L;
     const long long ci = static_cast<long long>(blockIdx.x) * G + grp;
     if (ci >= a.n_chunks) return;
-    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int g0 = a.ch_g0[ci], g1 = gl_chunk_end(a, ci);
     const int ct = a.ch_contig[ci];
     const int cfirst = a.contig_ptr[ct], cend = a.contig_ptr[ct + 1];
     const bool on = j < L;
@@ -1207,7 +1214,7 @@ __global__ void __launch_bounds__(kGT) gl_chunk_maps(GenArgs a) {
     const int L = a.L;
     const long long ci = static_cast<long long>(blockIdx.x) * G + grp;
     if (ci >= a.n_chunks || j >= L) return;
-    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int g0 = a.ch_g0[ci], g1 = gl_chunk_end(a, ci);
     if (g0 == a.contig_ptr[a.ch_contig[ci]]) return;  // nothing before a contig's first chunk
     int y = j;
     for (int t = g1 - 1; t >= g0; --t) y = a.back[static_cast<size_t>(t) * L + y];
@@ -1250,7 +1257,7 @@ __global__ void __launch_bounds__(kGT) gl_chunk_ends(GenArgs a) {
 __global__ void __launch_bounds__(kGT) gl_chunk_backtrack(GenArgs a) {
     const long long ci = static_cast<long long>(blockIdx.x) * kGT + threadIdx.x;
     if (ci >= a.n_chunks) return;
-    const int g0 = a.ch_g0[ci], g1 = a.ch_g0[ci + 1];
+    const int g0 = a.ch_g0[ci], g1 = gl_chunk_end(a, ci);
     if (g1 <= g0) return;
     int y = a.chY[ci];
     a.y[g1 - 1] = static_cast<int8_t>(y);

@@ -1,6 +1,7 @@
 #include "crf_plan.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -138,8 +139,12 @@ Plan::~Plan() {
             (void)hipFree(d_seq_ws);
             (void)hipFree(d_win_scratch);
             (void)hipFree(d_gen_ws);
-            (void)hipFree(d_gen_tab);
+            (void)hipFree(gen_tab[0].d);
+            (void)hipFree(gen_tab[1].d);
             (void)hipFree(d_seg_ws);
+            if (side_stream) (void)hipStreamDestroy(side_stream);
+            if (ev_fork) (void)hipEventDestroy(ev_fork);
+            if (ev_join) (void)hipEventDestroy(ev_join);
             (void)hipSetDevice(prev);
         }
     }
@@ -230,7 +235,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
         return GECCO_CRF_EINVAL;
     }
     p.gen_small = false;
-    p.gen_tab_chunk = 0;  // (chunk tables of the previous contigs)
+    p.gen_tab[0].chunk = p.gen_tab[1].chunk = 0;  // (chunk tables of the previous contigs)
     p.pipe = Plan::Pipe{};  // (score differences and CSR pointers of the previous layout)
     p.csr_begin = p.csr_end = -1;  // (the owner sets them after the build, for the batch at hand)
     p.model = &m;
@@ -444,11 +449,10 @@ inline size_t align256g(size_t x) { return (x + 255) & ~size_t(255); }
 // A contig longer than this sends the whole batch through the chunked whole-contig kernels (crf_general.hip):
 // below it, one group of lanes per contig walking it sequentially is the cheaper arrangement.
 constexpr int32_t kGenLongContig = 2048;
-// gl_viterbi_wave is taken when (longest contig) x ratio <= genes of the batch (plan_run_viterbi)
-constexpr int64_t kGenWaveRatio32 = 60, kGenWaveRatio24 = 85;
 
+// chunk_min_len >= 0: only contigs LONGER than that get chunks (the second table set); -1: every contig
 int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, GenArgs &a, bool whole_contig = false,
-                  hipStream_t stream = nullptr) {
+                  hipStream_t stream = nullptr, int32_t chunk_min_len = -1) {
     const Model &m = *p.model;
     const size_t n = size_t(p.n_genes), L = size_t(m.L);
     const size_t b_vec = align256g(n * L * 8 + 8), b_one = align256g(n * 8 + 8), b_back = align256g(n * L + 8);
@@ -471,34 +475,39 @@ int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, 
             if (v >= 4 && v <= 4096) C = v;
         }
         std::lock_guard<std::mutex> lock(p.ws_mutex);
-        if (!p.d_gen_tab || p.gen_tab_chunk != C) {
+        Plan::GenTab &tab = p.gen_tab[chunk_min_len >= 0 ? 1 : 0];
+        if (!tab.d || tab.chunk != C || tab.min_len != chunk_min_len) {
             std::vector<int32_t> ch_g0, ch_contig, cc_ptr;
             cc_ptr.push_back(0);
             for (int32_t c = 0; c < p.n_contigs; ++c) {
-                for (int32_t g = p.contig_ptr[c]; g < p.contig_ptr[c + 1]; g += C) {
-                    ch_g0.push_back(g);
-                    ch_contig.push_back(c);
+                if (p.contig_ptr[c + 1] - p.contig_ptr[c] > chunk_min_len) {
+                    for (int32_t g = p.contig_ptr[c]; g < p.contig_ptr[c + 1]; g += C) {
+                        ch_g0.push_back(g);
+                        ch_contig.push_back(c);
+                    }
                 }
                 cc_ptr.push_back(int32_t(ch_g0.size()));
             }
-            ch_g0.push_back(p.n_genes);
+            ch_g0.push_back(p.n_genes);  // (a chunk ends where the next one starts or where its contig does: gl_chunk_end)
             const size_t n_ch = ch_contig.size();
             const size_t o1 = align256g(ch_g0.size() * 4), o2 = o1 + align256g(n_ch * 4 + 4), total = o2 + align256g(cc_ptr.size() * 4);
-            if (p.d_gen_tab) (void)hipFree(p.d_gen_tab);
-            p.d_gen_tab = nullptr;
-            int rc = check_hip(hipMalloc(reinterpret_cast<void **>(&p.d_gen_tab), total), "hipMalloc chunk tables");
+            if (tab.d) (void)hipFree(tab.d);
+            tab.d = nullptr;
+            tab.chunk = 0;
+            int rc = check_hip(hipMalloc(reinterpret_cast<void **>(&tab.d), total), "hipMalloc chunk tables");
             if (rc) return rc;
             std::vector<char> img(total, 0);
             std::memcpy(img.data(), ch_g0.data(), ch_g0.size() * 4);
             std::memcpy(img.data() + o1, ch_contig.data(), n_ch * 4);
             std::memcpy(img.data() + o2, cc_ptr.data(), cc_ptr.size() * 4);
-            if ((rc = check_hip(hipMemcpy(p.d_gen_tab, img.data(), total, hipMemcpyHostToDevice), "upload chunk tables"))) return rc;
-            p.gen_tab_chunk = C;
-            p.gen_tab_nch = n_ch;
-            p.gen_tab_off1 = o1;
-            p.gen_tab_off2 = o2;
+            if ((rc = check_hip(hipMemcpy(tab.d, img.data(), total, hipMemcpyHostToDevice), "upload chunk tables"))) return rc;
+            tab.chunk = C;
+            tab.min_len = chunk_min_len;
+            tab.nch = n_ch;
+            tab.off1 = o1;
+            tab.off2 = o2;
         }
-        nch = p.gen_tab_nch;
+        nch = tab.nch;
     }
     const size_t b_chM = align256g(nch * L * L * 8 + 8), b_chv = align256g(nch * L * 8 + 8), b_chs = align256g(nch * 8 + 8);
     const size_t b_chunks = chunked ? b_chM + 3 * b_chv + 2 * b_chs + 2 * align256g(nch * L + 8) : 0;
@@ -528,9 +537,10 @@ int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, 
     a.back = reinterpret_cast<uint8_t *>(w + 3 * b_vec + 2 * b_one);
     if (chunked && nch) {
         char *q = w + 3 * b_vec + 2 * b_one + b_back;
-        a.ch_g0 = reinterpret_cast<const int32_t *>(p.d_gen_tab);
-        a.ch_contig = reinterpret_cast<const int32_t *>(p.d_gen_tab + p.gen_tab_off1);
-        a.cc_ptr = reinterpret_cast<const int32_t *>(p.d_gen_tab + p.gen_tab_off2);
+        const Plan::GenTab &tab = p.gen_tab[chunk_min_len >= 0 ? 1 : 0];
+        a.ch_g0 = reinterpret_cast<const int32_t *>(tab.d);
+        a.ch_contig = reinterpret_cast<const int32_t *>(tab.d + tab.off1);
+        a.cc_ptr = reinterpret_cast<const int32_t *>(tab.d + tab.off2);
         a.n_chunks = int32_t(nch);
         a.chM = reinterpret_cast<double *>(q);
         q += b_chM;
@@ -1037,29 +1047,73 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
         return GECCO_CRF_EINVAL;
     }
     if (p.general) {
-        // 17 to 32 labels: a wave per contig (gl_viterbi_wave) when the batch has its parallelism in its contigs -- the walk of
-        // the longest contig, T_max steps of ~0.36 us (a single wave issues an instruction every four cycles), against the
-        // chunked kernels' L x the arithmetic over all n genes (6.3 / 4.3 ns per gene at L = 32 / 24; measured on 1 000 contigs,
-        // 0.22 M genes, longest 1 519: 1.42 -> 0.55 ms at L = 32, 0.96 -> 0.55 at L = 24; at L = 16 the chunked kernels win,
-        // 0.30 against 0.37 ms).  GECCO_CRF_GENERAL_VITERBI=wave|chunked forces either for 9 <= L <= 32 (tests, A/B).
-        bool wave = false;
-        if (p.model->L > 8) {
+        // 13 to 32 labels: a wave per contig (gl_viterbi_wave) where the batch has its parallelism in its contigs.  The wave
+        // kernel takes as long as the longest contig it is given (~0.36 / 0.25 us per gene above / up to 16 labels: a lone wave
+        // issues an instruction every four cycles); the chunked kernels pay L x the arithmetic for every gene they are given
+        // plus a chain of six launches and the walk over their longest contig's chunks.  So the batch is SPLIT: the k longest
+        // contigs -- the tail of a metagenome's length distribution -- go through the chunked kernels on the plan's side
+        // stream, NEXT TO the waves of the others, with k minimising  max(t_wave(longest of the others), t_chunked(the k longest)).
+        // Measured on 1 000 contigs / 0.22 M genes, longest 1 519, next 762 (all chunked -> all waves -> split):
+        // L = 32 1.42 -> 0.55 -> 0.32 ms, L = 24 0.96 -> 0.55 -> 0.32 ms, L = 16 0.28 -> 0.37 -> 0.22 ms.
+        // GECCO_CRF_GENERAL_VITERBI=wave|chunked forces either for 9 <= L <= 32 (tests, A/B); =split forces the split at k = 1.
+        const int L = p.model->L;
+        int32_t wave_tmax = -1;  // -1: no wave kernel; 0: every contig; > 0: contigs up to this length
+        if (L > 8 && p.n_contigs > 0) {
             const char *env = std::getenv("GECCO_CRF_GENERAL_VITERBI");  // (read per call: the tests switch it)
-            const int forced = !env ? -1 : env[0] == 'w' ? 1 : env[0] == 'c' ? 0 : -1;
-            int32_t t_max = 0;
-            for (int32_t c = 0; c < p.n_contigs; ++c) t_max = std::max(t_max, p.contig_ptr[c + 1] - p.contig_ptr[c]);
-            const int64_t ratio = p.model->L >= 28 ? kGenWaveRatio32 : kGenWaveRatio24;
-            wave = forced == 1 || (forced < 0 && p.model->L > 16 && int64_t(t_max) * ratio <= int64_t(p.n_genes));
+            const int forced = !env ? -1 : env[0] == 'w' ? 1 : env[0] == 'c' ? 0 : env[0] == 's' ? 2 : -1;
+            if (forced == 1) {
+                wave_tmax = 0;
+            } else if (forced == 2 || (forced < 0 && L > 12)) {
+                std::vector<int32_t> len(size_t(p.n_contigs));
+                for (int32_t c = 0; c < p.n_contigs; ++c) len[size_t(c)] = p.contig_ptr[c + 1] - p.contig_ptr[c];
+                std::sort(len.begin(), len.end(), std::greater<int32_t>());
+                // us: a wave's step (LP = 32 / 16 lanes per target label set); the chunked kernels per gene of the batch, per gene
+                // of their longest contig (the walk over its chunks) and their dependent launches (measured at L = 32 on a tail
+                // of one 1 519-gene contig: 270 us; at L = 16: 150 us)
+                const double t_step = L > 16 ? 0.36 : 0.25, t_gene = L >= 28 ? 6.3e-3 : L > 16 ? 4.3e-3 : 1.3e-3;
+                const double t_walk = L > 16 ? 0.07 : 0.04, t_launches = L > 16 ? 150.0 : 80.0;
+                const double all_chunked = double(p.n_genes) * t_gene + double(len[0]) * t_walk;  // (t_gene: a whole batch's rate)
+                double best = all_chunked;
+                int64_t tail = 0;
+                for (int32_t k = 0; k < p.n_contigs; ++k) {  // the k longest contigs chunked NEXT TO the waves of the others
+                    const double t_tail = k ? double(tail) * t_gene + double(len[0]) * t_walk + t_launches : 0.0;
+                    const double t = std::max(double(len[size_t(k)]) * t_step, t_tail);
+                    if (t < best || (forced == 2 && k == 1)) {
+                        best = t;
+                        wave_tmax = k ? len[size_t(k)] : 0;  // (contigs as long as the k-th longest stay with the waves)
+                        if (forced == 2 && k == 1) break;
+                    }
+                    tail += len[size_t(k)];
+                    if (double(tail) * t_gene + t_launches > best) break;  // (cannot get better from here)
+                }
+                if (wave_tmax > 0 && len[0] <= wave_tmax) wave_tmax = 0;  // (nothing is longer: no tail)
+            }
         }
         GenArgs g;
-        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g, !wave, stream))) return rc;
+        const bool wave = wave_tmax >= 0, tail_chunked = wave_tmax > 0;
+        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g, !wave || tail_chunked, stream, tail_chunked ? wave_tmax : -1))) return rc;
         g.y = d_y;
         g.score = d_score;
         g.E = nullptr;
         g.smax = nullptr;
+        g.wave_tmax = tail_chunked ? wave_tmax : 0;
         if ((rc = check_hip(launch_gen_state(g, stream), "state score launch"))) return rc;
-        if (wave) return check_hip(launch_gen_viterbi_wave(g, stream), "viterbi launch");
-        return check_hip(launch_gen_viterbi(g, stream), "viterbi launch");
+        if (!wave) return check_hip(launch_gen_viterbi(g, stream), "viterbi launch");
+        if (!tail_chunked || g.n_chunks <= 0) return check_hip(launch_gen_viterbi_wave(g, stream), "viterbi launch");
+        // the long tail (chunked kernels: short in work, long in dependent launches) NEXT TO the waves of the other contigs:
+        // forked onto the plan's side stream behind the state scores, joined before anything later on the caller's stream.
+        // The two write disjoint genes, contigs and back-pointer regions (a chunkless contig's path score is the waves').
+        if (!p.side_stream) {
+            if ((rc = check_hip(hipStreamCreateWithFlags(&p.side_stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
+            if ((rc = check_hip(hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming), "hipEventCreate"))) return rc;
+            if ((rc = check_hip(hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming), "hipEventCreate"))) return rc;
+        }
+        if ((rc = check_hip(hipEventRecord(p.ev_fork, stream), "hipEventRecord"))) return rc;
+        if ((rc = check_hip(hipStreamWaitEvent(p.side_stream, p.ev_fork, 0), "hipStreamWaitEvent"))) return rc;
+        if ((rc = check_hip(launch_gen_viterbi(g, p.side_stream), "viterbi launch"))) return rc;
+        if ((rc = check_hip(hipEventRecord(p.ev_join, p.side_stream), "hipEventRecord"))) return rc;
+        if ((rc = check_hip(launch_gen_viterbi_wave(g, stream), "viterbi launch"))) return rc;
+        return check_hip(hipStreamWaitEvent(stream, p.ev_join, 0), "hipStreamWaitEvent");
     }
     a.y = d_y;
     a.score = d_score;

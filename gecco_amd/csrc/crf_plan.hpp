@@ -81,9 +81,17 @@ struct Plan {
     size_t seq_ws_cap = 0, gen_ws_cap = 0, seg_ws_cap = 0, win_scratch_cap = 0;
     // chunk tables of the any-L whole-contig kernels (first gene / contig of every chunk, chunks of every contig): they
     // depend on the plan's contigs and the chunk length only, so they are built and uploaded on first use
-    char *d_gen_tab = nullptr;
-    int32_t gen_tab_chunk = 0;
-    size_t gen_tab_nch = 0, gen_tab_off1 = 0, gen_tab_off2 = 0;
+    // Two sets: every contig (marginals, Viterbi of small models), and the contigs longer than `min_len` only (Viterbi of
+    // 17-32 labels: the long tail of a batch whose other contigs take the wave-per-contig kernel).
+    struct GenTab {
+        char *d = nullptr;
+        int32_t chunk = 0, min_len = -1;  // (chunk == 0: not built)
+        size_t nch = 0, off1 = 0, off2 = 0;
+    } gen_tab[2];
+    // Viterbi of 17-32 labels: the chunked kernels of a batch's long contigs run on a stream of the plan's own next to the
+    // wave-per-contig kernel of the others (forked from and joined to the caller's stream by events)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // Pipelined decode (plan_run_decode_pipelined): what the last call left for the next one -- the batch's score differences
     // in buffer `parity` of the workspace (pending) and the batch's CSR arrays, which the caller keeps alive until then.
     struct Pipe {

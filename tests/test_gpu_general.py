@@ -232,10 +232,11 @@ def test_contig_sequential_kernels(nat, L, monkeypatch):
 
 
 @pytest.mark.parametrize("L", [9, 13, 16, 17, 24, 32])
-@pytest.mark.parametrize("mode", ["wave", "chunked"])
+@pytest.mark.parametrize("mode", ["wave", "chunked", "split"])
 def test_viterbi_wave_per_contig(nat, L, mode, monkeypatch):
     """9 to 32 labels: one wave per contig (gl_viterbi_wave: partial maxima merged in ascending source order, back-pointers as
-    quads, scalar back-tracking) and the chunked kernels give CRFsuite's labels and scores -- contigs of 1 .. 1 500 genes (every
+    quads, scalar back-tracking), the chunked kernels, and the split (the longest contig chunked, the others by waves -- what
+    the plan does with the long tail of a batch) give CRFsuite's labels and scores -- contigs of 1 .. 1 500 genes (every
     remainder of the quads and of the sixteen-quad rounds), and integer weights, where ties decide (strict `<`, first arg max)."""
     from oracle import crf_oracle as orc
 
@@ -259,8 +260,9 @@ def test_viterbi_wave_per_contig(nat, L, mode, monkeypatch):
 
 
 def test_viterbi_wave_is_chosen_for_batches_of_many_contigs(nat, monkeypatch):
-    """The plan takes the wave-per-contig kernel when (longest contig) x 85 <= genes of the batch (17 <= L < 28; x 60 above), the
-    chunked kernels otherwise: both give the oracle's labels; the choice only shows in the time."""
+    """Above 16 labels the plan splits a batch by its cost model: the long tail of the contig lengths through the chunked
+    kernels, the rest through the wave-per-contig kernel (all of it, or none): every choice gives the oracle's labels; the
+    choice only shows in the time."""
     from oracle import crf_oracle as orc
 
     monkeypatch.delenv("GECCO_CRF_GENERAL_VITERBI", raising=False)
@@ -268,7 +270,7 @@ def test_viterbi_wave_is_chosen_for_batches_of_many_contigs(nat, monkeypatch):
     L = 20
     w, trans = synth_model(200, rng, L=L)
     model = nat.Model.from_tables(w, trans)
-    for lengths in ([50] * 400, [3000, 20, 20]):  # (many short contigs, 50 x 85 <= 20 000: wave; one long contig: chunked)
+    for lengths in ([50] * 400, [3000, 20, 20], [60] * 300 + [900, 2500], [0, 0, 5, 0]):  # (all waves; chunked; split; empties)
         cptr, gptr, attr = synth_contigs(rng, lengths, 200)
         y, sc = model.viterbi(cptr, gptr, attr)
         ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
