@@ -236,6 +236,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     }
     p.gen_small = false;
     p.gen_tab[0].chunk = p.gen_tab[1].chunk = 0;  // (chunk tables of the previous contigs)
+    p.gen_wave_tmax = INT32_MIN;
     p.pipe = Plan::Pipe{};  // (score differences and CSR pointers of the previous layout)
     p.csr_begin = p.csr_end = -1;  // (the owner sets them after the build, for the batch at hand)
     p.model = &m;
@@ -1063,6 +1064,8 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
             const int forced = !env ? -1 : env[0] == 'w' ? 1 : env[0] == 'c' ? 0 : env[0] == 's' ? 2 : -1;
             if (forced == 1) {
                 wave_tmax = 0;
+            } else if (forced < 0 && p.gen_wave_tmax != INT32_MIN) {
+                wave_tmax = p.gen_wave_tmax;  // (chosen when this layout was first decoded: the sort below is the host's only loop)
             } else if (forced == 2 || (forced < 0 && L > 12)) {
                 std::vector<int32_t> len(size_t(p.n_contigs));
                 for (int32_t c = 0; c < p.n_contigs; ++c) len[size_t(c)] = p.contig_ptr[c + 1] - p.contig_ptr[c];
@@ -1087,6 +1090,7 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
                     if (double(tail) * t_gene + t_launches > best) break;  // (cannot get better from here)
                 }
                 if (wave_tmax > 0 && len[0] <= wave_tmax) wave_tmax = 0;  // (nothing is longer: no tail)
+                if (forced < 0) p.gen_wave_tmax = wave_tmax;
             }
         }
         GenArgs g;
