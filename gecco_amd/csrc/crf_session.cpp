@@ -596,7 +596,7 @@ T *mapped_or_null(T *host) {
 
 // Direct path: what submit_uploads does on the upload stream, done by the host and by address.  The chunk (= the whole batch)
 // gets device-visible addresses for its arrays: a copy in the lane's pinned staging block (a 50-gene contig: 600 bytes) that
-// the kernels read in place; for an array of 64 KB and more, device memory filled by a copy command on the COMPUTE stream.
+// the kernels read in place; for an array of 256 KB and more, device memory filled by a copy command on the COMPUTE stream.
 // Outputs are written by the kernels into pinned host memory: the caller's own buffer where it is pinned and large enough to
 // be worth asking, the staging block otherwise.  The compact wire format is undone on the way (row pointers are the caller's
 // gene_ptr; 16-bit indices are widened by the staging copy), so no launch has to.
@@ -629,10 +629,14 @@ int submit_direct_arrays(RunCtx &X, Lane &ln, int chunk_index) {
         nb = size_t(b1 - b0);
     }
     constexpr size_t kAsk = 32768;  // bytes from which a caller's OUTPUT buffer is asked whether it is pinned
-    // An input array of kCopy bytes and more goes to device memory by a copy command on the compute stream (2.5 us + the
-    // transfer, against a PCIe round trip for every tile that reads it in place: break-even near 10 000 genes); smaller ones
-    // are read from the staging block.
-    constexpr size_t kCopy = 65536;
+    // An input array of kCopy bytes and more goes to device memory by a copy command on the compute stream (~8 us of engine
+    // turnaround + the transfer, against a PCIe round trip for every tile that reads it in place); smaller ones are read from
+    // the staging block.  tools/direct_sweep.py, us per windowed call at 20 000 / 40 000 / 65 000 genes: copy from 64 KB on
+    // 47.6 / 53.5 / 61.1, from 256 KB 34.0 / 44.2 / 49.7, from 1 MB 34.6 / 42.0 / 55.5.  (GECCO_CRF_DIRECT_COPY_BYTES: A/B runs)
+    static const size_t kCopy = [] {
+        const char *e = std::getenv("GECCO_CRF_DIRECT_COPY_BYTES");
+        return e ? size_t(std::atoll(e)) : size_t(262144);
+    }();
     const bool c_gp = (ng + 1) * 4 >= kCopy, c_at = nnz * 4 >= kCopy && !r.attr_id16;
     if (c_gp) {
         if ((rc = ln.d_gp.reserve((ng + 1) * 4, "hipMalloc gene_ptr"))) return rc;
