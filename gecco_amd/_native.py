@@ -713,7 +713,8 @@ class Session:
 
     def set_direct_genes(self, genes: int) -> None:
         """Largest batch (genes) that takes the direct path -- one chunk, kernels on pinned host memory, no copy commands
-        (`gecco_crf_session_set_direct_genes`; 0: never)."""
+        (`gecco_crf_session_set_direct_genes`; 0: never; -1: the defaults -- every one-chunk batch on a one-device session,
+        131 072 genes on a session over several devices, 65 536 for cluster calls)."""
         _check(self._lib.gecco_crf_session_set_direct_genes(self._h, int(genes)))
 
     def stats(self) -> dict:

@@ -225,12 +225,19 @@ struct Session {
     int32_t chunk_genes = 1 << 19;
     std::mutex mu;  // one batch at a time per session
     // Batches of at most this many genes take the DIRECT path: one chunk, no copy commands, no second stream -- the kernels read
-    // the arrays from pinned host memory and write their outputs there, the host waits for the compute stream.
-    // GECCO_CRF_DIRECT_GENES overrides (0: never).
-    // Measured (tools/direct_sweep.py, pinned buffers, us per call direct / chunked): marginals 33 / 61 at 2 000 genes, 33 / 78 at
-    // 10 000, 62 / 97 at 65 000, 105 / 140 at 200 000; cluster rows 62 / 72, 63 / 91, 91 / 94, 121 / 113: the refiner's seven
-    // short launches sit in one stream behind the tiles either way, so cluster calls stop at half the size.
-    int32_t direct_genes = 1 << 17;
+    // the arrays from pinned host memory (or from device memory filled by a copy on the compute stream) and write their outputs
+    // there, the host waits for the compute stream.  gecco_crf_session_set_direct_genes / GECCO_CRF_DIRECT_GENES
+    // override (0: never); -1 = the defaults below.
+    // Measured (tools/direct_sweep.py, pinned buffers, us per call direct / ONE chunk through the three streams): marginals
+    // 33 / 62 at 2 000 genes, 33 / 80 at 10 000, 51 / 98 at 65 000, 106 / 147 at 200 000, 206 / 237 at 500 000 -- a batch that is
+    // one chunk anyway is faster direct; decode calls likewise (206 / 213 at 500 000).  Cluster rows 59 / 74, 62 / 91, 90 / 95,
+    // 104 / 99 at 100 000: the refiner's seven short launches sit behind the tiles either way, so cluster calls stop at 65 536.
+    // A session over several devices keeps 131 072: beyond, its chunks run on all of them at once.
+    int32_t direct_genes = -1;
+    int32_t direct_limit(bool want_segments) const {
+        if (direct_genes >= 0) return want_segments ? direct_genes / 2 : direct_genes;
+        return want_segments ? (1 << 16) : devs.size() > 1 ? (1 << 17) : (1 << 19);
+    }
     bool reference_bits = false;  // windowed marginals in CRFsuite's operation order (crf_exact.hip): the reference's bits
     SessionStats stats;
     ~Session();
@@ -328,7 +335,7 @@ void session_set_reference_bits(Session &s, bool on) {
 }
 void session_set_direct_genes(Session &s, int32_t genes) {
     std::lock_guard<std::mutex> lock(s.mu);
-    s.direct_genes = std::max(0, genes);
+    s.direct_genes = genes < 0 ? -1 : genes;  // (-1: the defaults)
 }
 SessionStats session_stats(const Session &s) { return s.stats; }
 
@@ -1129,7 +1136,7 @@ int session_run(Session &S, const BatchRequest &r) {
     std::vector<Chunk> chunks;
     // a small batch is ONE chunk on the first device, its kernels working on pinned host memory (no copy commands)
     // (a caller who asked for chunks smaller than the batch gets chunks)
-    const bool direct = n_genes > 0 && n_genes <= std::min(r.want_segments ? S.direct_genes / 2 : S.direct_genes, S.chunk_genes) && !full && !r.score_out;
+    const bool direct = n_genes > 0 && n_genes <= std::min(S.direct_limit(r.want_segments), S.chunk_genes) && !full && !r.score_out;
     if (direct) {
         Chunk ck;
         ck.c1 = r.n_contigs;

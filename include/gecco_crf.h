@@ -239,9 +239,12 @@ int gecco_crf_session_set_chunk_genes(gecco_crf_session *s, int32_t genes); /* d
  * /root/reference/tests/test_cli/test_run.py:35-70 -- take the DIRECT path: the batch is one chunk, its arrays are read by the
  * kernels from pinned host memory (the caller's own buffers when they come from gecco_crf_host_alloc and are large enough for
  * that to matter, a pinned staging copy otherwise) and its outputs are written there; no copy command, no second stream, the
- * call is its launches and one wait (input arrays of 64 KB and more are copied to device memory by a copy command on that same
- * stream).  `genes` = largest batch that takes it (default 131072, half of that for cluster calls; 0 = never; never more
- * than the chunk size).  Same output bits as the chunked path.  Whole-contig marginals and path scores always take the chunked path. */
+ * call is its launches and one wait (input arrays of 256 KB and more are copied to device memory by a copy command on that same
+ * stream).  `genes` = largest batch that takes it (half of that for cluster calls; 0 = never; never more than the chunk size;
+ * -1 = the defaults: every batch that is one chunk anyway -- 2^19 genes -- on a one-device session, 131072 on a session over
+ * several devices, 65536 for cluster calls).  Same output bits as the chunked path up to the last ulp of the 0.3 % of windows
+ * that take the max-normalised form (reference-bits mode: the same bits).  Whole-contig marginals and path
+ * scores always take the chunked path. */
 int gecco_crf_session_set_direct_genes(gecco_crf_session *s, int32_t genes);
 /* Figures of the last batch (any pointer may be NULL). */
 int gecco_crf_session_stats(const gecco_crf_session *s, int32_t *n_chunks, int64_t *h2d_bytes,
