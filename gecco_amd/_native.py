@@ -172,6 +172,30 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_hip_runtime() -> Optional[str]:
+    """A PyTorch wheel carries its own copy of libamdhip64 (same SONAME as the system's), and whichever copy a process loads
+    first serves everybody: loaded second, torch's copy finds no device.  So that the import order does not matter, the wheel's
+    copy -- when there is a torch to import later -- is loaded here, before libgecco_crf.so pulls in the system's
+    (`GECCO_AMD_HIP_RUNTIME=system` keeps the system's; a process that has imported torch already has made the choice)."""
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("GECCO_AMD_HIP_RUNTIME", "") == "system":
+        return None
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return None
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if not os.path.exists(cand):
+            return None
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        return cand
+    except Exception:  # (any trouble: the system's runtime serves, as before)
+        return None
+
+
 def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     """dlopen the native library and bind every declared symbol (raises if any is missing)."""
     global _lib
@@ -183,6 +207,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
             f"{p} not found: build it with `python -m gecco_amd.build` (hipcc, gfx950). "
             "gecco_amd has no CPU fallback."
         )
+    _preload_hip_runtime()
     lib = ctypes.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

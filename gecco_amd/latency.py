@@ -312,8 +312,11 @@ def cold_process(device=0, n_genes=50):
     return {"genes": int(cptr[-1]), "devices": nd, "dlopen_us": us[0], "hip_runtime_start_us": us[1], "unpickle_md5_us": us[2],
             "model_parse_us": us[3], "session_create_us": us[4], "first_call_us": us[5], "second_call_us": us[6],
             "same_result": bool(np.array_equal(p1, p2)),
-            "note": "a fresh Python process without torch (the system's HIP runtime): first_call = code object load + device "
-                    "allocations + weight tables + launch; pageable numpy buffers through Session.windowed_marginals"}
+            "hip_runtime": next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln), None),
+            "note": "a fresh Python process without torch: first_call = code object load + device allocations + weight tables + "
+                    "launch; pageable numpy buffers through Session.windowed_marginals.  Where a PyTorch wheel is installed the "
+                    "library loads the wheel's copy of the HIP runtime (so that a later `import torch` still finds the device): "
+                    "larger libraries, ~70 ms more; GECCO_AMD_HIP_RUNTIME=system keeps the system's copy"}
 
 
 def main(argv=None):
