@@ -179,3 +179,27 @@ def test_exp_correctly_rounded_against_decimal():
     assert got.tobytes() == want.tobytes()
     assert np.isnan(_native.exp_correctly_rounded(np.array([np.nan]))[0])
     assert _native.exp_correctly_rounded(np.array([800.0]))[0] == np.inf and _native.exp_correctly_rounded(np.array([-800.0]))[0] == 0.0
+
+
+def test_library_loads_the_wheels_hip_runtime_first():
+    """A process that loads the library and imports torch afterwards must end up with ONE copy of libamdhip64 (the wheel's, when
+    a torch is installed): loaded second, torch's copy would find no device.  GECCO_AMD_HIP_RUNTIME=system
+    keeps the system's copy."""
+    import importlib.util
+    import subprocess
+    import sys
+
+    if importlib.util.find_spec("torch") is None:
+        pytest.skip("no torch wheel here: the system's runtime is the only one")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from gecco_amd import _native\n_native.load_library()\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\nprint(libs)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    libs = eval(out.stdout.strip().splitlines()[-1])
+    assert len(libs) == 1 and "/torch/lib/" in libs[0], libs
+    env = dict(os.environ, GECCO_AMD_HIP_RUNTIME="system")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr
+    libs = eval(out.stdout.strip().splitlines()[-1])
+    assert len(libs) == 1 and "/torch/" not in libs[0], libs
