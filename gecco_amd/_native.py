@@ -733,7 +733,7 @@ class Session:
 
     def set_reference_bits(self, on: bool = True) -> None:
         """Windowed marginals in CRFsuite's own operation order with a correctly rounded exp: the reference's output files bit
-        for bit, at about eight times the fast kernels' time (`gecco_crf_session_set_reference_bits`)."""
+        for bit, at about six times the fast kernels' time (`gecco_crf_session_set_reference_bits`)."""
         _check(self._lib.gecco_crf_session_set_reference_bits(self._h, int(bool(on))))
 
     def set_direct_genes(self, genes: int) -> None:

@@ -107,7 +107,7 @@ struct Plan {
                                          // one copy and one inter-copy gap less per chunk; they are ~0.1 MB, read once)
     int64_t csr_begin = -1, csr_end = -1;  // gene_ptr[0] / gene_ptr[n_genes] when the owner knows them (batch driver's direct path), else -1
     // Reference-bits mode (crf_exact.hip): windowed marginals in CRFsuite's own operation order with a correctly rounded exp --
-    // the reference's output files bit for bit, at about eight times the fast kernels' time.  Set by the owner before
+    // the reference's output files bit for bit, at about six times the fast kernels' time.  Set by the owner before
     // plan_build (batch driver: gecco_crf_session_set_reference_bits); GECCO_CRF_REFERENCE_BITS=1 sets it for every plan.
     bool reference_bits = false;
     bool reference_now = false;  // (this layout runs in reference-bits mode: reference_bits, or the environment)

@@ -255,7 +255,7 @@ int gecco_crf_session_stats(const gecco_crf_session *s, int32_t *n_chunks, int64
  * digits).  With this switch on, the session's windowed marginals -- and so its cluster calls and the p of its decode calls --
  * are computed in CRFsuite's OWN operation order ([EXT] crf1dc_exp_state / alpha_score / beta_score / marginal_point as
  * restated in oracle/crf_oracle.c) with a correctly rounded exp in place of libm's: the reference's bits wherever its libm
- * rounds correctly (glibc: all but ~0.07 % of arguments), at about eight times the fast kernels' time.  2-label models, windows
+ * rounds correctly (glibc: all but ~0.07 % of arguments), at about six times the fast kernels' time.  2-label models, windows
  * of at most 32 genes (GECCO_CRF_EUNSUPPORTED otherwise).  GECCO_CRF_REFERENCE_BITS=1 switches it on for every session and plan. */
 int gecco_crf_session_set_reference_bits(gecco_crf_session *s, int32_t on);
 /* The exp that mode uses, on the host (a double-double evaluation; same code as the device's): out[i] = the double nearest to
