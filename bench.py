@@ -571,7 +571,7 @@ def main() -> None:
             lv["predict_tables"] = levels.tables_level(golden)
             lv["object_api"] = levels.object_level(golden)
             lv["class_levels_mode"] = ("predict_tables / object_api run ClusterCRF's default: reference-bits mode (csrc/crf_exact.hip, "
-                                       "6x the fast window kernel's time on C3 -- invisible at these levels)")
+                                       "5.4x the fast window kernel's time on C3 -- invisible at these levels)")
         except Exception as err:
             lv["error"] = f"{type(err).__name__}: {err}"
         out["levels"] = lv

@@ -67,11 +67,12 @@ struct RefArgs {
 // memory, no zeroed array (a gene no window covers gets its 0.0 here: numpy.zeros, crf/__init__.py:251), and p may live in host
 // memory.  The exponentials of the tile's slots (and the slot -> gene map) are staged in LDS once, padding items as (1, 1).
 // OWN_EXP (a handful of tiles: one launch instead of two, the W - 1 front slots exponentiated twice).
-template <bool OWN_EXP>
-__global__ void __launch_bounds__(kRefT, 2) crf_windowed_reference_l2(const RefArgs A) {
-    __shared__ double2 Es[kRefT + kRefMaxW];
-    __shared__ unsigned long long best[kRefT + kRefMaxW];
-    __shared__ int gslot[kRefT + kRefMaxW];
+// WT: compile-time bound of the window size (20 = GECCO's own: the registers of twelve steps fewer buy another wave per SIMD)
+template <bool OWN_EXP, int WT>
+__global__ void __launch_bounds__(kRefT, WT <= 20 ? 5 : 2) crf_windowed_reference_l2(const RefArgs A) {
+    __shared__ double2 Es[kRefT + WT];
+    __shared__ unsigned long long best[kRefT + WT];
+    __shared__ int gslot[kRefT + WT];
     const int W = A.W;
     const int out = kRefT - (W - 1);                  // slots this tile owns
     const int own0 = blockIdx.x * out;                // the first of them
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(kRefT, 2) crf_windowed_reference_l2(const RefA
     const bool mine = q >= 0 && q < A.S && ((A.start_bits[q >> 6] >> (q & 63)) & 1ull);
     if (mine) {
         const int base = threadIdx.x;
-        double al[kRefMaxW], sc[kRefMaxW];  // alpha of the asked label, scale factors
+        double al[WT], sc[WT];  // alpha of the asked label, scale factors
         double p0, p1;
         // ---- [EXT] crf1dc_alpha_score
         {
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(kRefT, 2) crf_windowed_reference_l2(const RefA
             sc[0] = c;
         }
 #pragma unroll
-        for (int t = 1; t < kRefMaxW; ++t) {
+        for (int t = 1; t < WT; ++t) {
             if (t < W) {
                 const double2 e = Es[base + t];
                 double x0 = p0 * A.t00, x1 = p0 * A.t01;  // cur[j] = 0 + prev[0] * trans[0][j]
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(kRefT, 2) crf_windowed_reference_l2(const RefA
         // ---- [EXT] crf1dc_beta_score + crf1dc_marginal_point, back to front
         double b0 = 0.0, b1 = 0.0;
 #pragma unroll
-        for (int t = kRefMaxW - 1; t >= 0; --t) {
+        for (int t = WT - 1; t >= 0; --t) {
             if (t < W) {
                 if (t == W - 1) {
                     b0 = b1 = sc[t];
@@ -198,9 +199,15 @@ hipError_t launch_windowed_reference(const WinArgs &w, const double2 *wtab01, co
     a.t10 = exp_trans_host[2];
     a.t11 = exp_trans_host[3];
     if (own_exp)
-        hipLaunchKernelGGL(crf_windowed_reference_l2<true>, dim3(tiles), dim3(kRefT), 0, stream, a);
+        if (w.W <= 20)
+            hipLaunchKernelGGL((crf_windowed_reference_l2<true, 20>), dim3(tiles), dim3(kRefT), 0, stream, a);
+        else
+            hipLaunchKernelGGL((crf_windowed_reference_l2<true, kRefMaxW>), dim3(tiles), dim3(kRefT), 0, stream, a);
     else
-        hipLaunchKernelGGL(crf_windowed_reference_l2<false>, dim3(tiles), dim3(kRefT), 0, stream, a);
+        if (w.W <= 20)
+            hipLaunchKernelGGL((crf_windowed_reference_l2<false, 20>), dim3(tiles), dim3(kRefT), 0, stream, a);
+        else
+            hipLaunchKernelGGL((crf_windowed_reference_l2<false, kRefMaxW>), dim3(tiles), dim3(kRefT), 0, stream, a);
     return hipGetLastError();
 }
 
