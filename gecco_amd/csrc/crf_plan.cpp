@@ -338,6 +338,9 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
             return e ? std::atoll(e) : int64_t(kWinTiles1MaxSlots);
         }();
         if (!env && !p.general && W == 20 && p.S > 2 * (kWinThreads - (W - 1)) && p.S <= tiles1_max) p.tiles_per_wg = 1;
+        // windows other than GECCO's 20 take the dynamic-W instantiation, whose two-tile form spills scalar registers: one tile
+        // (tools/window_size_sweep.py, 1 M genes, two / one tile: W = 5 19.9 / 17.1 us, W = 10 22.9 / 19.2, W = 32 76 / 69)
+        if (!env && !p.general && W != 20) p.tiles_per_wg = 1;
     }
     // window-start flags per slot (_meta.py:131: starts at 0, step, 2*step, ... <= n' - W)
     // one zero word in front (slots -64 .. -1: the lead-in of the first workgroup) and kStartBitsTail behind (the reach of
