@@ -26,6 +26,7 @@
 //                their gene offsets and -- on request -- the probabilities of their genes (what a cluster table needs of p)
 // Bound: HBM, 2 x 10 B/gene read + 4 B/gene written; four short launches (round 3: six + the gather).
 #include <algorithm>
+#include <cstdlib>
 
 #include "crf_device.hpp"
 #include "crf_scan.hpp"
@@ -83,8 +84,9 @@ __device__ __forceinline__ LaneIn load_lane(const SegArgs &A, Stage &stg) {
 // flags[g]: bit0 = first gene of a contig, bit1 = last gene (the layout of the plan's whole-contig tables).  One lane per
 // eight genes: it finds the contig of its first gene in the contig table (a binary search through L2-resident words) and
 // walks from there -- every byte of the array is written, by one launch (no memset before it).
-__global__ void __launch_bounds__(kT) seg_flags(const int32_t *__restrict__ cptr, int n_contigs, int n_genes, uint8_t *__restrict__ flags) {
-    const int g0 = (blockIdx.x * kT + threadIdx.x) * 8;
+__device__ __forceinline__ void seg_flags_body(const int32_t *__restrict__ cptr, int n_contigs, int n_genes, uint8_t *__restrict__ flags,
+                                               const int word_index) {
+    const int g0 = word_index * 8;
     if (g0 >= n_genes + 8) return;
     uint64_t word = 0;
     if (g0 < n_genes) {
@@ -109,8 +111,11 @@ __global__ void __launch_bounds__(kT) seg_flags(const int32_t *__restrict__ cptr
     }
     *reinterpret_cast<uint64_t *>(flags + g0) = word;
 }
+__global__ void __launch_bounds__(kT) seg_flags(const int32_t *__restrict__ cptr, int n_contigs, int n_genes, uint8_t *__restrict__ flags) {
+    seg_flags_body(cptr, n_contigs, n_genes, flags, blockIdx.x * kT + threadIdx.x);
+}
 
-__global__ void __launch_bounds__(kT) seg_fold(const SegArgs A) {
+__device__ __forceinline__ void seg_fold_body(const SegArgs &A) {
     __shared__ Stage stg;
     __shared__ SegE lds[kT / 64];
     const LaneIn L = load_lane(A, stg);
@@ -133,6 +138,7 @@ __global__ void __launch_bounds__(kT) seg_fold(const SegArgs A) {
     A.lane[blockIdx.x * kT + threadIdx.x] = excl;
     if (threadIdx.x == 0) A.block[blockIdx.x] = total;
 }
+__global__ void __launch_bounds__(kT) seg_fold(const SegArgs A) { seg_fold_body(A); }
 
 // Product of the elements e[0 .. n) in order, by ONE wave (every wave of a workgroup for itself: no barrier): 64 at a time.
 __device__ __forceinline__ SegE wave_prefix_total(const SegE *__restrict__ e, int n) {
@@ -147,7 +153,7 @@ __device__ __forceinline__ SegE wave_prefix_total(const SegE *__restrict__ e, in
     return acc;
 }
 
-__global__ void __launch_bounds__(kT) seg_replay(const SegArgs A) {
+__device__ __forceinline__ void seg_replay_body(const SegArgs &A) {
     __shared__ Stage stg;
     const LaneIn L = load_lane(A, stg);
     // what the workgroups before this one do to the grouper (the only serial step of round 3, a launch of its own then)
@@ -157,7 +163,7 @@ __global__ void __launch_bounds__(kT) seg_replay(const SegArgs A) {
         *A.n_raw = int32_t(all.ng0);  // the batch is entered "out"
         A.pre[A.n_genes] = int32_t(all.ann);
     }
-    if (L.cnt <= 0) return;
+    if (L.cnt <= 0) return;  // (no barrier below this line)
     const SegE X = A.lane[blockIdx.x * kT + threadIdx.x];
     const uint32_t sb = B.map & 1u;  // the batch is entered "out": evaluate every map at 0
     uint32_t st = (X.map >> sb) & 1u;
@@ -199,6 +205,7 @@ __global__ void __launch_bounds__(kT) seg_replay(const SegArgs A) {
         for (int k = 0; k < L.cnt; ++k) A.pre[L.g0 + k] = pre[k];
     }
 }
+__global__ void __launch_bounds__(kT) seg_replay(const SegArgs A) { seg_replay_body(A); }
 
 // smallest i in [lo, hi) with a[i] > v (hi if none)
 __device__ __forceinline__ int upper_bound_i32(const int32_t *__restrict__ a, int lo, int hi, int v) {
@@ -209,7 +216,7 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t *__restrict__ a, in
     return lo;
 }
 
-__global__ void __launch_bounds__(kT) seg_validate(const SegArgs A) {
+__device__ __forceinline__ void seg_validate_body(const SegArgs &A) {
     const int n_raw = *A.n_raw;
     const int ntile = (n_raw + kT - 1) / kT;
     for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
@@ -283,13 +290,14 @@ __global__ void __launch_bounds__(kT) seg_validate(const SegArgs A) {
         __syncthreads();
     }
 }
+__global__ void __launch_bounds__(kT) seg_validate(const SegArgs A) { seg_validate_body(A); }
 
 // Ordered compaction of the kept rows.  A workgroup takes tiles t, t + G, ...; (rows, genes) kept in the tiles before
 // a tile are summed by every wave for itself (64 tiles per step), carried from the workgroup's previous tile.  Kept rows go
 // to A.seg, their gene offsets to A.seg_off; with A.gout the probabilities of a row's genes follow row after row (a wave
 // copies the rows of its 64 lanes one after the other, coalesced).  The batch driver points all three at pinned HOST memory:
 // everything is read from device memory and only written across PCIe (posted writes).
-__global__ void __launch_bounds__(kT) seg_compact(const SegArgs A) {
+__device__ __forceinline__ void seg_compact_body(const SegArgs &A) {
     __shared__ U2 lds[kT / 64];
     const int n_raw = *A.n_raw;
     const int ntile = (n_raw + kT - 1) / kT;
@@ -346,6 +354,30 @@ __global__ void __launch_bounds__(kT) seg_compact(const SegArgs A) {
             if (A.seg_off && int(before.x) <= A.max_seg) A.seg_off[before.x] = int32_t(before.y);
         }
     }
+}
+__global__ void __launch_bounds__(kT) seg_compact(const SegArgs A) { seg_compact_body(A); }
+
+// A batch of ONE workgroup's worth of genes (kBlockGenes = 2 048: one genome's contig, C1): the five launches above as one --
+// "the workgroups before this one" are none, every reduction over workgroups is empty, and what a stage reads of the stage
+// before it was written by lanes of the same workgroup (a barrier and a workgroup-scope fence in between).  The one place
+// where a lane leaves a stage early (seg_replay_body) has no barrier behind it inside the stage.
+__global__ void __launch_bounds__(kT) seg_small(const SegArgs A, const int build_flags) {
+    if (build_flags) {
+        for (int w = threadIdx.x; w * 8 < A.n_genes + 8; w += kT)
+            seg_flags_body(A.cptr, A.n_contigs, A.n_genes, const_cast<uint8_t *>(A.flags), w);
+        __threadfence_block();
+        __syncthreads();
+    }
+    seg_fold_body(A);
+    __threadfence_block();
+    __syncthreads();
+    seg_replay_body(A);
+    __threadfence_block();
+    __syncthreads();
+    seg_validate_body(A);
+    __threadfence_block();
+    __syncthreads();
+    seg_compact_body(A);
 }
 
 inline size_t align256s(size_t x) { return (x + 255) & ~size_t(255); }
@@ -415,6 +447,15 @@ hipError_t launch_segment(const double *d_p, const uint8_t *d_ann, const uint8_t
     a.gcap = gather_cap;
     a.row_c0 = params.row_contig0;
     a.row_g0 = params.row_gene0;
+    static const bool fused_small = [] {  // GECCO_CRF_SEGMENT_FUSED=0: the five launches for every batch (tests, A/B)
+        const char *e = std::getenv("GECCO_CRF_SEGMENT_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    if (nb == 1 && fused_small) {
+        a.flags = d_flags ? d_flags : own_flags;
+        hipLaunchKernelGGL(seg_small, dim3(1), dim3(kT), 0, stream, a, d_flags ? 0 : 1);
+        return hipGetLastError();
+    }
     if (!d_flags) {
         hipLaunchKernelGGL(seg_flags, dim3(unsigned((n / 8 + 1 + kT - 1) / kT)), dim3(kT), 0, stream, d_cptr, n_contigs, n_genes, own_flags);
         d_flags = own_flags;
