@@ -957,18 +957,32 @@ __device__ __forceinline__ void chunk_walk_fwd(const GenArgs &a, long long ct, i
     const double ninf = -__builtin_huge_val();
     const int c0 = a.cc_ptr[ct], c1 = a.cc_ptr[ct + 1];
     double v = MAXPLUS ? (j == 0 ? 0.0 : ninf) : (j == 0 ? 1.0 : 0.0);
+    // (round 5: the columns of the NEXT B chunks are on their way while the current B steps are taken -- the round trip to
+    // memory per batch of chunks was all a step waited for)
+    double mn[B][LP];
+    int en[B];
+    auto fetch = [&](const int cb) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int c = cb + b;
+            const bool live = on && c + 1 < c1;  // (nothing leaves the contig's last chunk)
+            const double *M = a.chM + static_cast<size_t>(live ? c : c0) * L * L;
+#pragma unroll
+            for (int k = 0; k < LP; ++k) mn[b][k] = (live && k < L) ? M[static_cast<size_t>(k) * L + j] : (MAXPLUS ? ninf : 0.0);
+            en[b] = (!MAXPLUS && live) ? a.chEx[static_cast<size_t>(c) * L + j] : 0;
+        }
+    };
+    if (c0 < c1) fetch(c0);
     for (int cb = c0; cb < c1; cb += B) {
         double mc[B][LP];
         int ex[B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
-            const int c = cb + b;
-            const bool live = on && c + 1 < c1;  // (nothing leaves the contig's last chunk)
-            const double *M = a.chM + static_cast<size_t>(c) * L * L;
+            ex[b] = en[b];
 #pragma unroll
-            for (int k = 0; k < LP; ++k) mc[b][k] = (live && k < L) ? M[static_cast<size_t>(k) * L + j] : (MAXPLUS ? ninf : 0.0);
-            ex[b] = (!MAXPLUS && live) ? a.chEx[static_cast<size_t>(c) * L + j] : 0;
+            for (int k = 0; k < LP; ++k) mc[b][k] = mn[b][k];
         }
+        if (cb + B < c1) fetch(cb + B);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const int c = cb + b;
@@ -1006,18 +1020,30 @@ __device__ __forceinline__ void chunk_walk_bwd(const GenArgs &a, long long ct, i
     const bool on = j < L;
     const int c0 = a.cc_ptr[ct], c1 = a.cc_ptr[ct + 1];
     double bt = 1.0;
-    for (int cb = c1 - 1; cb >= c0; cb -= B) {
-        double mr[B][LP];
-        int ex[B];
+    double mn[B][LP];
+    int en[B];
+    auto fetch = [&](const int cb) {  // (the rows of the next B chunks towards the front: on their way during the current steps)
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const int c = cb - b;
             const bool live = on && c > c0;  // (nothing is in front of the contig's first chunk)
             const double *row = a.chM + (static_cast<size_t>(live ? c : c0) * L + (on ? j : 0)) * L;
 #pragma unroll
-            for (int k = 0; k < LP; ++k) mr[b][k] = (live && k < L) ? row[k] : 0.0;
-            ex[b] = live ? a.chEx[static_cast<size_t>(c) * L + j] : 0;
+            for (int k = 0; k < LP; ++k) mn[b][k] = (live && k < L) ? row[k] : 0.0;
+            en[b] = live ? a.chEx[static_cast<size_t>(c) * L + j] : 0;
         }
+    };
+    if (c1 > c0) fetch(c1 - 1);
+    for (int cb = c1 - 1; cb >= c0; cb -= B) {
+        double mr[B][LP];
+        int ex[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            ex[b] = en[b];
+#pragma unroll
+            for (int k = 0; k < LP; ++k) mr[b][k] = mn[b][k];
+        }
+        if (cb - B >= c0) fetch(cb - B);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const int c = cb - b;
