@@ -1078,7 +1078,7 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
                 // of one 1 519-gene contig: 270 us; at L = 16: 150 us)
                 const double t_step = L > 16 ? 0.36 : 0.25, t_gene = L >= 28 ? 6.3e-3 : L > 16 ? 4.3e-3 : 1.3e-3;
                 const double t_walk = L > 16 ? 0.07 : 0.04, t_launches = L > 16 ? 150.0 : 80.0;
-                const double all_chunked = double(p.n_genes) * t_gene + double(len[0]) * t_walk;  // (t_gene: a whole batch's rate)
+                const double all_chunked = double(p.n_genes) * t_gene + double(len[0]) * t_walk + t_launches;
                 double best = all_chunked;
                 int64_t tail = 0;
                 for (int32_t k = 0; k < p.n_contigs; ++k) {  // the k longest contigs chunked NEXT TO the waves of the others
