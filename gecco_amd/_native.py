@@ -93,11 +93,12 @@ SIGNATURES = {
     "gecco_crf_exp_correctly_rounded": (ctypes.c_int, [_c_f64p, ctypes.c_int64, _c_f64p]),
     "gecco_crf_session_windowed": (
         ctypes.c_int,
-        [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p],
+        # (array arguments as addresses: `ndarray.ctypes.data_as` costs 2 us per array, a quarter of a warm call on one contig)
+        [_vp, _vp, ctypes.c_int32, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp],
     ),
     "gecco_crf_session_windowed_degrees": (
         ctypes.c_int,
-        [_vp, _c_i32p, ctypes.c_int32, _c_i32p, _vp, _c_i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_f64p],
+        [_vp, _vp, ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp],
     ),
     "gecco_crf_session_decode": (
         ctypes.c_int,
@@ -765,13 +766,12 @@ class Session:
         assert out.dtype == np.float64 and out.flags.c_contiguous and out.size >= n
         if degree is not None:
             assert degree.dtype == np.uint8 and degree.flags.c_contiguous and degree.size >= n
-            _check(self._lib.gecco_crf_session_windowed_degrees(self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p),
-                                                                degree.ctypes.data if degree.size else None, _ptr(attr_id, _c_i32p),
-                                                                int(window), int(step), int(label), int(bool(pad)), _ptr(out, _c_f64p)))
+            _check(self._lib.gecco_crf_session_windowed_degrees(self._h, contig_ptr.ctypes.data, nc, gene_ptr.ctypes.data,
+                                                                degree.ctypes.data if degree.size else None, attr_id.ctypes.data,
+                                                                int(window), int(step), int(label), int(bool(pad)), out.ctypes.data))
             return out[:n]
-        _check(self._lib.gecco_crf_session_windowed(self._h, _ptr(contig_ptr, _c_i32p), nc, _ptr(gene_ptr, _c_i32p),
-                                                    _ptr(attr_id, _c_i32p), int(window), int(step), int(label), int(bool(pad)),
-                                                    _ptr(out, _c_f64p)))
+        _check(self._lib.gecco_crf_session_windowed(self._h, contig_ptr.ctypes.data, nc, gene_ptr.ctypes.data, attr_id.ctypes.data,
+                                                    int(window), int(step), int(label), int(bool(pad)), out.ctypes.data))
         return out[:n]
 
     def decode(self, contig_ptr, gene_ptr, attr_id, window, step=1, label=1, pad=True, out_p=None, out_y=None, degree=None,
