@@ -15,6 +15,7 @@ What differs is where the arithmetic runs: instead of one python-crfsuite call p
 window (``:253``), every contig of the call is packed into one CSR batch and scored by the
 HIP kernels through the C ABI (``include/gecco_crf.h``).  There is no CPU fallback.
 """
+import gc
 import itertools
 import operator
 import os
@@ -24,6 +25,7 @@ from typing import Any, Callable, Dict, FrozenSet, Iterable, List, Optional, Seq
 import numpy as np
 
 from . import _native, packing, pickle_model
+from ._objpath_loader import module as _objpath_module
 
 __all__ = ["ClusterCRF", "NotFittedError"]
 
@@ -187,6 +189,9 @@ def _annotate(gene: Any, gene_p: Optional[float], domain_p: Optional[List[float]
         d.with_cluster_weight(weights.get((d.name, "1"))) for d in gene.protein.domains))
 
 
+_PLAIN_MODELS: Dict[Any, bool] = {}  # (Gene, Protein, Domain classes) -> plain dataclasses with GECCO's field names?
+
+
 def _annotate_all(genes: List[Any], probs: List[float], w1: Dict[str, float]) -> Optional[List[Any]]:
     """`_annotate(gene, p, None, weights)` for a whole list of genes of ONE plain dataclass model (GECCO's, or this
     package's): the per-object work is two dict operations and nothing is looked up twice.  Returns None when the
@@ -201,19 +206,35 @@ def _annotate_all(genes: List[Any], probs: List[float], w1: Dict[str, float]) ->
         if g.protein.domains:
             dom_cls = type(g.protein.domains[0])
             break
+    # (the shape checks below look at classes and at the field names of one object of each: remembered per class triple --
+    # on a contig of a few dozen genes they cost as much as the copies)
+    known = _PLAIN_MODELS.get((gene_cls, prot_cls, dom_cls))
+    if known is not None:
+        if not known:
+            return None
+        native = _objpath_module()
+        if native is not None:
+            return native.annotate_all(genes, probs, w1, gene_cls, prot_cls, dom_cls)
+    key = (gene_cls, prot_cls, dom_cls)
     for obj, cls in ((g0, gene_cls), (g0.protein, prot_cls)):
         if not _is_dataclass(obj) or hasattr(cls, "__post_init__") or hasattr(cls, "__slots__") or not hasattr(obj, "__dict__"):
+            _PLAIN_MODELS[key] = False
             return None
     if dom_cls is not None and (not _IS_DATACLASS.setdefault(dom_cls, __import__("dataclasses").is_dataclass(dom_cls))
                                 or hasattr(dom_cls, "__post_init__") or hasattr(dom_cls, "__slots__")):
+        _PLAIN_MODELS[key] = False
         return None
     # ... with GECCO's field names (gecco/model.py:274-290,321-375): anything else goes through its own with_* methods
     if not {"protein", "qualifiers", "_probability"} <= g0.__dict__.keys() or "domains" not in g0.protein.__dict__:
+        _PLAIN_MODELS[key] = False
         return None
     if dom_cls is not None:
         d0 = next(g for g in genes if g.protein.domains).protein.domains[0]
         if not hasattr(d0, "__dict__") or not {"name", "probability", "cluster_weight", "qualifiers"} <= d0.__dict__.keys():
+            _PLAIN_MODELS[key] = False
             return None
+    if dom_cls is not None:  # (a batch without a single domain says nothing about the domain class: not remembered)
+        _PLAIN_MODELS[key] = True
     from ._objpath_loader import module
 
     native = module()  # csrc/objpath.c: the loop below against the CPython C API (tp_alloc + PyDict_Copy per object)
@@ -373,11 +394,9 @@ class ClusterCRF(object):
         contigs: Optional[List[List[Any]]] = None
         batch: Optional[packing.PackedBatch] = None
         if self.feature_type == "protein":
-            from ._objpath_loader import module as _objpath
-
             # csrc/objpath.c: ONE pass that checks the order, sorts the domain lists that need it, groups and packs the
             # features (:209-214) -- every object is visited once, while it is in cache
-            native = _objpath()
+            native = _objpath_module()
             if native is not None:
                 genes = genes if isinstance(genes, (list, tuple)) else list(genes)
                 got = native.sort_group(genes, operator.attrgetter("start"), self.model._attr_index)
@@ -434,8 +453,6 @@ class ClusterCRF(object):
         # Millions of small container objects are about to be allocated and none of them dies: the cyclic collector's
         # generational passes over the growing heap cost 6x the allocations themselves (measured: 430 -> 63 ms per 50 000
         # genes).  Collection is suspended for the loop and restored to what the caller had.
-        import gc
-
         gc_was_enabled = gc.isenabled()
         gc.disable()
         try:
