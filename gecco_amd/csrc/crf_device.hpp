@@ -315,6 +315,7 @@ hipError_t launch_gen_marginals(const GenArgs &a, hipStream_t stream);
 hipError_t launch_gen_viterbi(const GenArgs &a, hipStream_t stream);
 // 9 to 32 labels, batches of many contigs: one wave per contig, CRFsuite's sequential recursion (no chunk tables needed)
 hipError_t launch_gen_viterbi_wave(const GenArgs &a, hipStream_t stream);
+hipError_t launch_gen_marginals_wave(const GenArgs &a, hipStream_t stream);  // row F likewise (a.E, a.smax, a.alpha, a.scale)
 int gen_chunk_genes();
 
 // weighted domain composition of called clusters (crf_composition.hip); d_tmp: one double per domain row

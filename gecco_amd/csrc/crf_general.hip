@@ -772,6 +772,196 @@ __global__ void __launch_bounds__(kGT) gl_viterbi_wave(GenArgs a) {
     }
 }
 
+// ---- row F for 17 to 32 labels, batches of many contigs: one WAVE per contig ------------------------------------------
+// The same arrangement as gl_viterbi_wave for CRFsuite's scaled forward-backward recursion ([EXT] crf1dc_alpha_score /
+// beta_score / marginal_point): lane (j, h) holds label j and half of the other index, the halves' partial sums meet by one DPP
+// quad permute, the per-step sum over the labels (the scale factor's 1 / sum) is a DPP reduction inside the rows of sixteen
+// lanes and four v_readlane across them, emissions / alpha / scale factors are staged eight or sixteen genes ahead.  A
+// partial sum adds its terms in another order than the sequential loop does: results agree with the oracle to 1e-12, like
+// the matrix-core kernels', not bit for bit.  log Z comes from the product of the scale factors, renormalised by frexp every
+// sixteen genes (one log per contig instead of one per gene).
+template <int X>
+__device__ __forceinline__ double gl_row_dpp(double v) {  // X = 0: row_half_mirror, 1: row_mirror
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), X == 0 ? 0x141 : 0x140, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), X == 0 ? 0x141 : 0x140, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// sum over the labels of a value that every label's H lanes hold alike (lanes of missing labels hold 0): the lanes with one
+// value of h are one lane per label, so the permutes that would add the H copies are left out; every lane gets the sum
+template <int H>
+__device__ __forceinline__ double gl_wave_label_sum(double v) {
+    if (H < 2) v += gl_quad_xor<1>(v);
+    if (H < 4) v += gl_quad_xor<2>(v);
+    v += gl_row_dpp<0>(v);  // lanes 0-7 <-> 7-0 of every half row: with the quad sums in place, the half row's
+    v += gl_row_dpp<1>(v);  // ... and the row's
+    auto row = [&](int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    };
+    const double t = (row(0) + row(16)) + (row(32) + row(48));
+    return t;
+}
+
+constexpr int kWaveFK = 8;  // genes per staged block of the forward-backward walk
+
+template <int LP>
+__global__ void __launch_bounds__(kGT) gl_marginals_wave(GenArgs a) {
+    constexpr int H = 64 / LP, PER = LP / H, K = kWaveFK;
+    __shared__ double vecs[kGT / 64][LP];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const long long ci = static_cast<long long>(blockIdx.x) * (kGT / 64) + wave;
+    if (ci >= a.n_contigs) return;
+    const int L = a.L, h = lane & (H - 1), j = lane / H;
+    const int g0 = __builtin_amdgcn_readfirstlane(a.contig_ptr[ci]);
+    const int T = __builtin_amdgcn_readfirstlane(a.contig_ptr[ci + 1]) - g0;
+    if (T <= 0) {
+        if (lane == 0 && a.lognorm) a.lognorm[ci] = 0.0;
+        return;
+    }
+    if (a.wave_tmax > 0 && T > a.wave_tmax) return;  // (the batch's long tail: the chunked kernels' next to this launch)
+    // lanes of labels that do not exist repeat label 0's work (their stores carry label 0's values); only the sum over the
+    // labels has to leave them out
+    const bool on = j < L;
+    const int jj = on ? j : 0;
+    double mcol[PER], mrow[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = h * PER + u;
+        mcol[u] = i < L ? a.exp_trans[i * L + jj] : 0.0;
+        mrow[u] = i < L ? a.exp_trans[jj * L + i] : 0.0;
+    }
+    double *vec = vecs[wave];
+    double *vout = vec + j;
+    const double *vin = vec + h * PER;
+    const double *E = a.E + static_cast<size_t>(g0) * L + jj;
+    const double *smax = a.smax + g0;
+    double *alpha = a.alpha + static_cast<size_t>(g0) * L + jj;
+    double *scale = a.scale + g0;
+    double *marg = a.marg + static_cast<size_t>(g0) * L + jj;
+    // ---- forward ([EXT] crf1dc_alpha_score): alpha_t[j] = (sum_i alpha_{t-1}[i] M[i][j]) E_t[j], scaled to sum 1 -- at every
+    // `period`-th gene and at the last one (the recursions hold for ANY positive scale factors as long as beta uses the same
+    // ones and the last alpha sums to 1: a step whose factor is 1 skips the sum over the labels and two divisions; the host
+    // allows period 4 when four unscaled steps cannot leave the range, as for gl_chunk_rows_mfma)
+    const int period = a.rows_rescale_period;
+    double v = 0.0, c = 1.0, prod = 1.0, sm_sum = 0.0;
+    int ex_sum = 0;
+    double en[K], sn[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        en[k] = k < T ? E[static_cast<size_t>(k) * L] : 0.0;
+        sn[k] = k < T ? smax[k] : 0.0;
+    }
+    const size_t stride = size_t(L);
+    const double *ep = E + static_cast<size_t>(K) * L;  // next emission block
+    double *ap = alpha;                                  // alpha of the gene at hand
+    auto fstep = [&](const int t, const double e_t, const double sm_t) {
+        if (t > 0) {
+            *vout = v;
+            __builtin_amdgcn_wave_barrier();
+            double acc = vin[0] * mcol[0];
+#pragma unroll
+            for (int u = 1; u < PER; ++u) acc = fma(vin[u], mcol[u], acc);
+            __builtin_amdgcn_wave_barrier();
+            if (H >= 2) acc += gl_quad_xor<1>(acc);
+            if (H >= 4) acc += gl_quad_xor<2>(acc);
+            v = acc * e_t;
+        } else {
+            v = e_t;
+        }
+        if (period == 1 || (t & (period - 1)) == period - 1 || t == T - 1) {  // (wave-uniform)
+            const double s = gl_wave_label_sum<H>(on ? v : 0.0);
+            c = s != 0.0 ? 1.0 / s : 1.0;
+            v *= c;
+            prod *= c;
+        } else {
+            c = 1.0;
+        }
+        *ap = v;
+        ap += stride;
+        scale[t] = c;
+        sm_sum += sm_t;
+    };
+    for (int tb = 0; tb < T; tb += K) {
+        double ec[K], sc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            ec[k] = en[k];
+            sc[k] = sn[k];
+        }
+        if (tb + K < T) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                en[k] = tb + K + k < T ? ep[static_cast<size_t>(k) * L] : 0.0;
+                sn[k] = tb + K + k < T ? smax[tb + K + k] : 0.0;
+            }
+            ep += static_cast<size_t>(K) * L;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (tb + k < T) fstep(tb + k, ec[k], sc[k]);
+        int ex;  // (the product of the scale factors since the last renormalisation stays far inside the double range)
+        prod = frexp(prod, &ex);
+        ex_sum += ex;
+    }
+    if (lane == 0 && a.lognorm) a.lognorm[ci] = sm_sum - (log(prod) + double(ex_sum) * 0.6931471805599453);
+    // ---- backward ([EXT] crf1dc_beta_score, marginal_point): beta_t[i] = (sum_k M[i][k] E_{t+1}[k] beta_{t+1}[k]) c_t,
+    // p_t[j] = alpha_t[j] beta_t[j] / c_t.  alpha / scale of step t were stored by this very lane's label (or by label 0's
+    // lanes for a missing label): the fence orders them before the loads below.
+    __threadfence();
+    double b = c;
+    marg[static_cast<size_t>(T - 1) * L] = v * b / c;
+    if (T == 1) return;
+    // step t needs alpha_t, c_t, E_{t+1}; blocks of K steps t = hi, hi - 1, ... fetched one block ahead
+    double an[K], cn[K], e1n[K];
+    const double *al_p = alpha + static_cast<size_t>(T - 2) * L;  // alpha_t of the next block's first step
+    const double *e1_p = E + static_cast<size_t>(T - 1) * L;      // E_{t+1} likewise
+    double *mp = marg + static_cast<size_t>(T - 2) * L;
+    auto fetch = [&](const int hi) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int t = hi - k;
+            an[k] = t >= 0 ? *(al_p - static_cast<size_t>(k) * L) : 0.0;
+            cn[k] = t >= 0 ? scale[t] : 1.0;
+            e1n[k] = t >= 0 ? *(e1_p - static_cast<size_t>(k) * L) : 0.0;
+        }
+        al_p -= static_cast<size_t>(K) * L;  // (never dereferenced below the contig: the tests above)
+        e1_p -= static_cast<size_t>(K) * L;
+    };
+    fetch(T - 2);
+    for (int hi = T - 2; hi >= 0; hi -= K) {
+        double ac[K], cc[K], e1c[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            ac[k] = an[k];
+            cc[k] = cn[k];
+            e1c[k] = e1n[k];
+        }
+        if (hi - K >= 0) fetch(hi - K);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int t = hi - k;
+            if (t >= 0) {
+                *vout = b * e1c[k];
+                __builtin_amdgcn_wave_barrier();
+                double acc = mrow[0] * vin[0];
+#pragma unroll
+                for (int u = 1; u < PER; ++u) acc = fma(mrow[u], vin[u], acc);
+                __builtin_amdgcn_wave_barrier();
+                if (H >= 2) acc += gl_quad_xor<1>(acc);
+                if (H >= 4) acc += gl_quad_xor<2>(acc);
+                const double ct = cc[k];
+                if (__builtin_amdgcn_readfirstlane(__double2hiint(ct)) == 0x3ff00000 && __builtin_amdgcn_readfirstlane(__double2loint(ct)) == 0) {
+                    b = acc;  // (a step without rescaling: c_t = 1)
+                    *mp = ac[k] * b;
+                } else {
+                    b = acc * ct;
+                    *mp = ac[k] * b / ct;
+                }
+                mp -= stride;
+            }
+        }
+    }
+}
+
 // ==================================================================================================
 // Long contigs, any number of labels ("matrix-product scan for C5").  The kernels
 // above give a whole contig to ONE group of lanes: a 50 000-gene contig is a 50 000-step dependent chain
@@ -1462,6 +1652,16 @@ hipError_t launch_gen_windowed(const GenArgs &a, hipStream_t stream) {
 }
 hipError_t launch_gen_marginals(const GenArgs &a, hipStream_t stream) { return launch_any(2, a, stream); }
 hipError_t launch_gen_viterbi(const GenArgs &a, hipStream_t stream) { return launch_any(3, a, stream); }
+hipError_t launch_gen_marginals_wave(const GenArgs &a, hipStream_t stream) {
+    if (a.L <= 8 || a.L > kGenMaxL) return hipErrorNotSupported;
+    if (a.n_contigs <= 0) return hipSuccess;
+    const dim3 grid(unsigned((a.n_contigs + kGT / 64 - 1) / (kGT / 64)));
+    if (a.L <= 16)
+        hipLaunchKernelGGL(gl_marginals_wave<16>, grid, dim3(kGT), 0, stream, a);
+    else
+        hipLaunchKernelGGL(gl_marginals_wave<32>, grid, dim3(kGT), 0, stream, a);
+    return hipGetLastError();
+}
 hipError_t launch_gen_viterbi_wave(const GenArgs &a, hipStream_t stream) {
     if (a.L <= 8 || a.L > kGenMaxL) return hipErrorNotSupported;
     if (a.n_contigs <= 0) return hipSuccess;

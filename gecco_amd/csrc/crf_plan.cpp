@@ -236,7 +236,7 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
     }
     p.gen_small = false;
     p.gen_tab[0].chunk = p.gen_tab[1].chunk = 0;  // (chunk tables of the previous contigs)
-    p.gen_wave_tmax = INT32_MIN;
+    p.gen_wave_tmax = p.gen_wave_tmax_f = INT32_MIN;
     p.pipe = Plan::Pipe{};  // (score differences and CSR pointers of the previous layout)
     p.csr_begin = p.csr_end = -1;  // (the owner sets them after the build, for the batch at hand)
     p.model = &m;
@@ -568,6 +568,62 @@ int fill_gen_args(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, 
     a.S = p.S;
     a.W = p.W;
     return GECCO_CRF_OK;
+}
+
+// Whole-contig recursions of 9 to 32 labels: which contigs go to the wave-per-contig kernel (crf_general.hip).  The waves take as
+// long as the longest contig they are given (t_step us per gene: a lone wave issues an instruction every four cycles); the
+// chunked kernels pay L x the arithmetic for every gene they are given (t_gene us), a walk over the chunks of their longest
+// contig (t_walk us per gene) and a chain of launches (t_launches us).  So the batch is SPLIT: the k longest contigs -- the
+// tail of a metagenome's length distribution -- go through the chunked kernels on the plan's side stream, NEXT TO the waves
+// of the others, with k minimising max(t_waves(longest of the others), t_chunked(the k longest)).
+// Returns -1: chunked kernels for everything; 0: waves for everything; > 0: waves for contigs up to this length.
+// `env`: wave | chunked | split (k = 1) forces; `automatic`: whether the model's label count is one the choice is made for;
+// `cache`: the choice for this layout (INT32_MIN: not made yet).
+int32_t choose_wave_split(const Plan &p, const char *env, bool automatic, double t_step, double t_gene, double t_walk, double t_launches,
+                          int32_t &cache) {
+    const int forced = !env ? -1 : env[0] == 'w' ? 1 : env[0] == 'c' ? 0 : env[0] == 's' ? 2 : -1;
+    if (forced == 1) return 0;
+    if (forced == 0 || (forced < 0 && !automatic)) return -1;
+    if (forced < 0 && cache != INT32_MIN) return cache;  // (the sort below is the host's only loop over the contigs)
+    int32_t wave_tmax = -1;
+    std::vector<int32_t> len(size_t(p.n_contigs));
+    for (int32_t c = 0; c < p.n_contigs; ++c) len[size_t(c)] = p.contig_ptr[c + 1] - p.contig_ptr[c];
+    std::sort(len.begin(), len.end(), std::greater<int32_t>());
+    const double all_chunked = double(p.n_genes) * t_gene + double(len[0]) * t_walk + t_launches;
+    double best = all_chunked;
+    int64_t tail = 0;
+    for (int32_t k = 0; k < p.n_contigs; ++k) {  // the k longest contigs chunked NEXT TO the waves of the others
+        const double t_tail = k ? double(tail) * t_gene + double(len[0]) * t_walk + t_launches : 0.0;
+        const double t = std::max(double(len[size_t(k)]) * t_step, t_tail);
+        if (t < best || (forced == 2 && k == 1)) {
+            best = t;
+            wave_tmax = k ? len[size_t(k)] : 0;  // (contigs as long as the k-th longest stay with the waves)
+            if (forced == 2 && k == 1) break;
+        }
+        tail += len[size_t(k)];
+        if (double(tail) * t_gene + t_launches > best) break;  // (cannot get better from here)
+    }
+    if (wave_tmax > 0 && len[0] <= wave_tmax) wave_tmax = 0;  // (nothing is longer: no tail)
+    if (forced < 0) cache = wave_tmax;
+    return wave_tmax;
+}
+
+// fork the chunked kernels of a batch's long tail onto the plan's side stream (behind what `stream` holds so far); join_tail
+// makes `stream` wait for them
+int fork_tail(Plan &p, hipStream_t stream) {
+    int rc;
+    if (!p.side_stream) {
+        if ((rc = check_hip(hipStreamCreateWithFlags(&p.side_stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
+        if ((rc = check_hip(hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming), "hipEventCreate"))) return rc;
+        if ((rc = check_hip(hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming), "hipEventCreate"))) return rc;
+    }
+    if ((rc = check_hip(hipEventRecord(p.ev_fork, stream), "hipEventRecord"))) return rc;
+    return check_hip(hipStreamWaitEvent(p.side_stream, p.ev_fork, 0), "hipStreamWaitEvent");
+}
+int join_tail(Plan &p, hipStream_t stream) {
+    int rc = check_hip(hipEventRecord(p.ev_join, p.side_stream), "hipEventRecord");
+    if (rc) return rc;
+    return check_hip(hipStreamWaitEvent(stream, p.ev_join, 0), "hipStreamWaitEvent");
 }
 
 int run_windowed_general(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_id, int32_t label, double *d_p_out,
@@ -1007,13 +1063,29 @@ int plan_run_marginals_full(Plan &p, const int32_t *d_gene_ptr, const int32_t *d
         return GECCO_CRF_EINVAL;
     }
     if (p.general) {
+        // 17 to 32 labels: the split of plan_run_viterbi for the forward-backward recursion (gl_marginals_wave; a step of it is
+        // ~0.5 us; the chunked kernels -- transfer matrices on the matrix cores -- run at 2.6 / 2.2 ns per gene at L = 32 / 24).
+        // Measured on 1 000 contigs / 0.22 M genes, longest 1 519 (all chunked -> all waves -> split): L = 32 0.60 -> 0.77 -> 0.44 ms.
+        // GECCO_CRF_GENERAL_MARGINALS=wave|chunked|split forces for 9 <= L <= 32 (tests, A/B).
+        const int L = p.model->L;
+        int32_t wave_tmax = -1;
+        if (L > 8 && p.n_contigs > 0)
+            wave_tmax = choose_wave_split(p, std::getenv("GECCO_CRF_GENERAL_MARGINALS"), L > 16, L > 16 ? 0.5 : 0.38,
+                                          L >= 28 ? 2.6e-3 : L > 16 ? 2.2e-3 : 1.0e-3, 0.1, 200.0, p.gen_wave_tmax_f);
+        const bool wave = wave_tmax >= 0, tail_chunked = wave_tmax > 0;
         GenArgs g;
-        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g, true, stream))) return rc;
+        if ((rc = fill_gen_args(p, d_gene_ptr, d_attr_id, g, !wave || tail_chunked, stream, tail_chunked ? wave_tmax : -1))) return rc;
         g.marg = d_marg;
         g.lognorm = d_lognorm;
         g.state = nullptr;
+        g.wave_tmax = tail_chunked ? wave_tmax : 0;
         if ((rc = check_hip(launch_gen_state(g, stream), "state score launch"))) return rc;
-        return check_hip(launch_gen_marginals(g, stream), "marginals launch");
+        if (!wave) return check_hip(launch_gen_marginals(g, stream), "marginals launch");
+        if (!tail_chunked || g.n_chunks <= 0) return check_hip(launch_gen_marginals_wave(g, stream), "marginals launch");
+        if ((rc = fork_tail(p, stream))) return rc;
+        if ((rc = check_hip(launch_gen_marginals(g, p.side_stream), "marginals launch"))) return rc;
+        if ((rc = check_hip(launch_gen_marginals_wave(g, stream), "marginals launch"))) return rc;
+        return join_tail(p, stream);
     }
     a.marg = d_marg;
     a.lognorm = d_lognorm;
@@ -1063,38 +1135,9 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
         const int L = p.model->L;
         int32_t wave_tmax = -1;  // -1: no wave kernel; 0: every contig; > 0: contigs up to this length
         if (L > 8 && p.n_contigs > 0) {
-            const char *env = std::getenv("GECCO_CRF_GENERAL_VITERBI");  // (read per call: the tests switch it)
-            const int forced = !env ? -1 : env[0] == 'w' ? 1 : env[0] == 'c' ? 0 : env[0] == 's' ? 2 : -1;
-            if (forced == 1) {
-                wave_tmax = 0;
-            } else if (forced < 0 && p.gen_wave_tmax != INT32_MIN) {
-                wave_tmax = p.gen_wave_tmax;  // (chosen when this layout was first decoded: the sort below is the host's only loop)
-            } else if (forced == 2 || (forced < 0 && L > 12)) {
-                std::vector<int32_t> len(size_t(p.n_contigs));
-                for (int32_t c = 0; c < p.n_contigs; ++c) len[size_t(c)] = p.contig_ptr[c + 1] - p.contig_ptr[c];
-                std::sort(len.begin(), len.end(), std::greater<int32_t>());
-                // us: a wave's step (LP = 32 / 16 lanes per target label set); the chunked kernels per gene of the batch, per gene
-                // of their longest contig (the walk over its chunks) and their dependent launches (measured at L = 32 on a tail
-                // of one 1 519-gene contig: 270 us; at L = 16: 150 us)
-                const double t_step = L > 16 ? 0.36 : 0.25, t_gene = L >= 28 ? 6.3e-3 : L > 16 ? 4.3e-3 : 1.3e-3;
-                const double t_walk = L > 16 ? 0.07 : 0.04, t_launches = L > 16 ? 150.0 : 80.0;
-                const double all_chunked = double(p.n_genes) * t_gene + double(len[0]) * t_walk + t_launches;
-                double best = all_chunked;
-                int64_t tail = 0;
-                for (int32_t k = 0; k < p.n_contigs; ++k) {  // the k longest contigs chunked NEXT TO the waves of the others
-                    const double t_tail = k ? double(tail) * t_gene + double(len[0]) * t_walk + t_launches : 0.0;
-                    const double t = std::max(double(len[size_t(k)]) * t_step, t_tail);
-                    if (t < best || (forced == 2 && k == 1)) {
-                        best = t;
-                        wave_tmax = k ? len[size_t(k)] : 0;  // (contigs as long as the k-th longest stay with the waves)
-                        if (forced == 2 && k == 1) break;
-                    }
-                    tail += len[size_t(k)];
-                    if (double(tail) * t_gene + t_launches > best) break;  // (cannot get better from here)
-                }
-                if (wave_tmax > 0 && len[0] <= wave_tmax) wave_tmax = 0;  // (nothing is longer: no tail)
-                if (forced < 0) p.gen_wave_tmax = wave_tmax;
-            }
+            const double t_step = L > 16 ? 0.36 : 0.25, t_gene = L >= 28 ? 6.3e-3 : L > 16 ? 4.3e-3 : 1.3e-3;
+            wave_tmax = choose_wave_split(p, std::getenv("GECCO_CRF_GENERAL_VITERBI"), L > 12, t_step, t_gene, L > 16 ? 0.07 : 0.04,
+                                          L > 16 ? 150.0 : 80.0, p.gen_wave_tmax);
         }
         GenArgs g;
         const bool wave = wave_tmax >= 0, tail_chunked = wave_tmax > 0;
@@ -1110,17 +1153,10 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
         // the long tail (chunked kernels: short in work, long in dependent launches) NEXT TO the waves of the other contigs:
         // forked onto the plan's side stream behind the state scores, joined before anything later on the caller's stream.
         // The two write disjoint genes, contigs and back-pointer regions (a chunkless contig's path score is the waves').
-        if (!p.side_stream) {
-            if ((rc = check_hip(hipStreamCreateWithFlags(&p.side_stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
-            if ((rc = check_hip(hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming), "hipEventCreate"))) return rc;
-            if ((rc = check_hip(hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming), "hipEventCreate"))) return rc;
-        }
-        if ((rc = check_hip(hipEventRecord(p.ev_fork, stream), "hipEventRecord"))) return rc;
-        if ((rc = check_hip(hipStreamWaitEvent(p.side_stream, p.ev_fork, 0), "hipStreamWaitEvent"))) return rc;
+        if ((rc = fork_tail(p, stream))) return rc;
         if ((rc = check_hip(launch_gen_viterbi(g, p.side_stream), "viterbi launch"))) return rc;
-        if ((rc = check_hip(hipEventRecord(p.ev_join, p.side_stream), "hipEventRecord"))) return rc;
         if ((rc = check_hip(launch_gen_viterbi_wave(g, stream), "viterbi launch"))) return rc;
-        return check_hip(hipStreamWaitEvent(stream, p.ev_join, 0), "hipStreamWaitEvent");
+        return join_tail(p, stream);
     }
     a.y = d_y;
     a.score = d_score;

@@ -90,7 +90,7 @@ struct Plan {
     } gen_tab[2];
     // Viterbi of 17-32 labels: the chunked kernels of a batch's long contigs run on a stream of the plan's own next to the
     // wave-per-contig kernel of the others (forked from and joined to the caller's stream by events)
-    int32_t gen_wave_tmax = INT32_MIN;  // the split chosen for this layout (plan_run_viterbi; INT32_MIN: not chosen yet)
+    int32_t gen_wave_tmax = INT32_MIN, gen_wave_tmax_f = INT32_MIN;  // the splits chosen for this layout (Viterbi, marginals; INT32_MIN: not yet)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // Pipelined decode (plan_run_decode_pipelined): what the last call left for the next one -- the batch's score differences

@@ -259,6 +259,30 @@ def test_viterbi_wave_per_contig(nat, L, mode, monkeypatch):
     assert np.array_equal(s2, es2)
 
 
+@pytest.mark.parametrize("L", [9, 13, 16, 17, 24, 32])
+@pytest.mark.parametrize("mode", ["wave", "chunked", "split"])
+def test_marginals_wave_per_contig(nat, L, mode, monkeypatch):
+    """Whole-contig marginals of 9 to 32 labels by a wave per contig (gl_marginals_wave), by the chunked kernels, and split (the
+    longest contig chunked next to the waves of the others): 1e-12 against the oracle, rows summing to 1, log Z to 1e-10."""
+    from oracle import crf_oracle as orc
+
+    monkeypatch.setenv("GECCO_CRF_GENERAL_MARGINALS", mode)
+    w, trans, cptr, gptr, attr = _case(L, 900 + L, extra=60)
+    model = nat.Model.from_tables(w, trans)
+    marg, ln = model.marginals_full(cptr, gptr, attr)
+    emarg, eln = orc.full_marginals(w, trans, cptr, gptr, attr)
+    assert marg.shape == emarg.shape
+    assert np.abs(marg - emarg).max() <= 1e-12
+    np.testing.assert_allclose(marg.sum(axis=1), 1.0, atol=1e-13)
+    assert np.abs(ln - eln).max() <= 1e-10 * max(1.0, np.abs(eln).max())
+    # empty contigs and one-gene contigs among the others
+    rng = np.random.default_rng(950 + L)
+    c2, g2, a2 = synth_contigs(rng, [0, 1, 0, 2, 17, 1, 300, 0], 300)
+    m2, l2 = model.marginals_full(c2, g2, a2)
+    em2, el2 = orc.full_marginals(w, trans, c2, g2, a2)
+    assert np.abs(m2 - em2).max() <= 1e-12 and np.abs(l2 - el2).max() <= 1e-10 * max(1.0, np.abs(el2).max())
+
+
 def test_viterbi_wave_is_chosen_for_batches_of_many_contigs(nat, monkeypatch):
     """Above 16 labels the plan splits a batch by its cost model: the long tail of the contig lengths through the chunked
     kernels, the rest through the wave-per-contig kernel (all of it, or none): every choice gives the oracle's labels; the
