@@ -325,31 +325,48 @@ struct GeneIndex {
         parallel_ranges(n, workers, [&](int64_t b, int64_t e, int w) {
             for (int64_t i = b; i < e; ++i) ++counts[size_t(w) * kParts + (h[size_t(i)] >> 58)];
         });
-        for (int p = 0; p < kParts; ++p) {
-            int64_t c = 0;
-            for (int w = 0; w < workers; ++w) c += counts[size_t(w) * kParts + p];
-            size_t cap = 16;
-            while (cap < size_t(c) * 2 + 8) cap <<= 1;
-            slots[p].assign(cap, 0);
-            mask[p] = cap - 1;
+        // ids listed part by part, in gene order inside a part (round 5: every worker used to scan ALL hashes for the parts it
+        // owned -- sixteen workers sixteen scans, slower than one): offsets in (part, worker) order, every worker scatters its
+        // own range, every part is then inserted from its contiguous list
+        std::vector<int64_t> off(size_t(kParts) * size_t(workers) + 1, 0);
+        {
+            int64_t run = 0;
+            for (int p = 0; p < kParts; ++p)
+                for (int w = 0; w < workers; ++w) {
+                    off[size_t(p) * workers + w] = run;
+                    run += counts[size_t(w) * kParts + p];
+                }
+            off[size_t(kParts) * workers] = run;
         }
+        std::vector<uint32_t> list(static_cast<size_t>(n));
+        parallel_ranges(n, workers, [&](int64_t b, int64_t e, int w) {
+            int64_t cur[kParts];
+            for (int p = 0; p < kParts; ++p) cur[p] = off[size_t(p) * workers + w];
+            for (int64_t i = b; i < e; ++i) list[size_t(cur[h[size_t(i)] >> 58]++)] = uint32_t(i);
+        });
         std::vector<char> dup(static_cast<size_t>(kParts), 0);
         const int pw = std::min(workers, kParts);
         parallel_ranges(kParts, pw, [&](int64_t pb, int64_t pe, int) {
-            for (int64_t i = 0; i < n; ++i) {  // every worker scans all hashes, inserts only its own parts
-                const uint64_t hv = h[size_t(i)];
-                const int64_t p = int64_t(hv >> 58);
-                if (p < pb || p >= pe) continue;
+            for (int64_t p = pb; p < pe; ++p) {
+                const int64_t l0 = off[size_t(p) * workers], l1 = off[size_t(p + 1) * workers];
+                size_t cap = 16;
+                while (cap < size_t(l1 - l0) * 2 + 8) cap <<= 1;
                 std::vector<uint32_t> &sl = slots[p];
-                for (uint64_t s = hv & mask[p];; s = (s + 1) & mask[p]) {
-                    const uint32_t cur = sl[s];
-                    if (!cur) {
-                        sl[s] = uint32_t(i + 1);
-                        break;
-                    }
-                    if (h[cur - 1] == hv && same(k[cur - 1], k[size_t(i)])) {
-                        dup[size_t(p)] = 1;
-                        break;
+                sl.assign(cap, 0);
+                mask[p] = cap - 1;
+                for (int64_t q = l0; q < l1; ++q) {
+                    const uint32_t i = list[size_t(q)];
+                    const uint64_t hv = h[i];
+                    for (uint64_t s = hv & mask[p];; s = (s + 1) & mask[p]) {
+                        const uint32_t cur = sl[s];
+                        if (!cur) {
+                            sl[s] = i + 1;
+                            break;
+                        }
+                        if (h[cur - 1] == hv && same(k[cur - 1], k[i])) {
+                            dup[size_t(p)] = 1;
+                            break;
+                        }
                     }
                 }
             }
@@ -525,18 +542,35 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
         std::sort(by.begin(), by.end(), [&](int32_t a, int32_t b) { return less(contigs.keys[a], contigs.keys[b]); });
         for (size_t r = 0; r < nc_all; ++r) c_rank[by[r]] = int32_t(r);
     }
+    // (round 5: the passes over the genes below are plain loops -- cut over the host threads; the sort itself only runs when
+    // the genes do not come in scoring order already, which annotation pipelines see to)
+    const int wn = worker_count(n);
     int64_t min_start = 0;
-    for (int64_t g = 0; g < n; ++g) min_start = std::min(min_start, g_start[size_t(g)]);
+    {
+        std::vector<int64_t> part(size_t(std::max(wn, 1)), 0);
+        parallel_ranges(n, wn, [&](int64_t b, int64_t e, int w) {
+            int64_t m = 0;
+            for (int64_t g = b; g < e; ++g) m = std::min(m, g_start[size_t(g)]);
+            part[size_t(w)] = m;
+        });
+        for (int64_t m : part) min_start = std::min(min_start, m);
+    }
     std::vector<int64_t> perm(static_cast<size_t>(n));
     {
         std::vector<uint64_t> key(static_cast<size_t>(n));
+        std::vector<char> bad(size_t(std::max(wn, 1)), 0);
+        parallel_ranges(n, wn, [&](int64_t b, int64_t e, int w) {
+            bool fits_here = true;
+            for (int64_t g = b; g < e; ++g) {
+                const uint64_t s = uint64_t(g_start[size_t(g)] - min_start);
+                if (s >> 40) fits_here = false;
+                key[size_t(g)] = (uint64_t(c_rank[size_t(g_sid[size_t(g)])]) << 40) | (s & ((1ull << 40) - 1));
+                perm[size_t(g)] = g;
+            }
+            bad[size_t(w)] = fits_here ? 0 : 1;
+        });
         bool fits = true;
-        for (int64_t g = 0; g < n; ++g) {
-            const uint64_t s = uint64_t(g_start[size_t(g)] - min_start);
-            if (s >> 40) fits = false;
-            key[size_t(g)] = (uint64_t(c_rank[size_t(g_sid[size_t(g)])]) << 40) | (s & ((1ull << 40) - 1));
-            perm[size_t(g)] = g;
-        }
+        for (char c : bad) fits &= c == 0;
         if (fits && nc_all < (1u << 24)) {
             radix_sort_by_key(key, perm);
         } else {  // coordinates beyond 2^40: comparison sort
@@ -549,14 +583,17 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
     std::vector<int32_t> pos_of(static_cast<size_t>(n));  // first-appearance index -> position in scoring order
     out.n_genes = int32_t(n);
     out.gene_row.resize(size_t(n));
-    for (int64_t k = 0; k < n; ++k) {
-        pos_of[size_t(perm[size_t(k)])] = int32_t(k);
-        out.gene_row[size_t(k)] = g_row[size_t(perm[size_t(k)])];
-    }
+    std::vector<std::vector<int32_t>> cuts(size_t(std::max(wn, 1)));  // contig boundaries found by every worker, in order
+    parallel_ranges(n, wn, [&](int64_t b, int64_t e, int w) {
+        for (int64_t k = b; k < e; ++k) {
+            pos_of[size_t(perm[size_t(k)])] = int32_t(k);
+            out.gene_row[size_t(k)] = g_row[size_t(perm[size_t(k)])];
+            if (k >= 1 && g_sid[size_t(perm[size_t(k)])] != g_sid[size_t(perm[size_t(k - 1)])]) cuts[size_t(w)].push_back(int32_t(k));
+        }
+    });
     std::vector<int32_t> cptr;
     cptr.push_back(0);
-    for (int64_t k = 1; k < n; ++k)
-        if (g_sid[size_t(perm[size_t(k)])] != g_sid[size_t(perm[size_t(k - 1)])]) cptr.push_back(int32_t(k));
+    for (const std::vector<int32_t> &c : cuts) cptr.insert(cptr.end(), c.begin(), c.end());
     if (n) cptr.push_back(int32_t(n));
     out.n_contigs = int32_t(cptr.size()) - 1;
     ph.lap("gene order");
@@ -568,13 +605,51 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
         parallel_ranges(nf, wf, [&](int64_t b, int64_t e, int) {
             for (int64_t i = b; i < e; ++i) out.row_gene[size_t(i)] = pos_of[size_t(row_gene_fa[size_t(i)])];
         });
+        ph.lap("row genes");
         bool grouped = true;  // rows already come gene by gene, in scoring order: only the runs need sorting
-        for (int64_t i = 0; i < nf; ++i) {
-            const int32_t pos = out.row_gene[size_t(i)];
-            ++out.row_ptr[size_t(pos) + 1];
-            if (i && pos < out.row_gene[size_t(i - 1)]) grouped = false;
+        {
+            std::vector<char> broken(size_t(std::max(wf, 1)), 0);
+            parallel_ranges(nf, wf, [&](int64_t b, int64_t e, int w) {
+                bool ok = true;
+                for (int64_t i = std::max<int64_t>(b, 1); i < e; ++i) ok &= out.row_gene[size_t(i)] >= out.row_gene[size_t(i - 1)];
+                broken[size_t(w)] = ok ? 0 : 1;
+            });
+            for (char c : broken) grouped &= c == 0;
         }
-        for (int64_t g = 0; g < n; ++g) out.row_ptr[size_t(g) + 1] += out.row_ptr[size_t(g)];
+        if (grouped && nf > 0) {
+            // row_ptr[g] = number of rows of the genes before g = index of the first row whose gene is >= g: the rows where the
+            // gene changes give it for the genes that have rows, the others take the next such gene's (round 5: host threads)
+            const int wn2 = worker_count(n);
+            std::vector<int64_t> first_defined(size_t(std::max(wn2, 1)) + 1, nf);  // per gene range: its first gene's value once filled
+            parallel_ranges(n + 1, wn2, [&](int64_t gb, int64_t ge, int) {
+                for (int64_t g = gb; g < ge; ++g) out.row_ptr[size_t(g)] = -1;
+            });
+            parallel_ranges(nf, wf, [&](int64_t b, int64_t e, int) {
+                for (int64_t i = b; i < e; ++i)
+                    if (i == 0 || out.row_gene[size_t(i)] != out.row_gene[size_t(i - 1)]) out.row_ptr[size_t(out.row_gene[size_t(i)])] = i;
+            });
+            out.row_ptr[size_t(n)] = nf;
+            // fill the genes without rows from behind: every range first reports the value its first gene will get ...
+            parallel_ranges(n + 1, wn2, [&](int64_t gb, int64_t ge, int w) {
+                int64_t v = -1;
+                for (int64_t g = gb; g < ge && v < 0; ++g) v = out.row_ptr[size_t(g)];
+                first_defined[size_t(w)] = v;  // (-1: nothing defined in this range)
+            });
+            for (int w = std::max(wn2, 1) - 1; w >= 0; --w)
+                if (first_defined[size_t(w)] < 0) first_defined[size_t(w)] = first_defined[size_t(w) + 1];
+            // ... then fills its own genes with the value carried in from the ranges behind it
+            parallel_ranges(n + 1, wn2, [&](int64_t gb, int64_t ge, int w) {
+                int64_t carry = first_defined[size_t(w) + 1];
+                for (int64_t g = ge - 1; g >= gb; --g) {
+                    if (out.row_ptr[size_t(g)] < 0) out.row_ptr[size_t(g)] = carry;
+                    else carry = out.row_ptr[size_t(g)];
+                }
+            });
+        } else {
+            for (int64_t i = 0; i < nf; ++i) ++out.row_ptr[size_t(out.row_gene[size_t(i)]) + 1];
+            for (int64_t g = 0; g < n; ++g) out.row_ptr[size_t(g) + 1] += out.row_ptr[size_t(g)];
+        }
+        ph.lap("row pointers");
         if (grouped) {
             parallel_ranges(n, worker_count(nf), [&](int64_t gb, int64_t ge, int) {
                 for (int64_t g = gb; g < ge; ++g) {
@@ -678,23 +753,34 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
             }
             name_of[size_t(w)] = doms.keys;
         });
-        // one code per distinct NAME across workers: a gene's rows may straddle two ranges
-        Interner all(4096);
+        // one code per distinct NAME across workers (a gene's rows may straddle two ranges): a name the model knows takes its
+        // attribute id, the others follow behind the A ids in first-appearance order -- the only names still interned here
+        // (round 5: interning every worker's every name again was 2 ms of serial work per 16 workers x 2 659 names)
+        const int32_t A = m.A;
+        dom_attr.resize(size_t(A));
+        for (int32_t a2 = 0; a2 < A; ++a2) dom_attr[size_t(a2)] = a2;
+        if (want_markers) dom_marker.assign(size_t(A), -1);
+        Interner unknown(64);
         std::vector<std::vector<int32_t>> global(static_cast<size_t>(wf));
         for (int w = 0; w < wf; ++w) {
             global[size_t(w)].resize(name_of[size_t(w)].size());
             for (size_t c = 0; c < name_of[size_t(w)].size(); ++c) {
+                const int32_t a2 = attr_of[size_t(w)][c];
+                if (a2 >= 0 && a2 < A) {
+                    if (want_markers) dom_marker[size_t(a2)] = mark_of[size_t(w)][c];
+                    global[size_t(w)][c] = a2;
+                    continue;
+                }
                 bool fresh = false;
-                const int32_t g = all.intern(name_of[size_t(w)][c], &fresh);
+                const int32_t g = A + unknown.intern(name_of[size_t(w)][c], &fresh);
                 if (fresh) {
-                    dom_attr.push_back(attr_of[size_t(w)][c]);
+                    dom_attr.push_back(-1);
                     if (want_markers) dom_marker.push_back(mark_of[size_t(w)][c]);
                 }
                 global[size_t(w)][c] = g;
             }
         }
-        if (wf > 1)
-            parallel_ranges(nf, wf, [&](int64_t b, int64_t e, int w) {
+        parallel_ranges(nf, wf, [&](int64_t b, int64_t e, int w) {
                 for (int64_t i = b; i < e; ++i) row_dom[size_t(i)] = global[size_t(w)][size_t(row_dom[size_t(i)])];
             });
     }
