@@ -151,7 +151,8 @@ struct Interner {
 };
 
 // stable sort of `idx` by 64-bit keys, least significant digit first; skipped when already in order
-void radix_sort_by_key(std::vector<uint64_t> &key, std::vector<int64_t> &idx) {
+template <class KeyVec, class IdxVec>
+void radix_sort_by_key(KeyVec &key, IdxVec &idx) {
     const size_t n = key.size();
     bool sorted = true;
     uint64_t all_or = 0;
@@ -160,8 +161,8 @@ void radix_sort_by_key(std::vector<uint64_t> &key, std::vector<int64_t> &idx) {
         if (i && key[i] < key[i - 1]) sorted = false;
     }
     if (sorted) return;
-    std::vector<uint64_t> k2(n);
-    std::vector<int64_t> i2(n);
+    KeyVec k2(n);
+    IdxVec i2(n);
     for (int shift = 0; shift < 64; shift += 16) {
         if (((all_or >> shift) & 0xffffull) == 0 && (all_or >> shift) == 0) break;
         std::vector<size_t> count(65537, 0);
@@ -314,10 +315,10 @@ struct GeneIndex {
     static constexpr int kParts = 64;
     std::vector<uint32_t> slots[kParts];  // gene + 1
     uint64_t mask[kParts];
-    const std::vector<Str> *keys = nullptr;
-    const std::vector<uint64_t> *hashes = nullptr;
+    const UVec<Str> *keys = nullptr;
+    const UVec<uint64_t> *hashes = nullptr;
     bool duplicates = false;
-    void build(const std::vector<Str> &k, const std::vector<uint64_t> &h, int workers) {
+    void build(const UVec<Str> &k, const UVec<uint64_t> &h, int workers) {
         keys = &k;
         hashes = &h;
         const int64_t n = int64_t(k.size());
@@ -338,7 +339,7 @@ struct GeneIndex {
                 }
             off[size_t(kParts) * workers] = run;
         }
-        std::vector<uint32_t> list(static_cast<size_t>(n));
+        UVec<uint32_t> list(static_cast<size_t>(n));
         parallel_ranges(n, workers, [&](int64_t b, int64_t e, int w) {
             int64_t cur[kParts];
             for (int p = 0; p < kParts; ++p) cur[p] = off[size_t(p) * workers + w];
@@ -400,8 +401,8 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
     Phase ph;
     const int wg = worker_count(ng), wf = worker_count(nf);
     // ---- genes in first-appearance order: gene-table rows, then proteins only the feature table knows
-    std::vector<Str> g_key(static_cast<size_t>(ng));  // per gene: its id
-    std::vector<uint64_t> g_hash(static_cast<size_t>(ng));
+    UVec<Str> g_key(static_cast<size_t>(ng));  // per gene: its id
+    UVec<uint64_t> g_hash(static_cast<size_t>(ng));
     parallel_ranges(ng, wg, [&](int64_t b, int64_t e, int) {
         for (int64_t i = b; i < e; ++i) {
             g_key[size_t(i)] = at(t.gene_protein_id, i);
@@ -452,8 +453,8 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
         });
     } else {  // repeated ids: the first row fixes the gene's position, the last one its contig and start (like a dict)
         Interner genes(size_t(ng) + 16);
-        std::vector<Str> keys2;
-        std::vector<uint64_t> hashes2;
+        UVec<Str> keys2;
+        UVec<uint64_t> hashes2;
         Str prev{nullptr, 0};
         int32_t prev_id = -1;
         for (int64_t i = 0; i < ng; ++i) {
@@ -485,7 +486,7 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
     // feature rows -> gene.  The feature table normally lists proteins in gene-table order with the rows of a
     // protein adjacent: try the previous row's gene and its successors before looking the id up.  Rows are cut
     // into ranges, one per worker; ids the gene table does not list are resolved afterwards, in row order.
-    std::vector<int32_t> row_gene_fa(static_cast<size_t>(nf));  // first-appearance gene index of every feature row
+    UVec<int32_t> row_gene_fa(static_cast<size_t>(nf));  // first-appearance gene index of every feature row
     std::vector<std::vector<int64_t>> unlisted(static_cast<size_t>(wf));
     parallel_ranges(nf, wf, [&](int64_t b, int64_t e, int w) {
         int32_t cur = -1;
@@ -555,9 +556,9 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
         });
         for (int64_t m : part) min_start = std::min(min_start, m);
     }
-    std::vector<int64_t> perm(static_cast<size_t>(n));
+    UVec<int64_t> perm(static_cast<size_t>(n));
     {
-        std::vector<uint64_t> key(static_cast<size_t>(n));
+        UVec<uint64_t> key(static_cast<size_t>(n));
         std::vector<char> bad(size_t(std::max(wn, 1)), 0);
         parallel_ranges(n, wn, [&](int64_t b, int64_t e, int w) {
             bool fits_here = true;
@@ -580,7 +581,7 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
             });
         }
     }
-    std::vector<int32_t> pos_of(static_cast<size_t>(n));  // first-appearance index -> position in scoring order
+    UVec<int32_t> pos_of(static_cast<size_t>(n));  // first-appearance index -> position in scoring order
     out.n_genes = int32_t(n);
     out.gene_row.resize(size_t(n));
     std::vector<std::vector<int32_t>> cuts(size_t(std::max(wn, 1)));  // contig boundaries found by every worker, in order
@@ -600,7 +601,7 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
     // ---- feature rows by (gene position, domain_start), stable
     out.row_gene.resize(size_t(nf));
     out.row_order.resize(size_t(nf));
-    out.row_ptr.assign(size_t(n) + 1, 0);
+    out.row_ptr.resize(size_t(n) + 1);
     {
         parallel_ranges(nf, wf, [&](int64_t b, int64_t e, int) {
             for (int64_t i = b; i < e; ++i) out.row_gene[size_t(i)] = pos_of[size_t(row_gene_fa[size_t(i)])];
@@ -646,6 +647,7 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
                 }
             });
         } else {
+            std::fill(out.row_ptr.begin(), out.row_ptr.end(), int64_t(0));
             for (int64_t i = 0; i < nf; ++i) ++out.row_ptr[size_t(out.row_gene[size_t(i)]) + 1];
             for (int64_t g = 0; g < n; ++g) out.row_ptr[size_t(g) + 1] += out.row_ptr[size_t(g)];
         }
@@ -668,7 +670,7 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
         } else {
             int64_t min_ds = 0;
             for (int64_t i = 0; i < nf; ++i) min_ds = std::min(min_ds, t.domain_start[i]);
-            std::vector<uint64_t> key(static_cast<size_t>(nf));
+            UVec<uint64_t> key(static_cast<size_t>(nf));
             bool fits = true;
             for (int64_t i = 0; i < nf; ++i) {
                 const uint64_t ds = uint64_t(t.domain_start[i] - min_ds);
@@ -691,7 +693,7 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out) 
     // a machine word: those go through a small table keyed by the word itself, no memcmp.  Every worker keeps
     // its own code space; codes only have to tell the names of ONE gene apart, so they are made global by
     // adding the worker's base after the pass.
-    std::vector<int32_t> row_dom(static_cast<size_t>(nf));
+    UVec<int32_t> row_dom(static_cast<size_t>(nf));
     std::vector<int32_t> dom_attr;    // per distinct (worker, name): attribute id or -1
     std::vector<int32_t> dom_marker;  // ... and its index in the caller's marker list or -1 (antismash criterion)
     const bool want_markers = t.n_markers > 0;

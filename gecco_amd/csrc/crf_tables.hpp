@@ -1,12 +1,35 @@
 // Columnar host side of the path: table columns -> CSR batch, called clusters -> clusters.tsv rows.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "../../include/gecco_crf.h"
 #include "crf_model.hpp"
 
 namespace gecco {
+
+// std::vector that does not zero what it allocates (resize / sized construction default-initialise): the packer's arrays
+// are tens of megabytes that its parallel passes write before anything reads them -- zeroing them first is a serial pass
+// over fresh pages (2-4 ms per 0.4 M genes), whereas first touched inside the passes the page faults spread over the threads.
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = DefaultInitAlloc<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U>
+    void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+        ::new (static_cast<void *>(p)) U;
+    }
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args) {
+        ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+    }
+};
+template <class T>
+using UVec = std::vector<T, DefaultInitAlloc<T>>;
 
 struct Packed {
     int32_t n_genes = 0, n_contigs = 0;
@@ -18,10 +41,10 @@ struct Packed {
     int32_t *contig_ptr = nullptr, *gene_ptr = nullptr, *attr_id = nullptr;
     uint8_t *annotated = nullptr;
     int32_t *marker_ptr = nullptr, *marker_id = nullptr;  // [n_genes+1], [..]: marker domains per gene, or null
-    std::vector<int64_t> gene_row;   // [n_genes] gene-table row of every gene, or -1 - (its first feature row)
-    std::vector<int32_t> row_gene;   // [n_rows]  position (scoring order) of every feature row's gene
-    std::vector<int64_t> row_order;  // [n_rows]  feature rows by (gene position, domain_start), stable
-    std::vector<int64_t> row_ptr;    // [n_genes+1] offsets of every gene's rows in row_order
+    UVec<int64_t> gene_row;   // [n_genes] gene-table row of every gene, or -1 - (its first feature row)
+    UVec<int32_t> row_gene;   // [n_rows]  position (scoring order) of every feature row's gene
+    UVec<int64_t> row_order;  // [n_rows]  feature rows by (gene position, domain_start), stable
+    UVec<int64_t> row_ptr;    // [n_genes+1] offsets of every gene's rows in row_order
     ~Packed();
 };
 
