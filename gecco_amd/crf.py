@@ -541,7 +541,7 @@ class ClusterCRF(object):
         correctly rounded exp, so that genes.tsv / features.tsv / clusters.tsv carry the reference's bits -- its acceptance test
         compares whole files, /root/reference/galaxy/gecco.xml:83-111).  ``reference_bits`` True / False decides; None (the
         default) means: ``GECCO_AMD_REFERENCE_BITS=0|1`` if set, else ON whenever the mode covers the model (2 labels, window
-        <= 32 items).  Every caller of this class is bound by its object or table handling (0.5 / 20 M genes/s), not by the
+        <= 32 items).  Every caller of this class is bound by its object or table handling (0.8 / 30 M genes/s), not by the
         kernels, so the drop-in class answers with the reference's bits; the C ABI's default stays the fast kernels."""
         want = getattr(self, "reference_bits", None)
         if want is None:
