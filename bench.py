@@ -141,6 +141,7 @@ def main() -> None:
             dist.init_process_group(backend="gloo")
             red_dev = torch.device("cpu")
 
+    from benchkit import line as bline
     from gecco_amd import _native as nat
     from gecco_amd import sharding, synth
 
@@ -246,7 +247,7 @@ def main() -> None:
     if args.workload == "C1":
         # BASELINE.json configs[0]: ONE 50-gene contig on the pretrained weights (tests/golden/model.pkl), SURVEY.md 8d's
         # domain law; a step of it is one launch of one window tile + one Viterbi workgroup: launch-bound by construction
-        from gecco_amd import latency as _lat
+        from benchkit import latency as _lat
 
         c1_model = nat.Model.from_lcrf(_lat.real_blob())
         cptr, gptr, attr = _lat.c1_batch(50, c1_model.num_attrs)
@@ -293,7 +294,6 @@ def main() -> None:
     kern_ms = res.plan.time_windowed(res.d_gp.data_ptr(), res.d_at.data_ptr(), res.d_p.data_ptr(), LABEL, res.stream, warmup=3,
                                      iters=args.kernel_iters)
     alg_bytes = _alg_bytes(n_genes, nnz, res.n_contigs)
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     # pipelined schedule: the launch that IS the step -- window tiles + Viterbi workgroups (crf_decode_pipelined); its
     # algorithmic bytes are the window kernel's plus one label byte per gene (the score differences the tiles leave for
     # the Viterbi workgroups of the next launch, 8 B written + 8 B read per gene, are the implementation's own traffic)
@@ -305,6 +305,24 @@ def main() -> None:
         pipe_ms = res.plan.time_decode_pipelined(res.d_gp.data_ptr(), res.d_at.data_ptr(), res.d_p.data_ptr(), res.d_y.data_ptr(), LABEL,
                                                  res.stream, warmup=3, iters=args.kernel_iters)
         pipe_alg = alg_bytes + n_genes
+    # one launch ALONE on an idle device, between two events on its stream (adds the dispatch latency of the launch; detail file)
+    isolated_us = None
+    if one_launch and "torch_stream" in res.lanes[0]:
+        ln = res.lanes[0]
+        res.flush()
+        ln["plan"].run_decode_pipelined(res.a_gp, res.a_at, ln["a_p"], None, 0, LABEL, ln["stream"])
+        ts = []
+        for _ in range(30):
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ln["torch_stream"])
+            ln["plan"].run_decode_pipelined(res.a_gp, res.a_at, ln["a_p"], ln["plan"], ln["a_y"], LABEL, ln["stream"])
+            e1.record(ln["torch_stream"])
+            torch.cuda.synchronize(dev)
+            ts.append(e0.elapsed_time(e1))
+        ln["primed"] = True
+        res.flush()
+        isolated_us = float(np.median(ts[5:])) * 1e3
     # ... and what a launch lasts under the schedule that was timed: with two decode streams two launches are in flight,
     # each of them longer than alone, while a batch leaves every ms_per_step.  HIP events on each lane's own stream, one
     # pair per launch (the first event completes when the lane's previous launch has).
@@ -398,20 +416,9 @@ def main() -> None:
             "sharding": "independent contig batches per rank, no collective",
         },
         "roofline": {
-            "bound": "hbm",
-            "kernel": res.plan.kernel_name,
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic,
+            **bline.roofline_record(res.plan.kernel_name, alg_bytes, kern_ms * 1e3, pmc=pmc, rocprof=pmc, step_us=None),
             "traffic_source": pmc.get("source") or pmc_note,
-            "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": kern_ms,
-            # the limiter in practice: fp64 VALU issue.  wave-level VALU instructions of one launch (PMC
-            # SQ_INSTS_VALU, same profile) x 4 cycles each / (kernel time x 1024 SIMDs x 2.4 GHz)
-            "valu_frac": valu_frac,
-            "valu_insts_per_launch": valu_insts,
             # the same against the issue rate this GPU SUSTAINS on fp64 (tools/ubench/valu_rates.hip, four waves per
             # SIMD of independent chains: 4.6-4.8 "2.4 GHz cycles" per wave instruction for v_add/v_mul/v_fma_f64 and the
             # DPP moves, i.e. ~2.05 GHz effective under this load) instead of the nominal 4 cycles at 2.4 GHz
@@ -437,29 +444,19 @@ def main() -> None:
         out["roofline_window_kernel"] = out["roofline"]
         vi = pmc_pipe.get("SQ_INSTS_VALU")
         out["roofline"] = {
-            "bound": "hbm",
-            "kernel": "crf_decode_pipelined",
-            "achieved": pipe_alg / (pipe_ms * 1e-3) / 1e9,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": pipe_alg / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "traffic": pmc_pipe.get("hbm_bytes_per_launch"),
+            **bline.roofline_record(pmc_pipe.get("kernel") or "crf_decode_pipelined", pipe_alg, pipe_ms * 1e3, kernel_us_isolated=isolated_us,
+                                    kernel_us_in_flight=(inflight_ms * 1e3) if inflight_ms else None, launches_in_flight=n_lanes,
+                                    pmc=pmc_pipe, rocprof=pmc_pipe, step_us=out["ms_per_step"] * 1e3),
             "traffic_source": pmc_pipe.get("source") or "no counter profile of this kernel source in profiles/pmc_traffic.json",
-            "traffic_note": "counter traffic holds what the algorithmic bytes leave out: the hand-over between launches (8 B/gene "
-                            "written by the tiles + 8 B/gene read by the Viterbi workgroups = 32 MB on C3), partial-line writes of "
-                            "the write-through stores (+9...13 MB in WRITE_SIZE) and the tiles' halo; no array is read twice (DESIGN.md 6)",
-            "algorithmic_bytes_per_launch": pipe_alg,
+            "traffic_note": "counter traffic holds what the algorithmic bytes leave out: the hand-over between launches, partial-line "
+                            "writes of the write-through stores and the tiles' halo; no array is read twice (DESIGN.md 6)",
             "kernel_ms": pipe_ms,
-            "kernel_ms_note": "HIP events around back-to-back launches on ONE stream: includes the boundary between launches; with "
-                              "several decode streams two launches overlap, so a launch takes longer than this while a batch "
-                              "takes less (ms_per_step)",
-            "launches_in_flight": n_lanes,
-            "kernel_ms_in_flight": inflight_ms,
-            "kernel_ms_in_flight_note": "the same launch under the schedule that was timed: mean over 200 launches of the interval "
-                                        "between two HIP events on the launch's own decode stream (the first completes when the "
-                                        "stream's previous launch has); two such launches overlap, so ms_per_step ~ half of it",
-            "valu_insts_per_launch": vi,
-            "valu_frac": (vi * 4.0 / (pipe_ms * 1e-3 * SIMDS * SCLK_HZ)) if vi else None,
+            "timing_note": "kernel_us: HIP events around back-to-back launches on ONE stream / launches = the interval at which "
+                           "launches complete (the head of a launch overlaps the tail of the one before); kernel_us_isolated: one "
+                           "launch on an idle device between two events (adds the dispatch latency); kernel_us_in_flight: the same "
+                           "launch under the timed schedule (two decode streams: two launches overlap, each lasts longer, a batch "
+                           "leaves every ms_per_step); kernel_us_rocprof: average begin-to-end duration in the committed "
+                           "rocprofv3 --kernel-trace --stats of `bench.py --streams 1` (profiles/INDEX.md)",
             # the same at the rate batches leave the decode streams (launches overlap): how close the STEP is to the fp64
             # issue bound; x 4.7 / 4 for the rate the chip sustains on fp64 (tools/ubench/valu_rates.hip)
             "valu_frac_of_step": (vi * 4.0 / (out["ms_per_step"] * 1e-3 * SIMDS * SCLK_HZ)) if vi else None,
@@ -549,7 +546,7 @@ def main() -> None:
             # the cluster-call levels on this law too: 8d's law puts nine genes in ten into a cluster (a degenerate refiner
             # input, and "rows + their probabilities" is then a download of nearly everything); this one calls few
             try:
-                from gecco_amd import levels as _lv2
+                from benchkit import levels as _lv2
 
                 out["levels_" + other + "_law"] = _lv2.cluster_levels_for(m8, w8, devices=(local_rank,))
             except Exception as err:
@@ -561,7 +558,7 @@ def main() -> None:
     # Gene objects -- a few iterations each; and the path `GECCO_HIP_DEVICES` users take on a multi-GPU node: ONE process,
     # one session over every visible device, host buffers in, host buffers out
     if rank == 0 and world == 1 and not args.no_levels and args.workload in ("C2", "C3"):
-        from gecco_amd import levels
+        from benchkit import levels
 
         golden = os.path.join(ROOT, "tests", "golden")
         lv = {"resident_step": {"ms": out["ms_per_step"], "genes_per_s": out["value"], "genes": n_genes,
@@ -595,7 +592,7 @@ def main() -> None:
     # (BASELINE.json configs[0] is the first of them; gecco_amd/latency.py)
     lat_checks = None
     if rank == 0 and world == 1 and not args.no_latency and args.workload in ("C1", "C3"):
-        from gecco_amd import latency as _lat
+        from benchkit import latency as _lat
 
         try:
             block, lat_checks, _lat_model = _lat.latency_block(device=local_rank)
@@ -606,7 +603,7 @@ def main() -> None:
                 import subprocess
 
                 env = dict(os.environ, GECCO_AMD_MODEL_DIR=os.path.join(ROOT, "tests", "golden"))
-                cp = subprocess.run([sys.executable, "-m", "gecco_amd.latency", "--cold-process"], cwd=ROOT, env=env, capture_output=True,
+                cp = subprocess.run([sys.executable, "-m", "benchkit.latency", "--cold-process"], cwd=ROOT, env=env, capture_output=True,
                                     text=True, timeout=180)
                 block["cold_process"] = json.loads(cp.stdout.strip().splitlines()[-1]) if cp.returncode == 0 else {"error": cp.stderr[-400:]}
             except Exception as err:
@@ -664,7 +661,7 @@ def main() -> None:
                                          "speedup_over_one_thread": (ng / best) / (ng / dt),
                                          "sample": f"same sample, OpenMP over ranges of 8 contigs inside the C oracle, best of 2; {cpu_note}"}
         try:
-            from gecco_amd import levels as _lv
+            from benchkit import levels as _lv
 
             golden_tables = _lv.golden_table_identity(os.path.join(ROOT, "tests", "golden"))
             golden_tables["reference_bits_mode"] = _lv.golden_table_identity(os.path.join(ROOT, "tests", "golden"), reference_bits=True)
@@ -708,7 +705,10 @@ def main() -> None:
             out["cpu_baseline_port"] = out["cpu_baseline"]
             out["cpu_baseline"] = ref
     if rank == 0:
-        print(json.dumps(out))
+        # ONE short line on stdout (the driver keeps only the tail of stdout: round 5's 29 KB line could not be parsed); the whole
+        # record -- levels, latency, session_multi_device, golden tables, notes -- goes to a side file the line names
+        path = bline.write_detail(bline.detail_path(ROOT, args.workload, world), out)
+        print(bline.dumps(bline.compact_line(out, detail=os.path.relpath(path, ROOT) if path.startswith(ROOT) else path)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

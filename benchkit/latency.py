@@ -19,7 +19,7 @@ Synthetic inputs follow SURVEY.md 8d's C1 law on the REAL model (tests/golden/mo
 gene {0: .30, 1: .35, 2: .17, >= 3: .18 as 3 + Geometric(.5)}, ids Zipf(1.2) over the model's 2 659 attributes;
 50 genes = one contig, larger sizes = contigs of 200 genes.
 
-`python -m gecco_amd.latency --cold-process` prints what a FRESH process pays before its first result (library load,
+`python -m benchkit.latency --cold-process` prints what a FRESH process pays before its first result (library load,
 runtime start, model parse, session, first call): bench.py runs it as a child process.
 """
 import ctypes
@@ -31,8 +31,8 @@ import warnings
 
 import numpy as np
 
-from . import _native as nat
-from . import pickle_model, synth
+from gecco_amd import _native as nat
+from gecco_amd import pickle_model, synth
 
 SIZES = (50, 1000, 10000, 100000)
 W, STEP, LABEL = 20, 1, 1
@@ -237,8 +237,8 @@ def resident_levels(model, cptr, gptr, attr, device=0, reps=None):
 
 def object_level(n_genes, model_dir=None, reps=None, seed=synth.SEED):
     """`ClusterCRF.predict_probabilities` on Gene objects built from the same C1 law."""
-    from .crf import ClusterCRF
-    from .model import Domain, Gene, Protein, Source, Strand
+    from gecco_amd.crf import ClusterCRF
+    from gecco_amd.model import Domain, Gene, Protein, Source, Strand
 
     crf = ClusterCRF.trained(model_dir or golden_dir())
     attrs = crf.model.attributes_
@@ -290,7 +290,7 @@ def latency_block(device=0, sizes=SIZES, with_objects=True, with_resident=True, 
 
 
 def cold_process(device=0, n_genes=50):
-    """Everything a fresh process pays before its first result (run as `python -m gecco_amd.latency --cold-process`)."""
+    """Everything a fresh process pays before its first result (run as `python -m benchkit.latency --cold-process`)."""
     t = [time.perf_counter()]
     lib = nat.load_library()
     t.append(time.perf_counter())

@@ -7,7 +7,7 @@ import warnings
 
 import numpy as np
 
-from . import _native as nat
+from gecco_amd import _native as nat
 
 
 def _timed(fn, reps):
@@ -132,8 +132,8 @@ def cluster_levels_for(model, wl, devices=(0,), reps=5, W=20):
 
 def object_level(model_dir, n_contigs=250, per=200, seed=0):
     """`ClusterCRF.predict_probabilities` on `Gene` objects of the real model (sort + pack + score + new objects)."""
-    from .crf import ClusterCRF
-    from .model import Domain, Gene, Protein, Source, Strand
+    from gecco_amd.crf import ClusterCRF
+    from gecco_amd.model import Domain, Gene, Protein, Source, Strand
 
     crf = ClusterCRF.trained(model_dir)
     attrs = crf.model.attributes_
@@ -168,9 +168,9 @@ def object_breakdown(crf, genes):
     import itertools
     import operator
 
-    from . import packing
+    from gecco_amd import packing
 
-    from ._objpath_loader import module as _objpath
+    from gecco_amd._objpath_loader import module as _objpath
 
     n = max(len(genes), 1)
     native = _objpath()
@@ -208,8 +208,8 @@ def object_breakdown(crf, genes):
 
 def tables_level(model_dir, nc=1000, per=200, seed=0, reps=5):
     """`predict.predict_tables`: feature / gene table columns -> CSR -> device -> output columns + cluster rows."""
-    from . import predict, tables
-    from .crf import ClusterCRF
+    from gecco_amd import predict, tables
+    from gecco_amd.crf import ClusterCRF
 
     crf = ClusterCRF.trained(model_dir)
     attrs = crf.model.attributes_
@@ -258,7 +258,7 @@ def golden_table_identity(golden_dir, out_dir=None, reference_bits=False):
     import os
     import tempfile
 
-    from . import predict
+    from gecco_amd import predict
 
     def rows(path):
         with open(path) as fh:

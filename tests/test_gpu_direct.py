@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 import torch  # noqa: E402,F401  (before libgecco_crf.so: the wheel's own HIP runtime has to be the first one loaded)
 
-from gecco_amd import latency  # noqa: E402
+from benchkit import latency  # noqa: E402
 from tests.helpers import synth_contigs, synth_model  # noqa: E402
 
 

@@ -116,7 +116,7 @@ def test_cli_tables_string_identity_with_the_reference_files(tmp_path, capsys):
     clusters.tsv): every text / integer cell written by `python -m gecco_amd.predict` is string-identical to the fixture's;
     float cells (probabilities printed with 16-17 digits) are counted and reported: a cell differs as soon as the value is one
     ulp away from CRFsuite's, and must never be more than 8 ulps away."""
-    from gecco_amd import levels
+    from benchkit import levels
 
     res = levels.golden_table_identity(GOLDEN, str(tmp_path))
     with capsys.disabled():

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 import torch  # noqa: E402,F401  (before libgecco_crf.so: the wheel's own HIP runtime has to be the first one loaded)
 
-from gecco_amd import latency  # noqa: E402
+from benchkit import latency  # noqa: E402
 from tests.helpers import GOLDEN, golden_csr, read_tsv, synth_contigs, synth_model  # noqa: E402
 
 
@@ -125,7 +125,7 @@ def test_cli_tables_are_the_reference_files_in_reference_bits_mode(tmp_path, cap
     """`python -m gecco_amd.predict --reference-bits` on the fixture: every cell of genes.tsv, features.tsv and of the CRF's
     columns of clusters.tsv is string-identical to the reference's file (`proteins` / `domains`: to the reference's current
     formula -- the fixture file predates it)."""
-    from gecco_amd import levels
+    from benchkit import levels
 
     res = levels.golden_table_identity(GOLDEN, str(tmp_path), reference_bits=True)
     with capsys.disabled():

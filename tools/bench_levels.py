@@ -68,7 +68,7 @@ def main():
                                             "note": "marginals + refiner on the device, rows and their probabilities come back "
                                                     "into fresh pageable arrays (32-bit wire format)"}
     # the levels of the bench line (pinned buffers in and out, degree bytes / 16-bit indices on the wire, decode, cluster calls)
-    from gecco_amd import levels  # noqa: E402
+    from benchkit import levels  # noqa: E402
     ses.set_chunk_genes(1 << 19)
     out["batch_driver_levels"] = levels.host_buffer_levels(model, wl, reps=10)
     # object API on the real model: 500 contigs x 200 genes of Gene objects

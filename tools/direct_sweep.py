@@ -10,7 +10,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gecco_amd import _native as nat  # noqa: E402
-from gecco_amd import latency  # noqa: E402
+from benchkit import latency  # noqa: E402
 
 
 def med(fn, reps=200):

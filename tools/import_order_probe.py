@@ -1,7 +1,8 @@
 import sys
 sys.path.insert(0, '.')
 import numpy as np
-from gecco_amd import _native as nat, latency
+from gecco_amd import _native as nat
+from benchkit import latency
 m = nat.Model.from_lcrf(latency.real_blob())
 c, g, a = latency.c1_batch(50, m.num_attrs)
 p = nat.Session(m, [0]).windowed_marginals(c, g, a, 20)

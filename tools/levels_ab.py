@@ -12,7 +12,8 @@ CHILD = r"""
 import json, os, sys
 sys.path.insert(0, %r)
 import torch
-from gecco_amd import _native as nat, levels, synth
+from gecco_amd import _native as nat, synth
+from benchkit import levels
 wl = synth.workload("C3")
 model = nat.Model.from_tables(wl["w"], wl["trans"])
 lv = levels.host_buffer_levels(model, wl, devices=(0,))

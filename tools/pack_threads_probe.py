@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 os.environ["GECCO_AMD_HIP_RUNTIME"] = "system"
 import numpy as np
 from gecco_amd import packing, tables, pickle_model, _native as nat
-from gecco_amd.latency import real_blob
+from benchkit.latency import real_blob
 model = nat.Model.from_lcrf(real_blob())
 attrs = model.attrs()
 rng = np.random.default_rng(0)

@@ -54,7 +54,7 @@ def session_levels():
         dt = timed(lambda: ses.windowed_marginals(cp, gpp, atp, 20, out=outp))
         res.setdefault("reference_bits" if mode else "fast", []).append(round(dt * 1e3, 4))
     print(json.dumps({"one_shot_pinned_ms": res, "genes": n}))
-    from gecco_amd import latency
+    from benchkit import latency
 
     blob_model = nat.Model.from_lcrf(latency.real_blob())
     ses1 = nat.Session(blob_model, [0])
@@ -68,7 +68,7 @@ def session_levels():
 
 
 def class_levels():
-    from gecco_amd import levels
+    from benchkit import levels
 
     golden = os.path.join(ROOT, "tests", "golden")
     for mode in ("0", "1"):
