@@ -173,28 +173,87 @@ SIGNATURES = {
 _lib = None
 
 
-def _preload_hip_runtime() -> Optional[str]:
-    """A PyTorch wheel carries its own copy of libamdhip64 (same SONAME as the system's), and whichever copy a process loads
-    first serves everybody: loaded second, torch's copy finds no device.  So that the import order does not matter, the wheel's
-    copy -- when there is a torch to import later -- is loaded here, before libgecco_crf.so pulls in the system's
-    (`GECCO_AMD_HIP_RUNTIME=system` keeps the system's; a process that has imported torch already has made the choice)."""
+def _elf_dynamic_strings(path: str, tags=(1, 14)) -> dict:
+    """DT_NEEDED (1) / DT_SONAME (14) strings of a 64-bit little-endian ELF shared object, read from the file (nothing is loaded)."""
+    import struct
+
+    out = {t: [] for t in tags}
+    with open(path, "rb") as fh:
+        hdr = fh.read(64)
+        if hdr[:4] != b"\x7fELF" or hdr[4] != 2 or hdr[5] != 1:
+            return out
+        shoff, = struct.unpack_from("<Q", hdr, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", hdr, 0x3A)
+        secs = []
+        for i in range(shnum):
+            fh.seek(shoff + i * shentsize)
+            sh = fh.read(shentsize)
+            _, typ, _, _, off, size, link = struct.unpack_from("<IIQQQQI", sh, 0)
+            secs.append((typ, off, size, link))
+        for typ, off, size, link in secs:
+            if typ != 6:  # SHT_DYNAMIC
+                continue
+            _, stroff, strsize, _ = secs[link]
+            fh.seek(stroff)
+            strtab = fh.read(strsize)
+            fh.seek(off)
+            dyn = fh.read(size)
+            for k in range(0, len(dyn) - 15, 16):
+                tag, val = struct.unpack_from("<qQ", dyn, k)
+                if tag == 0:
+                    break
+                if tag in out:
+                    out[tag].append(strtab[val:strtab.index(b"\0", val)].decode())
+    return out
+
+
+def _preload_hip_runtime(lib_path: str) -> Optional[str]:
+    """A PyTorch wheel carries its own copy of libamdhip64, and whichever copy a process loads first serves everybody: loaded
+    second, torch's copy finds no device.  `GECCO_AMD_HIP_RUNTIME` decides what a process that has NOT imported torch yet does:
+
+    * unset / ``auto``: the wheel's copy is loaded ahead of libgecco_crf.so ONLY when its SONAME equals the libamdhip64 SONAME
+      libgecco_crf.so was linked against (same ABI major: one runtime in the process, whatever the import order); a different
+      SONAME gets a warning and the system's runtime (a later `import torch` in that process will then not see the device);
+    * ``system``: never preload;  * ``torch``: preload whatever the wheel carries (the caller vouches for it).
+
+    A process that has imported torch already has made the choice.  Returns the path that was loaded, or None."""
     import sys
+    import warnings
 
-    if "torch" in sys.modules or os.environ.get("GECCO_AMD_HIP_RUNTIME", "") == "system":
+    mode = os.environ.get("GECCO_AMD_HIP_RUNTIME", "auto").lower()
+    if "torch" in sys.modules or mode == "system":
         return None
+    import importlib.util
+
     try:
-        import importlib.util
-
         spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.submodule_search_locations:
-            return None
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if not os.path.exists(cand):
-            return None
-        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
-        return cand
-    except Exception:  # (any trouble: the system's runtime serves, as before)
+    except (ImportError, ValueError):
         return None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    if mode != "torch":
+        try:
+            wheel = _elf_dynamic_strings(cand)[14]
+            needed = [n for n in _elf_dynamic_strings(lib_path)[1] if n.startswith("libamdhip64")]
+        except (OSError, ValueError, IndexError) as err:
+            warnings.warn(f"gecco_amd: could not compare the HIP runtime of the installed torch wheel with the one {lib_path} was linked "
+                          f"against ({err}); keeping the system's runtime", RuntimeWarning, stacklevel=3)
+            return None
+        if not wheel or not needed or wheel[0] != needed[0]:
+            warnings.warn(f"gecco_amd: the installed torch wheel carries {wheel[0] if wheel else 'an unnamed libamdhip64'}, "
+                          f"libgecco_crf.so is linked against {needed[0] if needed else 'no libamdhip64'}: keeping the system's HIP "
+                          "runtime (import torch BEFORE gecco_amd if this process needs both, or set GECCO_AMD_HIP_RUNTIME=torch)",
+                          RuntimeWarning, stacklevel=3)
+            return None
+    try:
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except OSError as err:
+        warnings.warn(f"gecco_amd: could not load {cand} ({err}); the system's HIP runtime serves", RuntimeWarning, stacklevel=3)
+        return None
+    return cand
 
 
 def load_library(path: Optional[str] = None) -> ctypes.CDLL:
@@ -208,7 +267,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
             f"{p} not found: build it with `python -m gecco_amd.build` (hipcc, gfx950). "
             "gecco_amd has no CPU fallback."
         )
-    _preload_hip_runtime()
+    _preload_hip_runtime(p)
     lib = ctypes.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

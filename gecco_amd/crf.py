@@ -518,8 +518,10 @@ class ClusterCRF(object):
             raise NotFittedError("This ClusterCRF instance is not fitted yet.")
         lab = self.model.native.label_id(label)
         if device is not None and [device] != list(self.devices):
-            return self.model.native.windowed_marginals(contig_ptr, gene_ptr, attr_id, self.window_size, self.window_step,
-                                                        lab, pad, device=device)
+            # a session of its own on the named device, in this object's mode: the bits do not depend on `device`
+            ses = _native.Session(self.model.native, [device])
+            ses.set_reference_bits(self._reference_bits_now())
+            return ses.windowed_marginals(contig_ptr, gene_ptr, attr_id, self.window_size, self.window_step, lab, pad)
         return self._session().windowed_marginals(contig_ptr, gene_ptr, attr_id, self.window_size, self.window_step, lab, pad)
 
     def _session(self) -> "_native.Session":

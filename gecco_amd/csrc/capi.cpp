@@ -352,7 +352,7 @@ GECCO_API int gecco_crf_session_set_chunk_genes(gecco_crf_session *s, int32_t ge
     return GECCO_CRF_OK;
 }
 GECCO_API int gecco_crf_session_set_direct_genes(gecco_crf_session *s, int32_t genes) {
-    if (!s || genes < 0) return GECCO_CRF_EINVAL;
+    if (!s || genes < -1) return GECCO_CRF_EINVAL;  // (-1: back to the defaults, as the header documents)
     session_set_direct_genes(*s->s, genes);
     return GECCO_CRF_OK;
 }

@@ -656,7 +656,10 @@ __global__ void __launch_bounds__(kGT) gl_viterbi_wave(GenArgs a) {
     double *vout = vec + j;  // (slots of missing labels: written with label 0's value -- finite --, read against -DBL_MAX)
     const double *vin = vec + h * PER;
     const double *st = a.state + static_cast<size_t>(g0) * L + jj;
-    // the contig's back-pointer quads: dwords [q * L + j], from the first dword boundary inside its n * L bytes
+    // the contig's back-pointer quads: dwords [q * L + j], from the first dword boundary inside its T * L bytes.  Row t (1 ..
+    // T - 1; gene 0 has no back-pointer) is byte (t - 1) & 3 of quad (t - 1) >> 2: the whole quads of the T - 1 rows take at
+    // most (T - 1) * L bytes, the alignment at most 3 < L (this kernel serves L >= 9): every store stays inside the contig's
+    // own T * L bytes, whatever kernel decodes its neighbours (split mode: the chunked kernels on the side stream).
     const size_t byte0 = (static_cast<size_t>(g0) * L + 3) & ~size_t(3);
     uint32_t *backq = reinterpret_cast<uint32_t *>(a.back + byte0) + jj;
     const bool writer = on && h == 0;
@@ -698,7 +701,7 @@ __global__ void __launch_bounds__(kGT) gl_viterbi_wave(GenArgs a) {
         d = best + s_t;
         const uint32_t bp = uint32_t(arg);
         acc = sh == 0 ? bp : (acc | (bp << sh));
-        if (sh == 24) backq[static_cast<size_t>(t >> 2) * L] = acc;  // (every lane of the label, the same dword)
+        if (sh == 24) backq[static_cast<size_t>((t - 1) >> 2) * L] = acc;  // (every lane of the label, the same dword)
     };
     int tb = 1;
     for (; tb + K <= T; tb += K) {  // whole blocks of sixteen genes: nothing to test inside
@@ -711,11 +714,11 @@ __global__ void __launch_bounds__(kGT) gl_viterbi_wave(GenArgs a) {
             for (int k = 0; k < K; ++k) nxt[k] = tb + K + k < T ? sp[static_cast<size_t>(k) * L] : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) step(tb + k, cur[k], ((1 + k) & 3) * 8);  // (tb = 1 mod 16)
+        for (int k = 0; k < K; ++k) step(tb + k, cur[k], (k & 3) * 8);  // (tb = 1 mod 16: row tb + k is byte k & 3 of its quad)
     }
 #pragma unroll
     for (int k = 0; k < K; ++k)
-        if (tb + k < T) step(tb + k, nxt[k], ((1 + k) & 3) * 8);  // the last, partial block (wave-uniform tests)
+        if (tb + k < T) step(tb + k, nxt[k], (k & 3) * 8);  // the last, partial block (wave-uniform tests)
     // end label = first arg max (every lane computes it: wave-uniform)
     *vout = d;
     __builtin_amdgcn_wave_barrier();
@@ -736,9 +739,9 @@ __global__ void __launch_bounds__(kGT) gl_viterbi_wave(GenArgs a) {
     if (lane == 0) yout[T - 1] = static_cast<int8_t>(y);
     if (T == 1) return;
     __threadfence();  // (the quads this wave stored are read back through other lanes)
-    // rows T - 1 .. 1; quad q = rows 4 q .. 4 q + 3; the top quad is `acc` when it is incomplete
-    const int q_top = (T - 1) >> 2;
-    const bool top_in_reg = ((T - 1) & 3) != 3;
+    // rows T - 1 .. 1; quad q = rows 4 q + 1 .. 4 q + 4; the top quad is `acc` when it is incomplete
+    const int q_top = (T - 2) >> 2;
+    const bool top_in_reg = ((T - 2) & 3) != 3;
     auto load_quads = [&](int q_hi, uint32_t (&w)[Q]) {  // quads q_hi - Q + 1 .. q_hi (those below 0: unused)
 #pragma unroll
         for (int r = 0; r < Q; ++r) {
@@ -761,8 +764,8 @@ __global__ void __launch_bounds__(kGT) gl_viterbi_wave(GenArgs a) {
             if (q < 0) continue;  // (wave-uniform)
 #pragma unroll
             for (int b = 3; b >= 0; --b) {
-                const int t = 4 * q + b;
-                if (t >= 1 && t <= T - 1) {  // (wave-uniform)
+                const int t = 4 * q + b + 1;
+                if (t <= T - 1) {  // (wave-uniform)
                     const uint32_t word = uint32_t(__builtin_amdgcn_readlane(int(w[r]), y * H));  // row t as label y_t's lane holds it
                     y = int((word >> (8 * b)) & 0xffu);                                       // = label of gene t - 1
                     if (lane == 0) yout[t - 1] = static_cast<int8_t>(y);

@@ -310,7 +310,9 @@ int plan_build(const Model &m, int device, const int32_t *contig_ptr, int32_t n_
             const char *env = std::getenv("GECCO_CRF_REFERENCE_BITS");
             return env && env[0] == '1';
         }();
-        p.reference_now = p.reference_bits || env_reference;
+        // (the environment switch is for windowed marginals of 2-label models: a Viterbi-only or whole-contig layout, or another
+        // label count, keeps its kernels; an explicit request -- reference_bits -- for an unsupported shape is an error)
+        p.reference_now = p.reference_bits || (env_reference && p.windowed_use && m.L == 2 && reference_bits_ok(m.L, W));
         if (p.reference_now) {
             if (!reference_bits_ok(m.L, W)) {
                 set_error("reference-bits mode serves 2-label models and windows of at most 32 genes");
@@ -1152,7 +1154,9 @@ int plan_run_viterbi(Plan &p, const int32_t *d_gene_ptr, const int32_t *d_attr_i
         if (!tail_chunked || g.n_chunks <= 0) return check_hip(launch_gen_viterbi_wave(g, stream), "viterbi launch");
         // the long tail (chunked kernels: short in work, long in dependent launches) NEXT TO the waves of the other contigs:
         // forked onto the plan's side stream behind the state scores, joined before anything later on the caller's stream.
-        // The two write disjoint genes, contigs and back-pointer regions (a chunkless contig's path score is the waves').
+        // The two write disjoint genes, contigs and back-pointer regions: a contig's back-pointers, in either kernel's layout, stay
+        // inside its own T * L bytes (gl_viterbi_wave: quads of rows 1 .. T - 1 from the first dword boundary).  (A chunkless
+        // contig's path score is the waves'.)
         if ((rc = fork_tail(p, stream))) return rc;
         if ((rc = check_hip(launch_gen_viterbi(g, p.side_stream), "viterbi launch"))) return rc;
         if ((rc = check_hip(launch_gen_viterbi_wave(g, stream), "viterbi launch"))) return rc;

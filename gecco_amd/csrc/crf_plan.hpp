@@ -108,8 +108,10 @@ struct Plan {
     int64_t csr_begin = -1, csr_end = -1;  // gene_ptr[0] / gene_ptr[n_genes] when the owner knows them (batch driver's direct path), else -1
     // Reference-bits mode (crf_exact.hip): windowed marginals in CRFsuite's own operation order with a correctly rounded exp --
     // the reference's output files bit for bit, at about six times the fast kernels' time.  Set by the owner before
-    // plan_build (batch driver: gecco_crf_session_set_reference_bits); GECCO_CRF_REFERENCE_BITS=1 sets it for every plan.
+    // plan_build (batch driver: gecco_crf_session_set_reference_bits); GECCO_CRF_REFERENCE_BITS=1 sets it for every 2-label plan that runs windowed marginals.
     bool reference_bits = false;
+    bool windowed_use = true;  // the owner runs windowed marginals on this layout (batch driver: false for Viterbi-only and
+                               // whole-contig-marginal requests): the environment switch applies to such layouts only
     bool reference_now = false;  // (this layout runs in reference-bits mode: reference_bits, or the environment)
     bool seq_in_host_memory = false;     // small batches (batch driver's direct path): the whole-contig tables AND the contig flags
                                          // stay in the pinned block, flags built by the host -- no copy, no launch in front of the decoder

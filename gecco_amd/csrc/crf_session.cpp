@@ -756,6 +756,7 @@ int submit_plan(RunCtx &X, Lane &ln, int chunk_index) {
         // small batches: the decoder's tables and flag bytes too are read where the host wrote them
         ln.plan.seq_in_host_memory = X.direct && !r.want_segments && !X.full && !r.score_out;
         ln.plan.reference_bits = X.S.reference_bits && X.windowed;
+        ln.plan.windowed_use = X.windowed;
     }
     if (ck.piece) {  // a stretch of ONE long contig, scored as a contig of its own
         const int32_t span[2] = {ck.u0, ck.u1};

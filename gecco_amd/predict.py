@@ -107,7 +107,11 @@ def predict_tables(genes_t: tables.GeneTable, feats_t: tables.FeatureTable, crf:
     label = native.label_id("1")
     if label < 0:
         raise ValueError("the model has no label '1'")
-    session = crf._session() if device is None else _native.Session(native, [dev])
+    if device is None:
+        session = crf._session()
+    else:  # a session of its own on the named device, in the class's mode (reference bits or fast kernels): same bits either way
+        session = _native.Session(native, [dev])
+        session.set_reference_bits(crf._reference_bits_now())
     g_end_all = np.asarray(genes_t.end, dtype=np.int64) if genes_t is not None and len(genes_t) else None
     f_end_all = np.asarray(feats_t.end, dtype=np.int64) if len(feats_t) else None
     in_order = have_row and (n == 0 or (len(genes_t) == n and rows[0] == 0 and bool(np.all(np.diff(rows) == 1))))

@@ -230,3 +230,19 @@ def test_direct_threshold_follows_chunk_size(nat, real_model):
     assert ses.stats()["direct"] == 0 and ses.stats()["n_chunks"] == 1
     _bits(a, b)
     _bits(a, c)
+
+
+def test_set_direct_genes_minus_one_restores_the_defaults(nat):
+    """include/gecco_crf.h documents -1 as "the defaults" (round 5's C ABI refused it): an override can be undone."""
+    rng = np.random.default_rng(3)
+    w, trans = synth_model(60, rng)
+    model = nat.Model.from_tables(w, trans)
+    cptr, gptr, attr = synth_contigs(rng, [300, 40, 7], 60)
+    ses = nat.Session(model, [0])
+    base = ses.windowed_marginals(cptr, gptr, attr, 20).copy()
+    ses.set_direct_genes(0)
+    assert np.abs(ses.windowed_marginals(cptr, gptr, attr, 20) - base).max() <= 1e-14
+    ses.set_direct_genes(-1)
+    assert np.array_equal(ses.windowed_marginals(cptr, gptr, attr, 20), base)
+    with pytest.raises(ValueError):
+        ses.set_direct_genes(-2)

@@ -427,3 +427,24 @@ def test_long_contig_any_label_count(nat, L):
     assert np.array_equal(y.astype(np.int32), ey)
     assert np.abs(sc - esc).max() <= 1e-9 * np.abs(esc).max()
     assert dt < 1.0  # the contig-sequential kernels need ~50 ms per pass for the long contig alone; this is a sanity bound
+
+
+@pytest.mark.parametrize("L", [9, 11, 13, 15, 31])
+def test_viterbi_split_wave_contig_next_to_a_chunked_one(nat, L, monkeypatch):
+    """Split mode, odd label counts: wave contigs whose length is a multiple of four (whole quads of back-pointers) directly in
+    front of the chunked contig, g0 * L not a multiple of four.  The wave kernel's quads hold rows 1 .. T - 1 from the first dword
+    boundary of the contig's OWN T * L bytes (round 5 let them run up to 3 bytes into the next contig's row-0 bytes): a contig
+    decoded by the chunked kernels on the side stream right behind a wave contig gets CRFsuite's labels, whatever the order."""
+    from oracle import crf_oracle as orc
+
+    monkeypatch.setenv("GECCO_CRF_GENERAL_VITERBI", "split")
+    rng = np.random.default_rng(4100 + L)
+    w, trans = synth_model(120, rng, L=L)
+    model = nat.Model.from_tables(w, trans)
+    for lengths in ([3, 8, 900, 12, 4], [1, 4, 4, 4, 1200, 4, 8], [5, 16, 64, 700, 20, 1], [2, 12, 1500]):
+        cptr, gptr, attr = synth_contigs(rng, lengths, 120)
+        for _ in range(3):  # (the two streams race differently from call to call)
+            y, sc = model.viterbi(cptr, gptr, attr)
+            ey, esc = orc.viterbi(w, trans, cptr, gptr, attr)
+            assert np.array_equal(y.astype(np.int32), ey)
+            assert np.abs(sc - esc).max() <= 1e-9 * max(1.0, np.abs(esc).max())

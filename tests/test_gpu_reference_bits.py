@@ -206,3 +206,58 @@ def test_reference_bits_do_not_depend_on_how_the_batch_is_cut(nat):
         _bits(s2.windowed_marginals(cptr, gptr, attr, 20), base)
         p, y = s2.decode(cptr, gptr, attr, 20)
         _bits(p, base)
+
+
+def test_device_override_keeps_the_mode(monkeypatch):
+    """`device=` on the columnar entry points builds a session of its own: it must run in the object's mode (round 5: it
+    silently ran the fast kernels), so the bits do not depend on whether `device` was passed."""
+    from gecco_amd.crf import ClusterCRF
+
+    monkeypatch.delenv("GECCO_AMD_REFERENCE_BITS", raising=False)
+    crf = ClusterCRF.trained(GOLDEN)
+    _, cptr, gptr, attr, _, _ = golden_csr(crf.model._attr_index)
+    base = crf.predict_probabilities_csr(cptr, gptr, attr)
+    crf.devices = [0, 0]  # (so that device=0 is "another device list" and takes the override path)
+    _bits(crf.predict_probabilities_csr(cptr, gptr, attr, device=0), base)
+    crf.reference_bits = False
+    fast = crf.predict_probabilities_csr(cptr, gptr, attr, device=0)
+    assert fast.tobytes() != base.tobytes() and np.max(np.abs(fast - base)) < 1e-14
+
+
+def test_predict_tables_device_override_keeps_the_mode(monkeypatch):
+    from gecco_amd import predict, tables
+    from gecco_amd.crf import ClusterCRF
+
+    monkeypatch.delenv("GECCO_AMD_REFERENCE_BITS", raising=False)
+    crf = ClusterCRF.trained(GOLDEN)
+    feats = tables.FeatureTable.load(os.path.join(GOLDEN, "BGC0001866.features.tsv"))
+    genes = tables.GeneTable.load(os.path.join(GOLDEN, "BGC0001866.genes.tsv"))
+    a = predict.predict_tables(genes, feats, crf)
+    b = predict.predict_tables(genes, feats, crf, device=0)
+    _bits(np.asarray(a[0].average_p, dtype=np.float64), np.asarray(b[0].average_p, dtype=np.float64))
+    crf.reference_bits = False
+    c = predict.predict_tables(genes, feats, crf, device=0)
+    assert np.asarray(c[0].average_p, dtype=np.float64).tobytes() != np.asarray(a[0].average_p, dtype=np.float64).tobytes()
+
+def test_environment_switch_leaves_viterbi_only_and_any_label_plans_alone(nat, monkeypatch):
+    """GECCO_CRF_REFERENCE_BITS=1 is for windowed marginals of 2-label models: a Viterbi-only or whole-contig call, and a
+    model with another label count, keep working (round 5: EUNSUPPORTED out of plan_build)."""
+    from oracle import crf_oracle as orc
+
+    monkeypatch.setenv("GECCO_CRF_REFERENCE_BITS", "1")
+    rng = np.random.default_rng(12)
+    w3, t3 = synth_model(50, rng, L=3)
+    c, g, a = synth_contigs(rng, [60, 5, 200], 50)
+    m3 = nat.Model.from_tables(w3, t3)
+    y, _ = m3.viterbi(c, g, a)
+    assert np.array_equal(y.astype(np.int32), orc.viterbi(w3, t3, c, g, a)[0])
+    ses = nat.Session(m3, [0])
+    p3 = ses.windowed_marginals(c, g, a, 20)  # (another label count: the environment switch does not apply)
+    assert np.abs(p3 - orc.windowed_marginals(w3, t3, c, g, a, 20, 1, 1, True)).max() <= 1e-12
+    w2, t2 = synth_model(50, rng)
+    m2 = nat.Model.from_tables(w2, t2)
+    y2, _ = m2.viterbi(c, g, a)
+    assert np.array_equal(y2.astype(np.int32), orc.viterbi(w2, t2, c, g, a)[0])
+    with orc.correctly_rounded_exp():
+        e2 = orc.windowed_marginals(w2, t2, c, g, a, 20, 1, 1, True)
+    _bits(nat.Session(m2, [0]).windowed_marginals(c, g, a, 20), e2)  # (windowed, 2 labels: the switch applies)

@@ -884,3 +884,42 @@ def test_objpath_fused_pass_and_buffer_annotation_equal_the_separate_steps():
         native.annotate_all(genes, p[:-1], w1, Gene, Protein, Domain)
     with pytest.raises(ValueError):
         native.annotate_all(genes, p.astype(np.float32), w1, Gene, Protein, Domain)
+
+
+# ---- the HIP runtime preload of gecco_amd._native (no blind preload of the torch wheel's libamdhip64) -------
+def test_elf_reader_finds_the_hip_runtime_the_library_was_linked_against():
+    from gecco_amd import _native
+
+    needed = _native._elf_dynamic_strings(_native.LIB_PATH)[1]
+    hip = [n for n in needed if n.startswith("libamdhip64")]
+    assert len(hip) == 1 and hip[0].startswith("libamdhip64.so."), needed
+    assert _native._elf_dynamic_strings(__file__) == {1: [], 14: []}  # (not an ELF file: nothing, no exception)
+
+
+def test_hip_runtime_preload_is_gated_on_the_soname(monkeypatch):
+    import sys
+    import warnings
+
+    from gecco_amd import _native
+
+    monkeypatch.delitem(sys.modules, "torch", raising=False)
+    monkeypatch.setenv("GECCO_AMD_HIP_RUNTIME", "system")
+    assert _native._preload_hip_runtime(_native.LIB_PATH) is None
+    monkeypatch.setenv("GECCO_AMD_HIP_RUNTIME", "auto")
+    real = _native._elf_dynamic_strings
+
+    def skewed(path, tags=(1, 14)):  # the wheel carries another ABI major than the one the library was linked against
+        out = real(path, tags)
+        if path != _native.LIB_PATH and out.get(14):
+            out[14] = ["libamdhip64.so.6"]
+        return out
+
+    monkeypatch.setattr(_native, "_elf_dynamic_strings", skewed)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = _native._preload_hip_runtime(_native.LIB_PATH)
+    import importlib.util
+
+    if importlib.util.find_spec("torch") is not None:
+        assert got is None
+        assert any("libamdhip64.so.6" in str(c.message) and "keeping the system" in str(c.message) for c in caught)
