@@ -84,3 +84,62 @@ def synth_contigs(rng, lengths, A, zipf=1.2):
     contig_ptr = np.zeros(len(lengths) + 1, dtype=np.int32)
     np.cumsum(lengths, out=contig_ptr[1:])
     return contig_ptr, gene_ptr.astype(np.int32), attr
+
+
+# ---- vectors produced by the reference's own Python (tools/gen_reference_fixtures.py -> tests/golden/ref_*.json.gz) ----------
+def load_ref(name):
+    import gzip
+    import json
+
+    with gzip.open(os.path.join(GOLDEN, name + ".json.gz"), "rt") as fh:
+        return json.load(fh)["cases"]
+
+
+def genes_from_crf_case(case):
+    """`gecco_amd.model` objects for a case of ref_predict_probabilities, in the INPUT order the reference was given
+    (rows: contig id, protein id, start, end, strand, [[domain, start, end], ...]; hmm / e-values constant)."""
+    from gecco_amd.model import Domain, Gene, Protein, Source, Strand
+
+    sources, genes = {}, []
+    for cid, pid, start, end, strand, doms in case["genes"]:
+        src = sources.setdefault(cid, Source(cid))
+        genes.append(Gene(src, start, end, Strand(strand),
+                          Protein(pid, None, [Domain(name, ds, de, "Pfam", 1e-5, 1e-7) for name, ds, de in doms])))
+    return genes
+
+
+def genes_from_refiner_case(case):
+    """rows: contig id, protein id, start, end, probability or None, [domain names]."""
+    from gecco_amd.model import Domain, Gene, Protein, Source, Strand
+
+    sources, genes = {}, []
+    for cid, pid, start, end, prob, doms in case["genes"]:
+        src = sources.setdefault(cid, Source(cid))
+        genes.append(Gene(src, start, end, Strand.Coding,
+                          Protein(pid, None, [Domain(name, 1, 51, "Pfam", 1e-5, 1e-7, probability=prob) for name in doms]),
+                          _probability=prob))
+    return genes
+
+
+def pack_refiner_case(case, markers=None):
+    """The packed arrays `gecco_crf_segment` / the oracle take for a refiner case: genes by (contig id, start, end) -- a stable
+    sort, like the reference's two sorts (refine.py:189-192) --, NaN for a missing probability; returns
+    (ids, contig ids, p, annotated, contig_ptr, marker_ptr, marker_id)."""
+    rows = sorted(case["genes"], key=lambda r: r[0])            # sorted(genes, key=source.id): stable
+    by = {}
+    for r in rows:
+        by.setdefault(r[0], []).append(r)
+    ids, cids, p, ann, cptr, mptr, mid = [], [], [], [], [0], [0], []
+    mindex = {m: i for i, m in enumerate(markers or [])}
+    for cid in sorted(by):
+        seq = sorted(by[cid], key=lambda r: (r[2], r[3]))        # (start, end): stable
+        cids.append(cid)
+        for r in seq:
+            ids.append(r[1])
+            p.append(float("nan") if r[4] is None else r[4])
+            ann.append(1 if r[5] else 0)
+            mid.extend(sorted({mindex[d] for d in r[5] if d in mindex}))
+            mptr.append(len(mid))
+        cptr.append(len(ids))
+    return (ids, cids, np.array(p, dtype=np.float64), np.array(ann, dtype=np.uint8), np.array(cptr, dtype=np.int32),
+            np.array(mptr, dtype=np.int32), np.array(mid, dtype=np.int32))

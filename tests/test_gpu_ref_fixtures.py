@@ -1,0 +1,152 @@
+"""GPU: the drop-in class, the device refiner and the device composition kernel against vectors produced by THE REFERENCE'S OWN
+PYTHON (tests/golden/ref_*.json.gz <- tools/gen_reference_fixtures.py, which imports /root/reference/gecco in the build
+container; the tagger behind the reference class is the C oracle).  What is compared is everything `ClusterCRF.predict_probabilities`
+(gecco/crf/__init__.py:148-273), `ClusterRefiner.iter_clusters` (gecco/refine.py:118-200) and `Cluster.domain_composition`
+(gecco/model.py:458-503) return or emit: output order, probabilities, cluster weights, warning texts, the progress contract,
+the in-place sort of the caller's domain lists, cluster ids / members, composition vectors."""
+import warnings
+
+import numpy as np
+import pytest
+
+from tests.helpers import GOLDEN, genes_from_crf_case, genes_from_refiner_case, load_ref, pack_refiner_case
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402,F401  (before libgecco_crf.so: the wheel's own HIP runtime has to be the first one loaded)
+
+
+@pytest.fixture(scope="module")
+def crf_cases():
+    return load_ref("ref_predict_probabilities")
+
+
+def _run_case(crf, case, reference_bits):
+    prm = case["params"]
+    crf.feature_type, crf.window_size, crf.window_step = prm["feature_type"], prm["window_size"], prm["window_step"]
+    crf.reference_bits = reference_bits
+    genes = genes_from_crf_case(case)
+    calls = []
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        out = crf.predict_probabilities(genes, pad=prm["pad"], progress=lambda i, t: calls.append((i, t)))
+    return genes, out, calls, [[w.category.__name__, str(w.message)] for w in caught]
+
+
+@pytest.mark.parametrize("reference_bits", [False, True])
+def test_predict_probabilities_equals_the_reference(crf_cases, reference_bits):
+    """240 seeded cases: windows of 5 / 20 / 32, step 1 / 3 / 20, pad True / False, contigs shorter than / equal to / longer than
+    the window, unknown and repeated domains, unsorted input, equal starts, protein and domain mode.  Fast kernels and
+    reference-bits mode (the class's default): probabilities within 1e-12 (north star: 1e-6), everything else identical."""
+    from gecco_amd.crf import ClusterCRF
+
+    crf = ClusterCRF.trained(GOLDEN)
+    n_ok = n_err = n_defect = 0
+    worst = 0.0
+    for case in crf_cases:
+        prm = case["params"]
+        if reference_bits and prm["window_size"] > 32:
+            continue
+        genes, out, calls, caught = _run_case(crf, case, reference_bits)
+        if "error" in case:
+            # domain mode with more domains than genes in a contig: the reference's `probabilities` array is sized by GENES while
+            # its windows run over DOMAINS (crf/__init__.py:248-254) and numpy refuses the assignment.  Nothing to compare with;
+            # this implementation answers with a probability per domain.
+            assert prm["feature_type"] == "domain" and case["error"]["type"] == "ValueError"
+            assert len(out) == len(genes)
+            n_err += 1
+            continue
+        exp = case["expect"]
+        assert [g.protein.id for g in out] == exp["order"]
+        assert caught == case["warnings"]                        # texts, categories, order (crf/__init__.py:219-233)
+        n_in = {r[1]: len(r[5]) for r in case["genes"]}
+        if any(n_in[pid] != len(d) for pid, d in zip(exp["order"], exp["domains"])):
+            n_defect += 1  # (domain mode: the reference's zip() dropped domains it had no probability for -- features.py:109-117)
+            continue
+        # the caller's domain lists are sorted in place (crf/__init__.py:200-201)
+        assert all([d.start for d in g.protein.domains] == sorted(d.start for d in g.protein.domains) for g in genes) and exp["input_sorted_in_place"]
+        for g, p, doms in zip(out, exp["p"], exp["domains"]):
+            assert (g._probability is None) == (p is None)
+            if p is not None:
+                worst = max(worst, abs(g._probability - p))
+            assert [d.name for d in g.protein.domains] == [d[0] for d in doms]
+            assert [d.cluster_weight for d in g.protein.domains] == [d[1] for d in doms]   # None when (name, '1') is no state feature
+            for d, e in zip(g.protein.domains, doms):
+                ep = e[2] if len(e) > 2 else p
+                assert (d.probability is None) == (ep is None)
+                if ep is not None:
+                    worst = max(worst, abs(d.probability - ep))
+        # progress (crf/__init__.py:239-240,255-256): (0, total) first; the reference then calls once per window, this class once
+        # per launch -- monotone, same total, and (total, total) at the end when step = 1
+        rp = case["progress"]
+        assert calls[0] == tuple(rp["first"]) == (0, rp["total"])
+        assert all(t == rp["total"] for _, t in calls) and all(a[0] <= b[0] for a, b in zip(calls, calls[1:]))
+        if prm["window_step"] == 1:
+            assert calls[-1] == tuple(rp["last"]) == (rp["total"], rp["total"])
+        n_ok += 1
+    assert worst <= 1e-12, worst
+    assert n_ok >= 200 and n_err + n_defect <= 20
+
+
+def test_device_refiner_equals_the_reference():
+    """csrc/crf_segment.hip (`gecco_crf_segment_ex`, one grouper over all contigs = ONE iter_clusters call) against the clusters
+    the reference's refiner returned: same ids (numbering before filtering), same member genes -- gecco and antismash criteria,
+    edge distance 0-3, trim on / off, genes without probability, thresholds hit exactly."""
+    from gecco_amd import _native as nat
+    from gecco_amd.refine import BIO_PFAMS
+
+    markers = sorted(BIO_PFAMS)
+    n = 0
+    for case in load_ref("ref_refiner"):
+        if "error" in case:
+            continue
+        prm = case["params"]
+        ids, cids, p, ann, cptr, mptr, mid = pack_refiner_case(case, markers)
+        kw = dict(marker_ptr=mptr, marker_id=mid) if prm["criterion"] == "antismash" else {}
+        seg = nat.segment(p, ann, cptr, prm["threshold"], prm["n_cds"], prm["edge_distance"], prm["trim"], carry_state=True,
+                          criterion=prm["criterion"], n_biopfams=prm["n_biopfams"], average_threshold=prm["average_threshold"], **kw)
+        got = [[f"{cids[c]}_cluster_{k}", ids[a:b]] for c, k, a, b in seg.tolist()]
+        assert got == [[c[0], c[1]] for c in case["clusters"]]
+        n += len(got)
+    assert n > 300
+
+
+def test_refiner_class_on_gpu_probabilities_is_consistent(crf_cases):
+    """End to end on the reference's inputs: probabilities from the GPU, clusters from the refiner class -- equal to the clusters
+    the same refiner finds on the REFERENCE'S probabilities (cluster calls are what must be bit-identical)."""
+    from gecco_amd.crf import ClusterCRF
+    from gecco_amd.refine import ClusterRefiner
+
+    crf = ClusterCRF.trained(GOLDEN)
+    refiner = ClusterRefiner(threshold=0.8, n_cds=3)
+    n = 0
+    for case in crf_cases[:120]:
+        if "expect" not in case or case["params"]["feature_type"] != "protein":
+            continue
+        _, out, _, _ = _run_case(crf, case, None)
+        ref_p = dict(zip(case["expect"]["order"], case["expect"]["p"]))
+        ref_out = [g.with_probability(ref_p[g.protein.id]) if ref_p[g.protein.id] is not None else g for g in out]
+        a = [(c.id, [g.protein.id for g in c.genes]) for c in refiner.iter_clusters(out)]
+        b = [(c.id, [g.protein.id for g in c.genes]) for c in refiner.iter_clusters(ref_out)]
+        assert a == b
+        n += len(a)
+    assert n > 20
+
+
+def test_device_composition_equals_the_reference():
+    """csrc/crf_composition.hip behind `gecco_amd.composition.domain_composition` against `Cluster.domain_composition` of the
+    reference, bit for bit (all_possible given / None, normalised or not, p-values or e-values)."""
+    from gecco_amd import composition
+    from gecco_amd.model import Cluster, Domain, Gene, Protein, Source, Strand
+
+    src = Source("c")
+    for case in load_ref("ref_composition"):
+        genes = [Gene(src, 1000 * i + 1, 1000 * i + 900, Strand.Coding,
+                      Protein(f"c_{i + 1}", None, [Domain(nm, 1, 50, "Pfam", ev, pv) for nm, ev, pv in doms]), _probability=case["gene_p"][i])
+                 for i, doms in enumerate(case["genes"])]
+        cluster = Cluster("c_cluster_1", genes)
+        assert cluster.average_probability == case["average_probability"] and cluster.maximum_probability == case["maximum_probability"]
+        for key, exp in case["composition"].items():
+            normalize, pvalue = key.split(",")[0].endswith("1"), key.split(",")[1].endswith("1")
+            got = composition.domain_composition(cluster, case["all_possible"], normalize=normalize, pvalue=pvalue)
+            assert np.asarray(got, dtype=np.float64).tobytes() == np.asarray(exp, dtype=np.float64).tobytes()

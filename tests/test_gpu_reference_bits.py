@@ -239,25 +239,48 @@ def test_predict_tables_device_override_keeps_the_mode(monkeypatch):
     c = predict.predict_tables(genes, feats, crf, device=0)
     assert np.asarray(c[0].average_p, dtype=np.float64).tobytes() != np.asarray(a[0].average_p, dtype=np.float64).tobytes()
 
-def test_environment_switch_leaves_viterbi_only_and_any_label_plans_alone(nat, monkeypatch):
-    """GECCO_CRF_REFERENCE_BITS=1 is for windowed marginals of 2-label models: a Viterbi-only or whole-contig call, and a
-    model with another label count, keep working (round 5: EUNSUPPORTED out of plan_build)."""
-    from oracle import crf_oracle as orc
+_ENV_SWITCH_SCRIPT = r"""
+import sys
+import numpy as np
+import torch  # noqa: F401
+sys.path.insert(0, {root!r})
+from gecco_amd import _native as nat
+from oracle import crf_oracle as orc
+from tests.helpers import synth_contigs, synth_model
 
-    monkeypatch.setenv("GECCO_CRF_REFERENCE_BITS", "1")
-    rng = np.random.default_rng(12)
-    w3, t3 = synth_model(50, rng, L=3)
-    c, g, a = synth_contigs(rng, [60, 5, 200], 50)
-    m3 = nat.Model.from_tables(w3, t3)
-    y, _ = m3.viterbi(c, g, a)
-    assert np.array_equal(y.astype(np.int32), orc.viterbi(w3, t3, c, g, a)[0])
-    ses = nat.Session(m3, [0])
-    p3 = ses.windowed_marginals(c, g, a, 20)  # (another label count: the environment switch does not apply)
-    assert np.abs(p3 - orc.windowed_marginals(w3, t3, c, g, a, 20, 1, 1, True)).max() <= 1e-12
-    w2, t2 = synth_model(50, rng)
-    m2 = nat.Model.from_tables(w2, t2)
-    y2, _ = m2.viterbi(c, g, a)
-    assert np.array_equal(y2.astype(np.int32), orc.viterbi(w2, t2, c, g, a)[0])
-    with orc.correctly_rounded_exp():
-        e2 = orc.windowed_marginals(w2, t2, c, g, a, 20, 1, 1, True)
-    _bits(nat.Session(m2, [0]).windowed_marginals(c, g, a, 20), e2)  # (windowed, 2 labels: the switch applies)
+rng = np.random.default_rng(12)
+w3, t3 = synth_model(50, rng, L=3)
+c, g, a = synth_contigs(rng, [60, 5, 200], 50)
+m3 = nat.Model.from_tables(w3, t3)
+y, _ = m3.viterbi(c, g, a)
+assert np.array_equal(y.astype(np.int32), orc.viterbi(w3, t3, c, g, a)[0])
+m, _ = m3.marginals_full(c, g, a)
+assert np.abs(m - orc.full_marginals(w3, t3, c, g, a)[0]).max() <= 1e-12
+p3 = nat.Session(m3, [0]).windowed_marginals(c, g, a, 20)  # (another label count: the environment switch does not apply)
+assert np.abs(p3 - orc.windowed_marginals(w3, t3, c, g, a, 20, 1, 1, True)).max() <= 1e-12
+w2, t2 = synth_model(50, rng)
+m2 = nat.Model.from_tables(w2, t2)
+y2, _ = m2.viterbi(c, g, a)  # (a Viterbi-only layout of a 2-label model: its own kernels)
+assert np.array_equal(y2.astype(np.int32), orc.viterbi(w2, t2, c, g, a)[0])
+with orc.correctly_rounded_exp():
+    e2 = orc.windowed_marginals(w2, t2, c, g, a, 20, 1, 1, True)
+got = nat.Session(m2, [0]).windowed_marginals(c, g, a, 20)  # (windowed, 2 labels: the switch applies)
+assert np.asarray(got).tobytes() == np.asarray(e2).tobytes()
+p40 = nat.Session(m2, [0]).windowed_marginals(c, g, a, 40)  # (a window the mode does not cover: the fast kernels, no error)
+assert np.abs(p40 - orc.windowed_marginals(w2, t2, c, g, a, 40, 1, 1, True)).max() <= 1e-12
+print("ENV_SWITCH_OK")
+"""
+
+
+def test_environment_switch_leaves_viterbi_only_and_any_label_plans_alone():
+    """GECCO_CRF_REFERENCE_BITS=1 is for windowed marginals of 2-label models: a Viterbi-only or whole-contig call, and a
+    model with another label count, keep working (round 5: EUNSUPPORTED out of plan_build).  The library reads the variable
+    once per process: a process of its own."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GECCO_CRF_REFERENCE_BITS="1")
+    cp = subprocess.run([sys.executable, "-c", _ENV_SWITCH_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=300,
+                        cwd=root)
+    assert cp.returncode == 0 and "ENV_SWITCH_OK" in cp.stdout, cp.stdout[-2000:] + cp.stderr[-4000:]
