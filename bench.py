@@ -675,6 +675,22 @@ def main() -> None:
         }
         if not args.windowed_only:
             out["parity"]["viterbi_label_mismatches"] = int((res.d_y[:ng].cpu().numpy() != y_ref.astype(np.int8)).sum())
+        # what "reference-bits mode" delivers against the oracle run with the HOST'S libm exp (what CRFsuite calls): genes whose
+        # probability differs in any bit, and by how many ulps at most -- next to the same count for the fast kernels
+        if model.num_labels == 2:
+            try:
+                ses_rb = nat.Session(model, [local_rank])
+                ses_rb.set_reference_bits(True)
+                p_bits = np.asarray(ses_rb.windowed_marginals(cp, wl["gene_ptr"][: ng + 1], wl["attr_id"], W, STEP, LABEL, True))
+                out["parity"]["reference_bits_vs_libm_oracle"] = _ulp_report(p_bits, p_ref)
+                out["parity"]["fast_kernels_vs_libm_oracle"] = _ulp_report(got, p_ref)
+                with orc.correctly_rounded_exp():
+                    p_cr = orc.windowed_marginals_mt(wl["w"], wl["trans"], cp, wl["gene_ptr"][: ng + 1], wl["attr_id"], W, STEP, LABEL, True,
+                                                     threads=ncpu)
+                out["parity"]["reference_bits_vs_correctly_rounded_oracle"] = _ulp_report(p_bits, p_cr)
+                del ses_rb
+            except Exception as err:
+                out["parity"]["reference_bits_vs_libm_oracle"] = {"error": f"{type(err).__name__}: {err}"}
         if lat_checks:
             # the C port's time for the very inputs of the latency block, and their parity (marginals, labels, cluster rows)
             lw, lt = _lat_model.state_weights()[0], _lat_model.trans_weights()[0]
@@ -711,6 +727,15 @@ def main() -> None:
         print(bline.dumps(bline.compact_line(out, detail=os.path.relpath(path, ROOT) if path.startswith(ROOT) else path)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _ulp_report(a, b):
+    """Two arrays of positive doubles: how many entries differ in any bit, the largest distance in ulps, out of how many."""
+    a, b = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    ok = np.isfinite(a) & np.isfinite(b)
+    d = np.abs(a[ok].view(np.int64) - b[ok].view(np.int64))
+    return {"genes_differing": int((d != 0).sum()) + int((~ok).sum() - (np.isnan(a) & np.isnan(b)).sum()), "max_ulps": int(d.max(initial=0)),
+            "genes": int(a.size)}
 
 
 def _usable_host_threads():

@@ -50,9 +50,10 @@ def test_predict_probabilities_equals_the_reference(crf_cases, reference_bits):
         genes, out, calls, caught = _run_case(crf, case, reference_bits)
         if "error" in case:
             # domain mode with more domains than genes in a contig: the reference's `probabilities` array is sized by GENES while
-            # its windows run over DOMAINS (crf/__init__.py:248-254) and numpy refuses the assignment.  Nothing to compare with;
-            # this implementation answers with a probability per domain.
-            assert prm["feature_type"] == "domain" and case["error"]["type"] == "ValueError"
+            # its windows run over DOMAINS (crf/__init__.py:248-254): numpy refuses the assignment (ValueError), or the annotator
+            # runs out of probabilities (features.py:119: StopIteration inside a generator = RuntimeError).  Nothing to compare
+            # with; this implementation answers with a probability per domain.
+            assert prm["feature_type"] == "domain" and case["error"]["type"] in ("ValueError", "RuntimeError")
             assert len(out) == len(genes)
             n_err += 1
             continue

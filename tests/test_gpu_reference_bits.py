@@ -284,3 +284,38 @@ def test_environment_switch_leaves_viterbi_only_and_any_label_plans_alone():
     cp = subprocess.run([sys.executable, "-c", _ENV_SWITCH_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=300,
                         cwd=root)
     assert cp.returncode == 0 and "ENV_SWITCH_OK" in cp.stdout, cp.stdout[-2000:] + cp.stderr[-4000:]
+
+
+def test_reference_bits_against_the_libm_oracle_on_c3(nat, capsys):
+    """What the mode proves and what it does not.  CRFsuite calls the HOST'S libm `exp`; reference-bits mode computes CRFsuite's
+    operation order with a CORRECTLY ROUNDED exp.  On C3 (2 M genes): bit-identical to the oracle run with a correctly rounded
+    exp on every gene; against the oracle run with this box's glibc `exp` a small share of the genes differs (by a few ulps) --
+    wherever glibc's result is not the correctly rounded one.  The fast kernels differ on most genes (a few ulps as well).
+    The counts are printed and reported by bench.py (`parity.reference_bits_vs_libm_oracle`)."""
+    from gecco_amd import synth
+    from oracle import crf_oracle as orc
+
+    wl = synth.workload("C3")
+    model = nat.Model.from_tables(wl["w"], wl["trans"])
+    cptr, gptr, attr = wl["contig_ptr"], wl["gene_ptr"], wl["attr_id"]
+    libm = orc.windowed_marginals_mt(wl["w"], wl["trans"], cptr, gptr, attr, 20, 1, 1, True)
+    with orc.correctly_rounded_exp():
+        exact = orc.windowed_marginals_mt(wl["w"], wl["trans"], cptr, gptr, attr, 20, 1, 1, True)
+    ses = nat.Session(model, [0])
+    fast = np.asarray(ses.windowed_marginals(cptr, gptr, attr, 20)).copy()
+    ses.set_reference_bits(True)
+    bits = np.asarray(ses.windowed_marginals(cptr, gptr, attr, 20)).copy()
+
+    def ulps(a, b):
+        d = np.abs(a.view(np.int64) - b.view(np.int64))
+        return int((d != 0).sum()), int(d.max())
+
+    n = len(libm)
+    rb_libm, rb_exact, fast_libm, oracle_modes = ulps(bits, libm), ulps(bits, exact), ulps(fast, libm), ulps(libm, exact)
+    with capsys.disabled():
+        print(f"\n[C3, {n} genes] reference-bits vs libm oracle: {rb_libm[0]} genes differ (max {rb_libm[1]} ulps); vs correctly rounded "
+              f"oracle: {rb_exact[0]}; fast kernels vs libm oracle: {fast_libm[0]} (max {fast_libm[1]} ulps); the two oracles: {oracle_modes[0]}")
+    assert rb_exact == (0, 0)
+    assert rb_libm[0] == oracle_modes[0] and rb_libm[0] <= 0.02 * n and rb_libm[1] <= 64
+    assert fast_libm[1] <= 4096 and float(np.abs(fast - libm).max()) <= 1e-12
+    assert int(((bits > 0.8) != (libm > 0.8)).sum()) == 0 and int(((fast > 0.8) != (libm > 0.8)).sum()) == 0
