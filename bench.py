@@ -149,6 +149,8 @@ def main() -> None:
         if dist is not None:
             dist.barrier()
 
+    lane_streams = {}
+
     class Resident:
         """One batch resident on this rank's device: plan + CSR + outputs."""
 
@@ -165,7 +167,12 @@ def main() -> None:
                       "d_y": torch.zeros(max(self.n_genes, 1), dtype=torch.int8, device=dev), "primed": False}
                 # a stream of its own, not the legacy default one (streams are captured into graphs everywhere but there)
                 if os.environ.get("GECCO_BENCH_OWN_STREAM", "1") == "1" or k > 0:
-                    ln["torch_stream"] = torch.cuda.Stream(dev)
+                    # ONE stream per lane index for the whole process: the batches of this script are stepped one after the other,
+                    # and the runtime binds every new stream to one of a few hardware queues -- two streams of a later batch that
+                    # land on the same queue serialise (seen as a 9 us shard step next to a 5 us one, by number of streams made before)
+                    if k not in lane_streams:
+                        lane_streams[k] = torch.cuda.Stream(dev)
+                    ln["torch_stream"] = lane_streams[k]
                     ln["stream"] = ln["torch_stream"].cuda_stream
                 else:
                     ln["stream"] = torch.cuda.current_stream(dev).cuda_stream
@@ -217,6 +224,7 @@ def main() -> None:
             t0 = time.perf_counter()
             for _ in range(steps):
                 self.step(schedule)
+            self.issue_s = (time.perf_counter() - t0) / max(steps, 1)  # what the HOST spent per step (enqueue only, nothing waited for)
             self.flush()
             torch.cuda.synchronize(dev)
             barrier()
@@ -382,6 +390,9 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "ms_per_step_single_region": regions[0] / args.steps * 1e3,
+        # the host's share: wall time of the enqueue loop per step (last region; no wait inside).  A batch whose step is no longer than
+        # this is bound by the launch path (HIP runtime ~3 us + this library ~1 us + ctypes), not by the GPU
+        "host_issue_us_per_step": res.issue_s * 1e6,
         "timed_regions": {"count": len(regions), "steps_each": args.steps, "min_total_ms": args.min_region_ms,
                           "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3,
                           "note": "every region = exactly `steps` steps between barrier + device synchronisation on both sides, "
@@ -474,7 +485,9 @@ def main() -> None:
         mine = sharding.partition_contigs(lengths, world)[rank]
         cptr, gptr, attr, _ = sharding.extract_shard(base["contig_ptr"], base["gene_ptr"], base["attr_id"], mine)
         shard = Resident(model, cptr, gptr, attr, lanes=n_lanes)
-        el = shard.timed(args.steps, args.warmup, 0.0)
+        # (pre-rolled and taken as the median region like the headline: a shard's step is a few microseconds, and a device that
+        # has idled while the shard was being built needs ~10 ms of work to be back at its clocks)
+        el = float(np.median(shard.timed_regions(args.steps, args.warmup, args.preroll_ms, args.min_region_ms)))
         tot = all_sum(shard.n_genes)
         out["strong_scaling"] = {
             "config": f"C4: the {args.workload} batch ({tot} genes) greedy-partitioned by gene count over {world} devices "
@@ -515,10 +528,10 @@ def main() -> None:
         mine = sharding.partition_contigs(lengths, 8)[0]
         cptr, gptr, attr, _ = sharding.extract_shard(base["contig_ptr"], base["gene_ptr"], base["attr_id"], mine)
         sh = Resident(model, cptr, gptr, attr, lanes=n_lanes)
-        el = sh.timed(args.steps, min(args.warmup, 50), 0.0)
+        el = float(np.median(sh.timed_regions(args.steps, min(args.warmup, 50), args.preroll_ms, args.min_region_ms)))  # (pre-rolled, median region)
         wms = sh.plan.time_windowed(sh.d_gp.data_ptr(), sh.d_at.data_ptr(), sh.d_p.data_ptr(), LABEL, sh.stream, warmup=3, iters=50)
         out["c4_shard"] = {"genes": sh.n_genes, "workgroups": sh.plan.num_tiles, "c4_shard_ms": el / args.steps * 1e3,
-                           "windowed_ms": wms,
+                           "windowed_ms": wms, "host_issue_us_per_step": sh.issue_s * 1e6,
                            "note": "rank 0's shard of the 8-way greedy partition (sharding.partition_contigs) on ONE device: "
                                    "8 devices cannot decode the batch faster than this per step"}
         out["c4_shard_ms"] = out["c4_shard"]["c4_shard_ms"]

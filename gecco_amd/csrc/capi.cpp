@@ -59,7 +59,8 @@ struct DeviceGuard {  // restores the caller's current device
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     }
     ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
+        int cur = -1;
+        if (prev >= 0 && (hipGetDevice(&cur) != hipSuccess || cur != prev)) (void)hipSetDevice(prev);
     }
 };
 

@@ -733,18 +733,101 @@ __global__ void __launch_bounds__(kWinThreads, 4) crf_windowed_small_l2(const Wi
 // batch on the first measurement).  K batches take K + 1 launches (plan_run_decode_pipelined: the last call flushes).
 // TILES: window tiles per workgroup, as in crf_windowed_l2 (1 for batches too small to fill the CUs' wave slots: a workgroup's
 // tiles run one after the other, and with a wave or two per SIMD the chain of one tile is all the latency hiding there is).
+// The launch's arguments, compact: the fields of WinArgs / SeqArgs this kernel reads and nothing else (376 bytes instead of the two
+// full blocks' 936).  A step of a small batch is bound by what the HOST spends per launch (tools/host_issue_probe.py: 4.7 us per
+// call at every batch size up to 0.2 M genes), and the runtime's argument copy grows with the block (tools/ubench/launch_floor:
+// +0.8 us for 400 bytes).  The kernel rebuilds the two blocks in registers; fields it leaves zero fold away as constants.
+struct PipeArgs {
+    // window tiles (batch k)
+    const int32_t *gene_ptr, *attr_id;
+    const double2 *wtab2;
+    const int32_t *c_slot, *c_gene, *c_n;
+    const int4 *tile_desc;
+    const uint64_t *start_bits;
+    double *p_out, *dstate_out;
+    const double *rtab;
+    int32_t S, ntiles, step, label, n_genes, A, all_regular, nvd8;
+    double mu01, rho, kappa_over_mu01, inv_kappa, ratio_zmax, expc5[5];
+    // Viterbi workgroups (batch k - 1)
+    const double *dstate;
+    const uint8_t *flags;
+    const uint16_t *lane_bits;
+    const int32_t *cblk, *csr_gene_ptr, *csr_attr_id;
+    const double2 *csr_wtab01;
+    double2 *alpha;
+    uint32_t *vd_stats;
+    int8_t *y;
+    int32_t s_n_genes, csr_n_attrs, v_exact, n_cblocks;
+    double t00, t01, t10, t11, v_lo, v_hi, v_k, v_wmax2, v_tmax;
+};
+
 template <int TILES, int WGS>
-__global__ void __launch_bounds__(kWinThreads, WGS) crf_decode_pipelined(const WinArgs P, const SeqArgs A, const int nvd8) {
+__global__ void __launch_bounds__(kWinThreads, WGS) crf_decode_pipelined(const PipeArgs K) {
     using Smem = WinSmem<20, kWinThreads, TILES, true>;
     constexpr size_t kBytes = sizeof(Smem) > sizeof(VdShortSmem) ? sizeof(Smem) : sizeof(VdShortSmem);
     static_assert(kBytes <= 20480, "eight workgroups per CU");
     __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
     const int b = blockIdx.x;
-    if (b >= nvd8) {
-        windowed_tile<20, true, false, kWinThreads, TILES, true>(P, *reinterpret_cast<Smem *>(raw), xcd_remap(b - nvd8, P.ntiles));
+    if (b >= K.nvd8) {
+        WinArgs P{};
+        P.gene_ptr = K.gene_ptr;
+        P.attr_id = K.attr_id;
+        P.wtab2 = K.wtab2;
+        P.c_slot = K.c_slot;
+        P.c_gene = K.c_gene;
+        P.c_n = K.c_n;
+        P.tile_desc = K.tile_desc;
+        P.start_bits = K.start_bits;
+        P.p_out = K.p_out;
+        P.dstate_out = K.dstate_out;
+        P.rtab = K.rtab;
+        P.S = K.S;
+        P.ntiles = K.ntiles;
+        P.W = 20;
+        P.step = K.step;
+        P.L = 2;
+        P.label = K.label;
+        P.n_genes = K.n_genes;
+        P.A = K.A;
+        P.tiles_per_wg = TILES;
+        P.all_regular = K.all_regular;
+        P.mu01 = K.mu01;
+        P.rho = K.rho;
+        P.kappa_over_mu01 = K.kappa_over_mu01;
+        P.inv_kappa = K.inv_kappa;
+        P.ratio_zmax = K.ratio_zmax;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) P.expc[7 + i] = K.expc5[i];  // (mu_exp_tab reads 1/6! ... 1/2! only)
+        P.csr_begin = P.csr_end = -1;
+        windowed_tile<20, true, false, kWinThreads, TILES, true>(P, *reinterpret_cast<Smem *>(raw), xcd_remap(b - K.nvd8, K.ntiles));
         return;
     }
-    if (b >= A.n_cblocks) return;
+    if (b >= K.n_cblocks) return;
+    SeqArgs A{};
+    A.dstate = K.dstate;
+    A.flags = K.flags;
+    A.lane_bits = K.lane_bits;
+    A.cblk = K.cblk;
+    A.csr_gene_ptr = K.csr_gene_ptr;
+    A.csr_attr_id = K.csr_attr_id;
+    A.csr_wtab01 = K.csr_wtab01;
+    A.csr_n_attrs = K.csr_n_attrs;
+    A.alpha = K.alpha;
+    A.vd_stats = K.vd_stats;
+    A.y = K.y;
+    A.n_genes = K.s_n_genes;
+    A.n_cblocks = K.n_cblocks;
+    A.short_contigs = 1;
+    A.v_exact = K.v_exact;
+    A.t00 = K.t00;
+    A.t01 = K.t01;
+    A.t10 = K.t10;
+    A.t11 = K.t11;
+    A.v_lo = K.v_lo;
+    A.v_hi = K.v_hi;
+    A.v_k = K.v_k;
+    A.v_wmax2 = K.v_wmax2;
+    A.v_tmax = K.v_tmax;
     vd_short_block(A, b, *reinterpret_cast<VdShortSmem *>(raw));
 }
 
@@ -882,11 +965,59 @@ bool decode_pipelined_ok(const WinArgs &w, const SeqArgs &s) {
 
 hipError_t launch_decode_pipelined(const WinArgs &w, const SeqArgs &s, hipStream_t stream) {
     if (!decode_pipelined_ok(w, s)) return hipErrorNotSupported;
-    const int nvd8 = (s.n_cblocks + 7) & ~7;
+    PipeArgs k{};
+    k.gene_ptr = w.gene_ptr;
+    k.attr_id = w.attr_id;
+    k.wtab2 = w.wtab2;
+    k.c_slot = w.c_slot;
+    k.c_gene = w.c_gene;
+    k.c_n = w.c_n;
+    k.tile_desc = w.tile_desc;
+    k.start_bits = w.start_bits;
+    k.p_out = w.p_out;
+    k.dstate_out = w.dstate_out;
+    k.rtab = w.rtab;
+    k.S = w.S;
+    k.ntiles = w.ntiles;
+    k.step = w.step;
+    k.label = w.label;
+    k.n_genes = w.n_genes;
+    k.A = w.A;
+    k.all_regular = w.all_regular;
+    k.nvd8 = (s.n_cblocks + 7) & ~7;
+    k.mu01 = w.mu01;
+    k.rho = w.rho;
+    k.kappa_over_mu01 = w.kappa_over_mu01;
+    k.inv_kappa = w.inv_kappa;
+    k.ratio_zmax = w.ratio_zmax;
+    for (int i = 0; i < 5; ++i) k.expc5[i] = w.expc[7 + i];
+    k.dstate = s.dstate;
+    k.flags = s.flags;
+    k.lane_bits = s.lane_bits;
+    k.cblk = s.cblk;
+    k.csr_gene_ptr = s.csr_gene_ptr;
+    k.csr_attr_id = s.csr_attr_id;
+    k.csr_wtab01 = s.csr_wtab01;
+    k.csr_n_attrs = s.csr_n_attrs;
+    k.alpha = s.alpha;
+    k.vd_stats = s.vd_stats;
+    k.y = s.y;
+    k.s_n_genes = s.n_genes;
+    k.v_exact = s.v_exact;
+    k.n_cblocks = s.n_cblocks;
+    k.t00 = s.t00;
+    k.t01 = s.t01;
+    k.t10 = s.t10;
+    k.t11 = s.t11;
+    k.v_lo = s.v_lo;
+    k.v_hi = s.v_hi;
+    k.v_k = s.v_k;
+    k.v_wmax2 = s.v_wmax2;
+    k.v_tmax = s.v_tmax;
     if (w.tiles_per_wg == 1)
-        hipLaunchKernelGGL((crf_decode_pipelined<1, 6>), dim3(nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, w, s, nvd8);
+        hipLaunchKernelGGL((crf_decode_pipelined<1, 6>), dim3(k.nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, k);
     else
-        hipLaunchKernelGGL((crf_decode_pipelined<2, 8>), dim3(nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, w, s, nvd8);
+        hipLaunchKernelGGL((crf_decode_pipelined<2, 8>), dim3(k.nvd8 + w.ntiles), dim3(kWinThreads), 0, stream, k);
     return hipGetLastError();
 }
 

@@ -102,9 +102,54 @@ int get_device_tables(const Model &m, int device, const DeviceTables **out) {
         free_device_tables(t);
         return rc;
     }
+    if (m.L == 2) {
+        for (int label = 0; label < 2; ++label) {
+            DeviceTables::WinConsts &c = t->win[label];
+            // exp() of differences only: every constant is a ratio of transition weights
+            const int o = 1 - label;
+            auto T = [&](int i, int j) { return m.trans[size_t(i) * 2 + j]; };
+            c.mu01 = std::exp(T(o, label) + T(label, o) - 2.0 * T(o, o));
+            c.rho = std::exp(T(label, label) + T(o, o) - T(o, label) - T(label, o));  // mu11 / mu01
+            const double kappa = std::exp(T(label, o) - T(o, o));
+            c.kappa_over_mu01 = std::exp(T(o, o) - T(o, label));                       // kappa / mu01
+            c.inv_kappa = 1.0 / kappa;
+            const double mx = *std::max_element(m.trans.begin(), m.trans.end());
+            auto G = [&](int i, int j) { return std::exp(m.trans[size_t(i) * 2 + j] - mx); };
+            c.g00 = G(o, o);
+            c.g01 = G(o, label);
+            c.g10 = G(label, o);
+            c.g11 = G(label, label);
+            fill_exp_coefficients(c.expc);
+            const char *env = std::getenv("GECCO_CRF_RATIO");
+            c.ratio_zmax = (env && env[0] == '0') ? -1.0 : 1.0e250;
+        }
+        DeviceTables::SeqConsts &q = t->seq;
+        q.mx = *std::max_element(m.trans.begin(), m.trans.end());
+        q.m00 = std::exp(m.trans[0] - q.mx);
+        q.m01 = std::exp(m.trans[1] - q.mx);
+        q.m10 = std::exp(m.trans[2] - q.mx);
+        q.m11 = std::exp(m.trans[3] - q.mx);
+        const double lo = *std::min_element(m.trans.begin(), m.trans.end());
+        q.raw_fold = (q.mx - lo) * double(kSeqGenesPerLane) < 600.0 ? 1 : 0;
+        q.v_lo = m.trans[1] - m.trans[3];
+        q.v_hi = m.trans[0] - m.trans[2];
+        q.v_k = m.trans[3] - m.trans[0];
+        const char *env = std::getenv("GECCO_CRF_VD_EXACT");
+        q.v_exact = (env && env[0] == '0') ? 0 : 1;
+        fill_exp_coefficients(q.expc);
+        t->consts_ok = true;
+    }
     m.dev_tables.push_back(t);
     *out = t;
     return GECCO_CRF_OK;
+}
+
+// hipSetDevice only when the calling thread is on another device (the C ABI's guard restores the caller's device afterwards):
+// a launch-bound step used to make four runtime calls for this
+static inline int use_device(int device) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == device) return GECCO_CRF_OK;
+    return check_hip(hipSetDevice(device), "hipSetDevice");
 }
 
 int Arena::reserve(size_t bytes, const char *what) {
@@ -683,7 +728,7 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
         set_error("null device buffer");
         return GECCO_CRF_EINVAL;
     }
-    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
+    int rc = use_device(p.device);
     if (rc) return rc;
     const Model &m = *p.model;
     if (p.general) return run_windowed_general(p, d_gene_ptr, d_attr_id, label, d_p_out, stream);
@@ -715,28 +760,17 @@ static int run_windowed_impl(Plan &p, const int32_t *d_gene_ptr, const int32_t *
     a.all_regular = p.all_regular ? 1 : 0;
     a.rescale_mask = p.rescale_mask;
     {
-        // exp() of differences only: every constant is a ratio of transition weights
-        const int o = 1 - label;
-        auto T = [&](int i, int j) { return m.trans[size_t(i) * 2 + j]; };
-        a.mu01 = std::exp(T(o, label) + T(label, o) - 2.0 * T(o, o));
-        a.rho = std::exp(T(label, label) + T(o, o) - T(o, label) - T(label, o));  // mu11 / mu01
-        const double kappa = std::exp(T(label, o) - T(o, o));
-        a.kappa_over_mu01 = std::exp(T(o, o) - T(o, label));                       // kappa / mu01
-        a.inv_kappa = 1.0 / kappa;
-    }
-    {
-        const int o = 1 - label;
-        const double mx = *std::max_element(m.trans.begin(), m.trans.end());
-        auto G = [&](int i, int j) { return std::exp(m.trans[size_t(i) * 2 + j] - mx); };
-        a.g00 = G(o, o);
-        a.g01 = G(o, label);
-        a.g10 = G(label, o);
-        a.g11 = G(label, label);
-    }
-    fill_exp_coefficients(a.expc);
-    {
-        const char *env = std::getenv("GECCO_CRF_RATIO");
-        a.ratio_zmax = (env && env[0] == '0') ? -1.0 : 1.0e250;
+        const DeviceTables::WinConsts &c = p.tables_model->win[label];  // (model constants, computed once per device: get_device_tables)
+        a.mu01 = c.mu01;
+        a.rho = c.rho;
+        a.kappa_over_mu01 = c.kappa_over_mu01;
+        a.inv_kappa = c.inv_kappa;
+        a.g00 = c.g00;
+        a.g01 = c.g01;
+        a.g10 = c.g10;
+        a.g11 = c.g11;
+        std::memcpy(a.expc, c.expc, sizeof(a.expc));
+        a.ratio_zmax = c.ratio_zmax;
     }
     a.csr_begin = int32_t(p.csr_begin);  // (row pointers are 32-bit)
     a.csr_end = int32_t(p.csr_end);
@@ -821,7 +855,7 @@ int plan_ensure_seq(Plan &p, hipStream_t stream, bool sync) {
         set_error("host-only plan: no HIP device bound (there is no CPU fallback)");
         return GECCO_CRF_ENODEV;
     }
-    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
+    int rc = use_device(p.device);
     if (rc) return rc;
     const size_t n = size_t(p.n_genes);
     // short contigs (none longer than a scan block): whole contigs are packed into workgroups of <= 2048 genes
@@ -981,7 +1015,7 @@ int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
         set_error("host-only plan: no HIP device bound (there is no CPU fallback)");
         return GECCO_CRF_ENODEV;
     }
-    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
+    int rc = use_device(p.device);
     if (rc) return rc;
     if (p.general) return GECCO_CRF_OK;  // the any-L path has its own workspace
     if ((rc = ensure_seq(p, stream))) return rc;
@@ -1019,28 +1053,23 @@ int fill_seq_args(Plan &p, SeqArgs &a, hipStream_t stream) {
     a.short_contigs = p.seq_short ? 1 : 0;
     a.n_contigs = p.n_contigs;
     a.n_genes = p.n_genes;
-    a.mx = *std::max_element(m.trans.begin(), m.trans.end());
+    const DeviceTables::SeqConsts &q = p.tables_model->seq;  // (model constants, computed once per device)
+    a.mx = q.mx;
     a.t00 = m.trans[0];
     a.t01 = m.trans[1];
     a.t10 = m.trans[2];
     a.t11 = m.trans[3];
-    a.m00 = std::exp(a.t00 - a.mx);
-    a.m01 = std::exp(a.t01 - a.mx);
-    a.m10 = std::exp(a.t10 - a.mx);
-    a.m11 = std::exp(a.t11 - a.mx);
+    a.m00 = q.m00;
+    a.m01 = q.m01;
+    a.m10 = q.m10;
+    a.m11 = q.m11;
     a.dstate = reinterpret_cast<const double *>(a.state);  // same workspace, one of the two forms per call
-    {
-        const double lo = *std::min_element(m.trans.begin(), m.trans.end());
-        a.raw_fold = (a.mx - lo) * double(kSeqGenesPerLane) < 600.0 ? 1 : 0;
-    }
-    a.v_lo = a.t01 - a.t11;
-    a.v_hi = a.t00 - a.t10;
-    a.v_k = a.t11 - a.t00;
-    {
-        const char *env = std::getenv("GECCO_CRF_VD_EXACT");
-        a.v_exact = (env && env[0] == '0') ? 0 : 1;
-    }
-    fill_exp_coefficients(a.expc);
+    a.raw_fold = q.raw_fold;
+    a.v_lo = q.v_lo;
+    a.v_hi = q.v_hi;
+    a.v_k = q.v_k;
+    a.v_exact = q.v_exact;
+    std::memcpy(a.expc, q.expc, sizeof(a.expc));
     return GECCO_CRF_OK;
 }
 }  // namespace
@@ -1262,7 +1291,11 @@ int plan_run_decode_pipelined(Plan *cur, const int32_t *d_gene_ptr, const int32_
         double *d_dstate = nullptr;
         if (!p.general && p.fast_ok && p.skipped.empty() && p.device >= 0 && p.n_genes > 0) {
             SeqArgs ca;
-            if ((rc = fill_seq_args(p, ca, stream))) return rc;
+            if (prev_delta && prev == cur) {
+                ca = pa;  // (a plan that follows itself: the block has just been filled for the Viterbi side)
+            } else if ((rc = fill_seq_args(p, ca, stream))) {
+                return rc;
+            }
             if (viterbi_delta_ok(ca, nullptr)) {
                 delta = true;
                 d_dstate = const_cast<double *>(reinterpret_cast<const double *>(ca.state)) + size_t(parity) * (size_t(p.n_genes) + 8);
@@ -1271,7 +1304,14 @@ int plan_run_decode_pipelined(Plan *cur, const int32_t *d_gene_ptr, const int32_
         PipelinedLaunch fl{};
         fl.seq = &pa;
         fl.took = &took;
-        if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, d_dstate, stream, (delta && prev_delta) ? &fl : nullptr)))
+        // A/B switch (wrong labels): the tiles keep their score differences to themselves -- what the WRITE half of the hand-over
+        // between launches (8 B per gene + its five vector instructions) costs the step (profiles/r06_ab.txt)
+        static const bool ab_no_store = [] {
+            const char *env = std::getenv("GECCO_CRF_AB_NO_HANDOVER_STORE");
+            return env && env[0] == '1';
+        }();
+        if ((rc = run_windowed_impl(p, d_gene_ptr, d_attr_id, label, d_p_out, nullptr, ab_no_store ? nullptr : d_dstate, stream,
+                                    (delta && prev_delta) ? &fl : nullptr)))
             return rc;
         p.pipe.pending = delta;
         p.pipe.parity = delta ? parity : p.pipe.parity;
@@ -1288,7 +1328,7 @@ int plan_viterbi_stats(Plan &p, int64_t out[4], bool reset) {
     for (int i = 0; i < 4; ++i) out[i] = 0;
     std::lock_guard<std::mutex> lock(p.ws_mutex);
     if (p.device < 0 || !p.d_seq_ws) return GECCO_CRF_OK;  // nothing has been decoded yet
-    int rc = check_hip(hipSetDevice(p.device), "hipSetDevice");
+    int rc = use_device(p.device);
     if (rc) return rc;
     if ((rc = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize"))) return rc;
     uint32_t v[4] = {0, 0, 0, 0};

@@ -23,6 +23,17 @@ struct DeviceTables {
     double *trans = nullptr;      // [L*L] raw weights (general-L Viterbi)
     double wmax_abs = 0.0, tmax_abs = 0.0;  // largest |state weight| / |transition weight| (bounds of the Viterbi exactness margin)
     double *rtab[2] = {nullptr, nullptr};  // L == 2: [32] mu01(label) * 2^(j/32), the exp table of the window kernel's slot constants
+    // Host-side constants of the kernels' argument blocks that depend on the model alone (L == 2), computed ONCE here: a launch
+    // used to recompute them (17 exp calls, 36 divisions, three getenv scans per pipelined decode call: ~1 us of a 5 us
+    // launch-bound step, tools/host_issue_probe.py).
+    struct WinConsts {
+        double mu01, rho, kappa_over_mu01, inv_kappa, g00, g01, g10, g11, expc[12], ratio_zmax;
+    } win[2];  // by queried label
+    struct SeqConsts {
+        double mx, m00, m01, m10, m11, v_lo, v_hi, v_k, expc[12];
+        int32_t raw_fold, v_exact;
+    } seq;
+    bool consts_ok = false;
 };
 
 // A pinned host block mirrored by a device block: plan tables are written on the host side and reach

@@ -31,4 +31,7 @@ python tools/prof_summary.py $O crf_ > $O/summary.txt 2>&1
 mkdir -p $O/win; for k in 1 2 3 4 5 6; do mv $O/pmc$k $O/win/ 2>/dev/null; done
 python tools/pmc_to_json.py $O/win C3 $TAG crf_windowed_l2 > $O/pmc.json 2>&1
 python tools/pmc_to_json.py $O/pipe C3:pipelined $TAG crf_decode_pipelined >> $O/pmc.json 2>&1
+# the committed begin-to-end durations bench.py quotes as roofline.kernel_us_rocprof (one decode stream: a launch alone on the chip)
+python tools/kt_to_json.py $O/kt C3:pipelined $TAG crf_decode_pipelined >> $O/pmc.json 2>&1
+python tools/kt_to_json.py $O/kt C3 $TAG crf_windowed_l2 >> $O/pmc.json 2>&1
 cat $O/summary.txt
