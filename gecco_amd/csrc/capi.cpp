@@ -91,7 +91,7 @@ int check_device(int32_t device) {
 }  // namespace
 
 GECCO_API const char *gecco_crf_last_error(void) { return last_error(); }
-GECCO_API int gecco_crf_version(void) { return 220; }
+GECCO_API int gecco_crf_version(void) { return 221; }
 
 GECCO_API int gecco_crf_model_load(const uint8_t *lcrf, size_t n_bytes, gecco_crf_model **out) {
     if (!out) return GECCO_CRF_EINVAL;

@@ -48,7 +48,7 @@ typedef struct gecco_crf_plan gecco_crf_plan;
 
 /* Thread-local description of the last error returned on this thread. */
 const char *gecco_crf_last_error(void);
-/* ABI version: major*100 + minor*10 + patch (2.2.0 = 220). */
+/* ABI version: major*100 + minor*10 + patch (2.2.1 = 221). */
 int gecco_crf_version(void);
 
 /* ---- model (replaces [EXT] pycrfsuite.Tagger.open / labels() / info(); the blob is the

@@ -56,3 +56,7 @@ for nl in (1, 2, 4):
     print(f"run_windowed, {nl} streams: issue {i:.2f} us per call, with the final wait {t:.2f}")
     i, t = loop(lambda ln: ln["plan"].run_decode_pipelined(a_gp, a_at, ln["ap"], ln["plan"], ln["ay"], 1, ln["s"]), nl)
     print(f"run_decode_pipelined, {nl} streams: issue {i:.2f} us per call, with the final wait {t:.2f}")
+    for ln in lanes:
+        ln["call"] = ln["plan"].bind_decode_pipelined(a_gp, a_at, ln["ap"], ln["plan"], ln["ay"], 1, ln["s"])
+    i, t = loop(lambda ln: ln["call"](), nl)
+    print(f"the same through Plan.bind_decode_pipelined (arguments converted once), {nl} streams: issue {i:.2f} us per call, with the final wait {t:.2f}")
