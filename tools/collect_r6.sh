@@ -19,5 +19,5 @@ python tools/pmc_to_json.py $O/pipe C3:pipelined r06 crf_decode_pipelined > /dev
 python tools/pmc_to_json.py $O/c5win C5 r06 crf_windowed_l2 > /dev/null
 python tools/pmc_to_json.py $O/nostore C3:pipelined:no_handover_store r06 crf_decode_pipelined > /dev/null
 python tools/kt_to_json.py $O/kt C3:pipelined r06 crf_decode_pipelined
-python tools/kt_to_json.py $O/kt C3 r06 crf_windowed_l2
+python tools/kt_to_json.py $O/ktw C3 r06 crf_windowed_l2 "rocprofv3 --kernel-trace --stats of bench.py --streams 1 --windowed-only (plain windowed launches)"
 python -c "import json; d=json.load(open('$P/pmc_traffic.json')); print({k: (v.get('kernel_source_sha16'), v.get('hbm_bytes_per_launch'), v.get('kernel_us_rocprof')) for k, v in d.items() if isinstance(v, dict)})"
