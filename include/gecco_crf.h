@@ -254,9 +254,14 @@ int gecco_crf_session_stats(const gecco_crf_session *s, int32_t *n_chunks, int64
  * test, which compares whole output files (/root/reference/galaxy/gecco.xml:83-111; probabilities are printed with 16-17
  * digits).  With this switch on, the session's windowed marginals -- and so its cluster calls and the p of its decode calls --
  * are computed in CRFsuite's OWN operation order ([EXT] crf1dc_exp_state / alpha_score / beta_score / marginal_point as
- * restated in oracle/crf_oracle.c) with a correctly rounded exp in place of libm's: the reference's bits wherever its libm
- * rounds correctly (glibc: all but ~0.07 % of arguments), at about six times the fast kernels' time.  2-label models, windows
- * of at most 32 genes (GECCO_CRF_EUNSUPPORTED otherwise).  GECCO_CRF_REFERENCE_BITS=1 switches it on for every session and plan. */
+ * restated in oracle/crf_oracle.c) with a CORRECTLY ROUNDED exp in place of libm's.  What that is and is not: bit-identical to
+ * the oracle run with a correctly rounded exp (libquadmath) on every gene, string-identical to the reference's fixture files
+ * (85 of 85 float cells); against the oracle run with the host's glibc exp -- what CRFsuite calls -- 2 881 of 1 999 989 genes of
+ * the C3 benchmark batch differ, by at most 14 ulps (glibc's exp is not correctly rounded on every argument, and which ones
+ * depends on its version and the CPU's FMA path); the fast kernels differ on 89 % of the genes, by at most 64 ulps.  About five
+ * times the fast window kernel's time.  2-label models, windows of at most 32 genes (GECCO_CRF_EUNSUPPORTED otherwise).
+ * GECCO_CRF_REFERENCE_BITS=1 (read once per process) switches it on for the windowed marginals of every 2-label session and plan
+ * whose window it covers; other layouts keep their kernels. */
 int gecco_crf_session_set_reference_bits(gecco_crf_session *s, int32_t on);
 /* The exp that mode uses, on the host (a double-double evaluation; same code as the device's): out[i] = the double nearest to
  * exp(x[i]). */
