@@ -151,3 +151,46 @@ def test_device_composition_equals_the_reference():
             normalize, pvalue = key.split(",")[0].endswith("1"), key.split(",")[1].endswith("1")
             got = composition.domain_composition(cluster, case["all_possible"], normalize=normalize, pvalue=pvalue)
             assert np.asarray(got, dtype=np.float64).tobytes() == np.asarray(exp, dtype=np.float64).tobytes()
+
+
+def test_predict_tables_equals_the_reference(crf_cases):
+    """The columnar path (`predict.predict_tables`: table columns -> native packer -> device -> table columns) on the
+    reference's inputs written as gene / feature tables: gene order, probabilities (<= 1e-12; NaN where the reference left a
+    skipped contig's genes without probability) and warnings as the reference's `predict_probabilities` gave them."""
+    from gecco_amd import predict, tables
+    from gecco_amd.crf import ClusterCRF
+
+    crf = ClusterCRF.trained(GOLDEN)
+    n = 0
+    worst = 0.0
+    for case in crf_cases:
+        prm = case["params"]
+        if prm["feature_type"] != "protein" or "expect" not in case:
+            continue
+        crf.window_size, crf.window_step = prm["window_size"], prm["window_step"]
+        rows = case["genes"]
+        gcols = {"sequence_id": np.array([r[0] for r in rows], dtype=object), "protein_id": np.array([r[1] for r in rows], dtype=object),
+                 "start": np.array([r[2] for r in rows], dtype=np.int64), "end": np.array([r[3] for r in rows], dtype=np.int64),
+                 "strand": np.array(["+" if r[4] > 0 else "-" for r in rows], dtype=object)}
+        frows = [(r, d) for r in rows for d in r[5]]
+        fcols = {"sequence_id": np.array([r[0] for r, _ in frows], dtype=object), "protein_id": np.array([r[1] for r, _ in frows], dtype=object),
+                 "start": np.array([r[2] for r, _ in frows], dtype=np.int64), "end": np.array([r[3] for r, _ in frows], dtype=np.int64),
+                 "strand": np.array(["+" if r[4] > 0 else "-" for r, _ in frows], dtype=object),
+                 "domain": np.array([d[0] for _, d in frows], dtype=object), "hmm": np.full(len(frows), "Pfam", dtype=object),
+                 "i_evalue": np.full(len(frows), 1e-5), "pvalue": np.full(len(frows), 1e-7),
+                 "domain_start": np.array([d[1] for _, d in frows], dtype=np.int64), "domain_end": np.array([d[2] for _, d in frows], dtype=np.int64)}
+        if not frows:
+            continue
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            g_out, f_out, _ = predict.predict_tables(tables.GeneTable(gcols), tables.FeatureTable(fcols), crf, pad=prm["pad"])
+        exp = case["expect"]
+        assert list(g_out.protein_id) == exp["order"]
+        assert sorted(str(w.message) for w in caught) == sorted(m for _, m in case["warnings"])
+        ep = np.array([np.nan if p is None else p for p in exp["p"]], dtype=np.float64)
+        gp = np.asarray(g_out.average_p, dtype=np.float64)
+        assert np.array_equal(np.isnan(gp), np.isnan(ep))
+        if (~np.isnan(ep)).any():
+            worst = max(worst, float(np.nanmax(np.abs(gp - ep))))
+        n += 1
+    assert n >= 150 and worst <= 1e-12, (n, worst)
