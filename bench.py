@@ -170,10 +170,16 @@ def main() -> None:
                     # ONE stream per lane index for the whole process: the batches of this script are stepped one after the other,
                     # and the runtime binds every new stream to one of a few hardware queues -- two streams of a later batch that
                     # land on the same queue serialise (seen as a 9 us shard step next to a 5 us one, by number of streams made before)
-                    if k not in lane_streams:
-                        lane_streams[k] = torch.cuda.Stream(dev)
-                    ln["torch_stream"] = lane_streams[k]
-                    ln["stream"] = ln["torch_stream"].cuda_stream
+                    mask = os.environ.get("GECCO_BENCH_CU_MASK")  # experiment: decode stream k sees a subset of the CUs (profiles/EXPERIMENTS.md)
+                    if mask:
+                        if k not in lane_streams:
+                            lane_streams[k] = _masked_stream(mask, k, max(1, lanes))
+                        ln["stream"] = lane_streams[k]
+                    else:
+                        if k not in lane_streams:
+                            lane_streams[k] = torch.cuda.Stream(dev)
+                        ln["torch_stream"] = lane_streams[k]
+                        ln["stream"] = ln["torch_stream"].cuda_stream
                 else:
                     ln["stream"] = torch.cuda.current_stream(dev).cuda_stream
                 self.lanes.append(ln)
@@ -753,6 +759,34 @@ def main() -> None:
         print(bline.dumps(bline.compact_line(out, detail=os.path.relpath(path, ROOT) if path.startswith(ROOT) else path)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _masked_stream(pattern, k, n):
+    """hipExtStreamCreateWithCUMask: decode stream k of n on a subset of the 256 CU bits.  pattern "block": bits [256 k / n, 256 (k + 1) / n);
+    "interleave": bits i with (i // 8) % n == k; "half:<bits>": stream 0 gets the first <bits> of every 32, the others the rest."""
+    import ctypes
+
+    import torch
+
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    if pattern == "block":
+        bits = range(256 * k // n, 256 * (k + 1) // n)
+    elif pattern == "interleave":
+        bits = [i for i in range(256) if (i // 8) % n == k]
+    elif pattern.startswith("half:"):
+        c = int(pattern.split(":")[1])
+        bits = [i for i in range(256) if ((i & 31) < c) == (k == 0)]
+    else:
+        raise SystemExit(f"GECCO_BENCH_CU_MASK={pattern!r}?")
+    words = (ctypes.c_uint32 * 8)()
+    for b in bits:
+        words[b >> 5] |= 1 << (b & 31)
+    h = ctypes.c_void_p()
+    hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+    if rc:
+        raise SystemExit(f"hipExtStreamCreateWithCUMask failed: {rc}")
+    return h.value
 
 
 def _ulp_report(a, b):
