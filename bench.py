@@ -90,7 +90,8 @@ def main() -> None:
     ap.add_argument("--no-8d", "--no-genome", dest="no_8d", action="store_true", help="skip the second roofline point on the other weight law")
     ap.add_argument("--no-c4", action="store_true", help="skip the 8-way shard point (profiles: keeps the per-kernel averages on one workload)")
     ap.add_argument("--streams", type=int, default=2,
-                    help="pipelined schedule: independent decode streams (plan + HIP stream each) the batches alternate between")
+                    help="pipelined schedule: independent decode streams (plan + HIP stream each) the batches alternate between (three help an "
+                         "8-way shard of C3 -- 4.2-4.7 against 5.3-5.9 us -- and nothing else: profiles/EXPERIMENTS.md)")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "two-launch"],
                     help="pipelined: one launch per step = window tiles of batch k + Viterbi workgroups of batch k - 1 "
                          "(gecco_crf_plan_run_decode_pipelined, + one flush); two-launch: gecco_crf_plan_run_decode")
@@ -281,7 +282,12 @@ def main() -> None:
         cptr, gptr, attr = synth.synth_contigs(rng, lengths, wl["A"], planted=0.01, hot_attrs=hot)
         wl.update(contig_ptr=cptr, gene_ptr=gptr, attr_id=attr)
     model = c1_model if args.workload == "C1" else nat.Model.from_tables(wl["w"], wl["trans"])
-    n_lanes = args.streams if (args.schedule == "pipelined" and not args.windowed_only) else 1
+    def lanes_for(n_genes_batch):
+        if args.schedule != "pipelined" or args.windowed_only:
+            return 1
+        return max(1, args.streams)
+
+    n_lanes = lanes_for(int(wl["contig_ptr"][-1]))
     res = Resident(model, wl["contig_ptr"], wl["gene_ptr"], wl["attr_id"], lanes=n_lanes)
     n_genes, nnz = res.n_genes, res.nnz
 
@@ -503,7 +509,7 @@ def main() -> None:
         lengths = np.diff(base["contig_ptr"]).astype(np.int64)
         mine = sharding.partition_contigs(lengths, world)[rank]
         cptr, gptr, attr, _ = sharding.extract_shard(base["contig_ptr"], base["gene_ptr"], base["attr_id"], mine)
-        shard = Resident(model, cptr, gptr, attr, lanes=n_lanes)
+        shard = Resident(model, cptr, gptr, attr, lanes=lanes_for(int(cptr[-1])))
         # (pre-rolled and taken as the median region like the headline: a shard's step is a few microseconds, and a device that
         # has idled while the shard was being built needs ~10 ms of work to be back at its clocks)
         el = float(np.median(shard.timed_regions(args.steps, args.warmup, args.preroll_ms, args.min_region_ms)))
@@ -546,11 +552,11 @@ def main() -> None:
         lengths = np.diff(base["contig_ptr"]).astype(np.int64)
         mine = sharding.partition_contigs(lengths, 8)[0]
         cptr, gptr, attr, _ = sharding.extract_shard(base["contig_ptr"], base["gene_ptr"], base["attr_id"], mine)
-        sh = Resident(model, cptr, gptr, attr, lanes=n_lanes)
+        sh = Resident(model, cptr, gptr, attr, lanes=lanes_for(int(cptr[-1])))
         el = float(np.median(sh.timed_regions(args.steps, min(args.warmup, 50), args.preroll_ms, args.min_region_ms)))  # (pre-rolled, median region)
         wms = sh.plan.time_windowed(sh.d_gp.data_ptr(), sh.d_at.data_ptr(), sh.d_p.data_ptr(), LABEL, sh.stream, warmup=3, iters=50)
         out["c4_shard"] = {"genes": sh.n_genes, "workgroups": sh.plan.num_tiles, "c4_shard_ms": el / args.steps * 1e3,
-                           "windowed_ms": wms, "host_issue_us_per_step": sh.issue_s * 1e6,
+                           "windowed_ms": wms, "host_issue_us_per_step": sh.issue_s * 1e6, "decode_streams": len(sh.lanes),
                            "note": "rank 0's shard of the 8-way greedy partition (sharding.partition_contigs) on ONE device: "
                                    "8 devices cannot decode the batch faster than this per step"}
         out["c4_shard_ms"] = out["c4_shard"]["c4_shard_ms"]
