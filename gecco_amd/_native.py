@@ -155,6 +155,8 @@ SIGNATURES = {
     "gecco_crf_cluster_rows_max_p": (_vp, [_vp]),
     "gecco_crf_cluster_rows_strings": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "gecco_crf_exact_mean": (ctypes.c_double, [_c_f64p, ctypes.c_int64]),
+    "gecco_crf_gather_f64": (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp]),
+    "gecco_crf_packed_order_info": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "gecco_crf_tsv_format": (
         ctypes.c_int,
         [ctypes.c_int64, ctypes.c_int32, _c_i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_char_p, ctypes.POINTER(_vp),
@@ -604,6 +606,17 @@ class PackedTables:
         if h:
             self._lib.gecco_crf_packed_free(h)
 
+    def order_info(self, gene_start: np.ndarray, gene_end: np.ndarray):
+        """(rows_in_order, refiner_order_differs) from the gene table's `start` / `end` columns (`gecco_crf_packed_order_info`):
+        whether the genes in scoring order are the gene table's rows 0 .. n - 1, and whether the refiner's (start, end) order
+        differs from the scoring order somewhere (equal starts with decreasing ends)."""
+        gs = np.ascontiguousarray(gene_start, dtype=np.int64)
+        ge = np.ascontiguousarray(gene_end, dtype=np.int64)
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(self._lib.gecco_crf_packed_order_info(self._h, gs.ctypes.data, ge.ctypes.data, min(gs.size, ge.size), ctypes.byref(a),
+                                                     ctypes.byref(b)))
+        return bool(a.value), bool(b.value)
+
     def cluster_rows(self, seg, seg_p, seg_off, gene_end, feature_end) -> dict:
         """Columns of clusters.tsv for `seg` rows: dict of numpy arrays and (data, offsets) string columns."""
         seg = np.ascontiguousarray(seg, dtype=np.int32).reshape(-1, 4)
@@ -678,6 +691,16 @@ def tsv_format(header: str, columns) -> bytes:
         return ctypes.string_at(out.value, out_len.value)
     finally:
         lib.gecco_crf_buffer_free(out)
+
+
+def gather_f64(src: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """src[idx] on several host threads (`gecco_crf_gather_f64`; idx int32, src float64)."""
+    src = np.ascontiguousarray(src, dtype=np.float64)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    out = np.empty(idx.size, dtype=np.float64)
+    if idx.size:
+        _check(load_library().gecco_crf_gather_f64(src.ctypes.data, src.size, idx.ctypes.data, idx.size, out.ctypes.data))
+    return out
 
 
 def exact_mean(values) -> float:

@@ -881,6 +881,20 @@ GECCO_API int gecco_crf_cluster_rows_strings(const gecco_crf_cluster_rows *r, in
     return GECCO_CRF_OK;
 }
 GECCO_API double gecco_crf_exact_mean(const double *v, int64_t n) { return (v && n > 0) ? exact_mean(v, n) : std::nan(""); }
+GECCO_API int gecco_crf_gather_f64(const double *src, int64_t n_src, const int32_t *idx, int64_t n, double *out) {
+    if (n < 0 || n_src < 0 || (n > 0 && (!src || !idx || !out))) return GECCO_CRF_EINVAL;
+    GECCO_GUARD_BEGIN
+    return gather_f64(src, n_src, idx, n, out);
+    GECCO_GUARD_END
+}
+GECCO_API int gecco_crf_packed_order_info(const gecco_crf_packed *p, const int64_t *gene_start, const int64_t *gene_end, int64_t n_gene_rows,
+                                          int32_t *rows_in_order, int32_t *refiner_order_differs) {
+    if (!p || !rows_in_order || !refiner_order_differs || n_gene_rows < 0 || (p->p.n_genes > 0 && (!gene_start || !gene_end)))
+        return GECCO_CRF_EINVAL;
+    GECCO_GUARD_BEGIN
+    return order_info(p->p, gene_start, gene_end, n_gene_rows, rows_in_order, refiner_order_differs);
+    GECCO_GUARD_END
+}
 
 GECCO_API int gecco_crf_tsv_format(int64_t n_rows, int32_t n_cols, const int32_t *kinds, const void *const *data,
                                    const int64_t *const *offsets, const char *header, uint8_t **out, int64_t *out_len) {

@@ -62,6 +62,13 @@ int pack_columns(const Model &m, const gecco_crf_table_columns &t, Packed &out);
 int cluster_rows(const Packed &pk, const gecco_crf_table_columns &t, const int64_t *gene_end, const int64_t *feat_end,
                  const int32_t *seg, int32_t n_seg, const double *seg_p, const int64_t *seg_off, ClusterRows &out);
 double exact_mean(const double *v, int64_t n);
+// out[i] = src[idx[i]] (idx in [0, n_src)), several host threads: the feature table's `cluster_probability` column
+int gather_f64(const double *src, int64_t n_src, const int32_t *idx, int64_t n, double *out);
+// What the output tables need to know of the scoring order (gene table rows given): are the genes' rows 0 .. n - 1 in order
+// (the gene table can be handed back as it is), and do two genes of a contig share a start with their ends in decreasing
+// order (the refiner's (start, end) order then differs from the scoring order, gecco/refine.py:190)?
+int order_info(const Packed &pk, const int64_t *gene_start, const int64_t *gene_end, int64_t n_gene_rows, int32_t *rows_in_order,
+               int32_t *refiner_order_differs);
 int format_tsv(int64_t n_rows, int32_t n_cols, const int32_t *kinds, const void *const *data, const int64_t *const *offsets,
                const char *header, uint8_t **out, int64_t *out_len);
 

@@ -399,6 +399,14 @@ int gecco_crf_cluster_rows_strings(const gecco_crf_cluster_rows *r, int32_t whic
 /* statistics.mean of the non-NaN values: the exact sum divided by the count, rounded once.  Any finite doubles of either
  * sign; infinite values follow float arithmetic (inf, -inf, NaN for both signs); NaN when there is no value. */
 double gecco_crf_exact_mean(const double *v, int64_t n);
+/* Output columns of the columnar path, on several host threads (ABI 2.2.1).  gather: out[i] = src[idx[i]] -- the feature
+ * table's `cluster_probability` is its genes' probabilities (gecco/crf/features.py:92-96).  order_info, given the gene table's
+ * `start` / `end` columns: rows_in_order = the genes in scoring order are the gene table's rows 0 .. n - 1 (the table can be
+ * handed back as it is); refiner_order_differs = two genes of a contig share a start with their ends in decreasing order, so the
+ * refiner's (start, end) order (gecco/refine.py:190) is not the CRF's (contig, start) order (gecco/crf/__init__.py:199). */
+int gecco_crf_gather_f64(const double *src, int64_t n_src, const int32_t *idx, int64_t n, double *out);
+int gecco_crf_packed_order_info(const gecco_crf_packed *p, const int64_t *gene_start, const int64_t *gene_end, int64_t n_gene_rows,
+                                int32_t *rows_in_order, int32_t *refiner_order_differs);
 /* TSV text of a table, the wire format either side of the path (gecco/_base.py:133-152): `header` first, then
  * n_rows lines of tab-separated cells.  kinds[c]: 0 text (data[c] bytes + offsets[c]), 1 int64, 2 float64; floats
  * are written with the shortest digits that round-trip, laid out as Python's repr() does, NaN as an empty field.

@@ -923,3 +923,51 @@ def test_hip_runtime_preload_is_gated_on_the_soname(monkeypatch):
     if importlib.util.find_spec("torch") is not None:
         assert got is None
         assert any("libamdhip64.so.6" in str(c.message) and "keeping the system" in str(c.message) for c in caught)
+
+
+def test_native_order_info_and_gather_equal_the_numpy_passes(monkeypatch):
+    """`gecco_crf_packed_order_info` / `gecco_crf_gather_f64` (several host threads) against the numpy passes of predict_tables they
+    replaced: gene rows in order or not, ties on (contig, start) with increasing / decreasing ends, many thread ranges."""
+    from gecco_amd import _native as nat, predict, tables
+
+    monkeypatch.setenv("GECCO_CRF_HOST_THREADS", "7")
+    monkeypatch.setenv("GECCO_CRF_HOST_GRAIN", "1")
+    model = nat.Model.from_tables(np.zeros((4, 2)), np.zeros((2, 2)))
+    S = tables.StringColumn.from_sequence
+    rng = np.random.default_rng(11)
+    seen = set()
+    for trial in range(60):
+        nc = int(rng.integers(1, 6))
+        sids, pids, starts, ends = [], [], [], []
+        for c in range(nc):
+            ng = int(rng.integers(1, 40))
+            st = np.sort(rng.integers(0, 40 if trial % 3 else 10 ** 6, size=ng)) * 10  # (few distinct starts: ties)
+            for i in range(ng):
+                sids.append(f"ctg{c}")
+                pids.append(f"c{c}_g{i}")
+                starts.append(int(st[i]))
+                ends.append(int(st[i] + rng.integers(1, 50)))
+        n = len(pids)
+        perm = np.arange(n) if trial % 2 == 0 else rng.permutation(n)  # gene table rows in scoring order or shuffled
+        if trial % 4 == 1:  # stable sort by start keeps the row order among ties: make rows sorted but contigs interleaved
+            perm = np.argsort(np.array(sids)[rng.permutation(n)], kind="stable")
+        sids, pids = [sids[i] for i in perm], [pids[i] for i in perm]
+        starts, ends = np.array(starts, dtype=np.int64)[perm], np.array(ends, dtype=np.int64)[perm]
+        fi = np.sort(rng.integers(0, n, size=max(1, n)))
+        pk = nat.PackedTables(model, S([sids[i] for i in fi]), S([pids[i] for i in fi]), starts[fi], S(["PF00001"] * len(fi)),
+                              rng.integers(0, 300, size=len(fi)).astype(np.int64), S(sids), S(pids), starts)
+        rows = pk.gene_row
+        assert rows.min() >= 0 and pk.n_genes == n
+        exp_in_order = bool(rows[0] == 0 and np.all(np.diff(rows) == 1))
+        code = np.repeat(np.arange(pk.n_contigs), np.diff(pk.contig_ptr))
+        exp_differs = predict._refiner_order_differs(code, starts[rows], ends[rows])
+        assert pk.order_info(starts, ends) == (exp_in_order, exp_differs)
+        seen.add((exp_in_order, exp_differs))
+        p = rng.random(n)
+        p[rng.random(n) < 0.1] = np.nan
+        got = nat.gather_f64(p, pk.row_gene)
+        np.testing.assert_array_equal(got, p[pk.row_gene])
+    assert len(seen) == 4  # every combination occurred
+    with pytest.raises(ValueError):
+        nat.gather_f64(np.zeros(3), np.array([0, 3], dtype=np.int32))
+    assert nat.gather_f64(np.zeros(3), np.zeros(0, dtype=np.int32)).shape == (0,)
