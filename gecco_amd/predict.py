@@ -119,7 +119,12 @@ def predict_tables(genes_t: tables.GeneTable, feats_t: tables.FeatureTable, crf:
     in_order, reorder = have_row and n == 0, None
     if have_row and n:
         g_start_all = np.asarray(genes_t.start, dtype=np.int64)
-        in_order, differs = pk.order_info(g_start_all, g_end_all)
+        if os.environ.get("GECCO_AMD_TABLES_NUMPY_PASSES") == "1":  # A/B switch: the numpy passes of round 5
+            in_order = len(genes_t) == n and rows[0] == 0 and bool(np.all(np.diff(rows) == 1))
+            differs = _refiner_order_differs(np.repeat(np.arange(pk.n_contigs), lengths), g_start_all if in_order else g_start_all[rows],
+                                             g_end_all if in_order else g_end_all[rows])
+        else:
+            in_order, differs = pk.order_info(g_start_all, g_end_all)
         if differs:
             g_start_o = g_start_all if in_order else g_start_all[rows]
             g_end_o = g_end_all if in_order else g_end_all[rows]
@@ -161,7 +166,10 @@ def predict_tables(genes_t: tables.GeneTable, feats_t: tables.FeatureTable, crf:
 
     # ---- features table: every domain row carries its gene's probability (features.py:92-96)
     fcols = dict(feats_t.columns)
-    fcols["cluster_probability"] = _native.gather_f64(p, pk.row_gene) if pk.n_rows else np.zeros(0)
+    if os.environ.get("GECCO_AMD_TABLES_NUMPY_PASSES") == "1":
+        fcols["cluster_probability"] = p[pk.row_gene] if pk.n_rows else np.zeros(0)
+    else:
+        fcols["cluster_probability"] = _native.gather_f64(p, pk.row_gene) if pk.n_rows else np.zeros(0)
     feats_out = tables.FeatureTable(fcols)
 
     # ---- clusters table (gecco/model.py:731-760)
