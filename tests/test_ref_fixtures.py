@@ -125,3 +125,20 @@ def test_oracle_composition_equals_the_reference():
             weights = [1 - (d[2] if pvalue else d[1]) for g in case["genes"] for d in g]
             got = oc.domain_composition(names, weights, case["all_possible"], normalize=normalize)
             assert np.asarray(got, dtype=np.float64).tobytes() == np.asarray(exp, dtype=np.float64).tobytes()
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/gecco"), reason="build container only: needs the reference's sources")
+def test_committed_fixtures_are_what_the_generator_writes_today(tmp_path):
+    """Where the reference is present (the build container), `tools/gen_reference_fixtures.py` is run again and must write the
+    committed files byte for byte: the vectors under tests/golden/ ARE the reference's outputs, not an edited copy."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cp = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_reference_fixtures.py"), "--out", str(tmp_path)], capture_output=True,
+                        text=True, timeout=600, cwd=root)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    for name in ("ref_predict_probabilities", "ref_refiner", "ref_composition"):
+        with open(tmp_path / f"{name}.json.gz", "rb") as a, open(os.path.join(root, "tests", "golden", f"{name}.json.gz"), "rb") as b:
+            assert a.read() == b.read(), name
